@@ -1,0 +1,81 @@
+"""ctypes binding of libarcflow_hip.so (include/arcflow_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails this
+module raises.  Build it with ``python -m arcflow_amd.build`` (or ``__graft_entry__.build()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import lib_path
+
+AFX_DT_BF16 = 1
+AFX_DT_F32 = 2
+
+EXPORTS = [
+    'afx_last_error', 'afx_version', 'afx_create', 'afx_destroy', 'afx_bind_weight', 'afx_finalize',
+    'afx_workspace_bytes', 'afx_set_workspace', 'afx_mmdit_forward', 'afx_profile_enable', 'afx_profile_read', 'afx_arcflow_step',
+    'afx_arcflow_velocity', 'afx_linear_bf16', 'afx_attention_ws_bytes', 'afx_attention_bf16',
+    'afx_norm_modulate_bf16', 'afx_qk_norm_rope_bf16', 'afx_gemv_bf16',
+]
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        'family', 'num_double', 'num_single', 'heads', 'head_dim', 'in_channels', 'joint_dim',
+        'pooled_dim', 'guidance_embeds', 'num_gaussians', 'logweights_channels', 'head_mode')]
+
+
+class ArcflowHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen the engine; raises ArcflowHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.environ.get('ARCFLOW_HIP_LIB', lib_path())
+    if not os.path.exists(path):
+        raise ArcflowHipError(
+            f'{path} not found: the HIP engine is not built. Run `python -m arcflow_amd.build` '
+            '(needs hipcc, cross-compiles for gfx950 without a GPU). There is no CPU fallback.')
+    lib = C.CDLL(path)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    lib.afx_last_error.restype = C.c_char_p
+    lib.afx_version.restype = C.c_char_p
+    lib.afx_create.argtypes = [C.POINTER(ModelDesc), C.POINTER(vp)]
+    lib.afx_destroy.argtypes = [vp]
+    lib.afx_bind_weight.argtypes = [vp, C.c_char_p, vp, i32, i32, C.POINTER(i64)]
+    lib.afx_finalize.argtypes = [vp]
+    lib.afx_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    lib.afx_workspace_bytes.restype = i64
+    lib.afx_set_workspace.argtypes = [vp, vp, i64]
+    lib.afx_mmdit_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.afx_profile_enable.argtypes = [vp, i32]
+    lib.afx_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
+    lib.afx_arcflow_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp, i32, i32, i32, i32, i32, vp]
+    lib.afx_arcflow_velocity.argtypes = [vp, vp, vp, i32, f32, f32, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.afx_linear_bf16.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, i32, vp, i64, vp]
+    lib.afx_attention_ws_bytes.argtypes = [i32, i32, i32]
+    lib.afx_attention_ws_bytes.restype = i64
+    lib.afx_attention_bf16.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.afx_norm_modulate_bf16.argtypes = [vp, i64, vp, i64, i32, i32, vp, vp, i64, i32, i32, vp]
+    lib.afx_qk_norm_rope_bf16.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    lib.afx_gemv_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int:       # default restype: status code
+            fn.restype = C.c_int32
+    _lib = lib
+    return lib
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise ArcflowHipError(f'libarcflow_hip error {rc}: {load().afx_last_error().decode()}')

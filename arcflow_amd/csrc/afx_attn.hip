@@ -1,0 +1,238 @@
+// Joint (text+image) flash attention forward for gfx950, head_dim = 128, bf16 in/out, no mask.
+//
+// Both contractions are computed TRANSPOSED so that the softmax row is lane-local:
+//     S^T = K . Q^T          (A operand = K rows,   B operand = Q rows)   D[key  ][query]
+//     O^T = V^T . P^T        (A operand = V^T rows, B operand = P^T)      D[d    ][query]
+// With v_mfma_f32_32x32x16_bf16 the D layout is  col = lane & 31, row = (r&3) + 8*(r>>2) + 4*(lane>>5),
+// so lane (q, hi) owns query q of the wave's 32-query slab in BOTH products: the row max / sum, the
+// rescale of O and the final 1/l are plain per-lane VALU work, no cross-lane traffic except one
+// xor-32 exchange of the tile max.  The exponentiated scores of lane (q, hi) are exactly the B
+// operand of the second product if the key order inside every 16-key group is permuted
+//     position p = hi*8 + j   <->   key  4*hi + (j & 3) + 8*(j >> 2),
+// and the sum over keys does not care about order -- so V is pre-transposed ONCE per layer into
+// V^T[b][h][d][S_pad] with that permutation applied (launch_v_transpose), and the main kernel needs
+// no transpose reads, no LDS round trip for P and no permlane traffic.
+//
+// Work-group = 4 waves x 32 queries; K tile [64 keys][128 d] and V^T tile [128 d][64 keys] stream
+// HBM -> LDS by LDS-DMA into a 2-stage ring with an XOR swizzle (conflict-free ds_read_b128 reads).
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+constexpr int HD = 128;            // head dim
+constexpr int KVB = 64;            // keys per tile
+constexpr int QW = 32;             // queries per wave
+constexpr int ATT_WAVES = 4;
+constexpr int ATT_THREADS = ATT_WAVES * 64;
+constexpr int QB = ATT_WAVES * QW; // queries per work-group
+constexpr int STAGE_BYTES = 2 * KVB * HD * 2;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// position p (0..15) inside a 16-key group -> key offset inside the group
+AFX_DEV int key_of_pos(int p) { return 4 * (p >> 3) + (p & 3) + 8 * ((p >> 2) & 1); }
+
+// ---------------------------------------------------------------------------------------------
+// V [B*S rows, ldv] (head h at column h*128)  ->  Vt [B][H][128][S_pad], keys permuted per 16-group,
+// keys >= S zero-filled.
+__global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v, int64_t ldv,
+                                                          bf16_t* __restrict__ vt, int H, int S, int S_pad) {
+  __shared__ bf16_t tile[KVB][HD + 2];
+  const int kv0 = blockIdx.x * KVB, h = blockIdx.y, b = blockIdx.z;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = i * 256 + tid;
+    const int r = p >> 4, c = p & 15;
+    u32x4_t w = (u32x4_t){0u, 0u, 0u, 0u};
+    if (kv0 + r < S) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * S + kv0 + r) * ldv + h * HD + c * 8);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&tile[r][c * 8]);   // (HD+2)*2 = 260 B rows: 4-byte aligned
+    dst[0] = w[0]; dst[1] = w[1]; dst[2] = w[2]; dst[3] = w[3];
+  }
+  __syncthreads();
+  bf16_t* out = vt + ((int64_t)(b * H + h) * HD) * S_pad + kv0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int d = i * 32 + (tid >> 3);
+    const int c = tid & 7;                          // 8 consecutive storage positions c*8 .. c*8+7
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int p0 = c * 8 + 2 * e, p1 = p0 + 1;
+      const int k0 = (p0 >> 4) * 16 + key_of_pos(p0 & 15);
+      const int k1 = (p1 >> 4) * 16 + key_of_pos(p1 & 15);
+      w[e] = (uint32_t)tile[k0][d] | ((uint32_t)tile[k1][d] << 16);
+    }
+    *reinterpret_cast<u32x4_t*>(out + (int64_t)d * S_pad + c * 8) = (u32x4_t){w[0], w[1], w[2], w[3]};
+  }
+}
+
+hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
+                              hipStream_t stream) {
+  const int S_pad = (int)attn_spad(S);
+  hipLaunchKernelGGL(v_transpose_kernel, dim3(S_pad / KVB, H, B), dim3(256), 0, stream, v, ldv, vt, H, S, S_pad);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
+    const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
+    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad) {
+  // two stages of { K tile [64][128] | V^T tile [128][64] }, 16 KiB each -> 64 KiB
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int q0 = blockIdx.x * QB + wave * QW;
+  const int qrow = min(q0 + ql, S - 1);
+  const int ntiles = S_pad / KVB;
+
+  const bf16_t* qp = q + ((int64_t)b * S + qrow) * ldq + h * HD;
+  const bf16_t* kbase = k + (int64_t)b * S * ldk + h * HD;
+  const bf16_t* vbase = vt + ((int64_t)(b * H + h) * HD) * S_pad;
+
+  // Q^T fragments (B operand): query ql, d = 16*step + 8*hi .. +7
+  bf16x8_t qf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16 + hi * 8);
+
+  f32x16_t oacc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+
+  // K / V^T tiles go HBM -> LDS by LDS-DMA (16 B per lane, lane-linear destination), double
+  // buffered; the XOR swizzle is applied to the per-lane SOURCE chunk and undone by the readers.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto stage_tile = [&](int t, int buf) {
+    const int kv0 = t * KVB;
+    char* kd = smem + buf * STAGE_BYTES;
+    char* vd = kd + KVB * HD * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = i * ATT_THREADS + tid;
+      const int r = p >> 4, cp = p & 15;
+      const int kr = min(kv0 + r, S - 1);
+      const bf16_t* ksrc = kbase + (int64_t)kr * ldk + ((cp ^ (r & 15)) << 3);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      const int d = p >> 3, vp = p & 7;
+      const bf16_t* vsrc = vbase + (int64_t)d * S_pad + kv0 + ((vp ^ ((d >> 1) & 7)) << 3);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)vsrc, (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+    }
+  };
+
+  stage_tile(0, 0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* ks = smem + (t & 1) * STAGE_BYTES;
+    const char* vs = ks + KVB * HD * 2;
+    if (t + 1 < ntiles) stage_tile(t + 1, (t + 1) & 1);   // DMA of the next tile runs under this tile's MFMAs
+
+    // ---- S^T = K Q^T : two 32-key blocks ---------------------------------------------------
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+      const int krow = kb * 32 + ql;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int chunk = (s * 2 + hi) ^ (krow & 15);
+        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ks + krow * 256 + (chunk << 4));
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+      }
+    }
+    // mask keys past the end of the sequence (last tile only)
+    if (t == ntiles - 1 && S_pad != S) {
+      const int kv0 = t * KVB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= S) sacc[kb][r] = -INFINITY;
+        }
+    }
+    // ---- online softmax (per lane = per query) ------------------------------------------------
+    float mt = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float psum = 0.f;
+    bf16x8_t pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ksub = 0; ksub < 2; ++ksub) {
+        float pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          pv[j] = __builtin_amdgcn_exp2f(sacc[kb][ksub * 8 + j] * c - mc);
+          psum += pv[j];
+        }
+        const u32x4_t w = pack8(pv);
+        pf[kb][ksub] = __builtin_bit_cast(bf16x8_t, w);
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----------------------------------------------------------------------
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int vrow = d * 32 + ql;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ksub = 0; ksub < 2; ++ksub) {
+          const int chunk = (kb * 4 + ksub * 2 + hi) ^ ((vrow >> 1) & 7);
+          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vs + vrow * 128 + (chunk << 4));
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kb][ksub], oacc[d], 0, 0, 0);
+        }
+    }
+
+    __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done reading this one
+  }
+
+  // ---- normalise and store: lane (q, hi) holds O[q][32*d + 8*g + 4*hi + 0..3] -------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (q0 + ql < S) {
+    bf16_t* op = o + ((int64_t)b * S + q0 + ql) * ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + g * 8 + hi * 4) = w;
+      }
+  }
+}
+
+hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                            const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
+                            hipStream_t stream) {
+  const int S_pad = (int)attn_spad(S);
+  dim3 grid((S + QB - 1) / QB, H, B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -1,0 +1,70 @@
+// Shared device helpers for the ArcFlow gfx950 kernels (wave64, bf16 storage, fp32 math).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afx {
+
+typedef uint16_t bf16_t;                                             // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;         // MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;           // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;         // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;        // 16-byte memory word
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+
+#define AFX_DEV __device__ __forceinline__
+
+AFX_DEV float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
+AFX_DEV bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+AFX_DEV uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+AFX_DEV void unpack8(const u32x4_t& w, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __uint_as_float(w[i] << 16);
+    f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+
+AFX_DEV u32x4_t pack8(const float (&f)[8]) {
+  u32x4_t w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return w;
+}
+
+AFX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+AFX_DEV float gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))), tanh(u) = 1 - 2/(exp(2u)+1)
+  const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+
+AFX_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware bijective remap of a 1-D grid: block b runs on XCD b%8; give every XCD a contiguous
+// chunk of logical work-group ids so neighbouring tiles share that XCD's L2.
+AFX_DEV int xcd_remap(int bid, int nwg) {
+  const int nx = 8;
+  const int q = nwg / nx, r = nwg % nx, x = bid % nx;
+  const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + bid / nx;
+}
+
+}  // namespace afx

@@ -1,0 +1,365 @@
+// HBM-bound helper kernels of the MMDiT trunk and the ArcFlow policy math (gfx950, wave64).
+// Everything here streams 16 B per lane and reduces with wave shuffles; fp32 math, bf16 storage.
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// ------------------------------------------------------------------------------------------------
+// AdaLN modulate:  out = LN(x) * (1 + scale[b]) + shift[b]      (LN: no affine, eps 1e-6)
+// RMS mode:        out = x * rsqrt(mean(x^2) + 1e-6) * scale    (scale = weight vector)
+// One wave per row, D <= 4096, D % 8 == 0; each lane owns chunks lane, lane+64, ... of 8 elements.
+constexpr int NM_MAX_CHUNKS = 8;
+
+__global__ __launch_bounds__(256) void norm_modulate_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int rows, int D,
+    const float* __restrict__ scale, const float* __restrict__ shift, int64_t ldmod, int rows_per_batch,
+    int rms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 3;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  float v[NM_MAX_CHUNKS][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      const u32x4_t w = *reinterpret_cast<const u32x4_t*>(xr + c * 8);
+      unpack8(w, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += rms ? v[i][e] * v[i][e] : v[i][e];
+    }
+  }
+  s = wave_sum(s);
+  float mean = 0.f, rstd;
+  if (rms) {
+    rstd = rsqrtf(s / (float)D + 1e-6f);
+  } else {
+    mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NM_MAX_CHUNKS; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mean;
+          q += d * d;
+        }
+      }
+    }
+    q = wave_sum(q);
+    rstd = rsqrtf(q / (float)D + 1e-6f);
+  }
+  const int64_t moff = rms ? 0 : (int64_t)(row / rows_per_batch) * ldmod;
+  bf16_t* orow = out + (int64_t)row * ldo;
+#pragma unroll
+  for (int i = 0; i < NM_MAX_CHUNKS; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(scale + moff + c * 8);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(scale + moff + c * 8 + 4);
+      const float sc[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+      float r[8];
+      if (rms) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = v[i][e] * rstd * sc[e];
+      } else {
+        const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(shift + moff + c * 8);
+        const f32x4_t h1 = *reinterpret_cast<const f32x4_t*>(shift + moff + c * 8 + 4);
+        const float sh[8] = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (v[i][e] - mean) * rstd * (1.0f + sc[e]) + sh[e];
+      }
+      *reinterpret_cast<u32x4_t*>(orow + c * 8) = pack8(r);
+    }
+  }
+}
+
+hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,
+                                int D, const float* scale, const float* shift, int64_t ldmod,
+                                int rows_per_batch, int rms, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (D > NM_MAX_CHUNKS * 512 || (D & 7)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows,
+                     D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, rms);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// In-place per-head RMSNorm(128, weight) + interleaved-pair RoPE.  16 lanes x 8 elements = one
+// (token, head); the 4 rotation pairs of a lane stay inside its own 16-byte chunk.
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(
+    bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w_txt, const float* __restrict__ w_img,
+    const float* __restrict__ cos_t, const float* __restrict__ sin_t, int S, int n_txt, int H, int64_t total) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (row, head, chunk)
+  if (g >= total) return;                                         // total % 16 == 0: whole groups exit together
+  const int c = (int)(g & 15);
+  const int64_t th = g >> 4;
+  const int h = (int)(th % H);
+  const int64_t row = th / H;
+  const int s = (int)(row % S);
+  bf16_t* p = x + row * ldx + h * 128 + c * 8;
+  float v[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(p), v);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+  const float* w = (s < n_txt ? w_txt : w_img) + c * 8;
+  const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(w);
+  const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(w + 4);
+  const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+  const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cos_t + (int64_t)s * 64 + c * 4);
+  const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(sin_t + (int64_t)s * 64 + c * 4);
+  float r[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a = v[2 * i] * rstd * wv[2 * i];
+    const float b = v[2 * i + 1] * rstd * wv[2 * i + 1];
+    r[2 * i] = a * cs[i] - b * sn[i];
+    r[2 * i + 1] = a * sn[i] + b * cs[i];
+  }
+  *reinterpret_cast<u32x4_t*>(p) = pack8(r);
+}
+
+hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, const float* w_img,
+                               const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
+                               hipStream_t stream) {
+  const int64_t total = (int64_t)B * S * H * 16;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, ldx,
+                     w_txt, w_img, cos_t, sin_t, S, n_txt, H, total);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny GEMV  y[b,n] (+)= act(sum_k x[b,k] W[n,k] + bias[n])  -- one wave per weight row, the row is
+// streamed once (16 B per lane per load) and reused for every batch row (B <= 8).  HBM-bound on W.
+constexpr int GEMV_MAXB = 8;
+
+__global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
+                                                   const bf16_t* __restrict__ bias, float* __restrict__ y,
+                                                   int B, int N, int K, int act, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const bf16_t* wr = W + (int64_t)n * K;
+  float acc[GEMV_MAXB];
+#pragma unroll
+  for (int b = 0; b < GEMV_MAXB; ++b) acc[b] = 0.f;
+  for (int c = lane; c < (K >> 3); c += 64) {
+    float w[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(wr + c * 8), w);
+#pragma unroll
+    for (int b = 0; b < GEMV_MAXB; ++b) {
+      if (b < B) {
+        const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(x + (int64_t)b * K + c * 8);
+        const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(x + (int64_t)b * K + c * 8 + 4);
+        acc[b] += w[0] * x0[0] + w[1] * x0[1] + w[2] * x0[2] + w[3] * x0[3] + w[4] * x1[0] + w[5] * x1[1] +
+                  w[6] * x1[2] + w[7] * x1[3];
+      }
+    }
+  }
+  const float bv = bias ? bf16_to_f32(bias[n]) : 0.f;
+#pragma unroll
+  for (int b = 0; b < GEMV_MAXB; ++b) {
+    if (b < B) {
+      float r = wave_sum(acc[b]) + bv;
+      if (act == 1) r = silu(r);
+      if (lane == 0) {
+        float* yp = y + (int64_t)b * N + n;
+        *yp = accumulate ? (*yp + r) : r;
+      }
+    }
+  }
+}
+
+hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
+                       int K, int act, int accumulate, hipStream_t stream) {
+  if (B > GEMV_MAXB || (K & 7)) return hipErrorInvalidValue;
+  if (N == 0 || B == 0) return hipSuccess;
+  hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, W, bias, y, B, N, K, act, accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(a) | sin(a)],
+// a_i = scale * t_b * exp(-ln(1e4) * i / 128)
+__global__ void sincos_kernel(const float* __restrict__ t, float scale, float* __restrict__ out, int B) {
+  const int i = threadIdx.x;        // 0..127
+  const int b = blockIdx.x;
+  if (b >= B) return;
+  const float f = expf(-9.210340371976184f * (float)i / 128.0f);
+  const float a = scale * (t[b] * f);
+  out[b * 256 + i] = cosf(a);
+  out[b * 256 + 128 + i] = sinf(a);
+}
+hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream) {
+  hipLaunchKernelGGL(sincos_kernel, dim3(B), dim3(128), 0, stream, t, scale, out, B);
+  return hipGetLastError();
+}
+
+__global__ void silu_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = silu(x[i]);
+}
+hipError_t launch_silu(const float* x, float* y, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(silu_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+  return hipGetLastError();
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = bf16_to_f32(x[i]);
+}
+hipError_t launch_bf16_to_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, y, n);
+  return hipGetLastError();
+}
+
+// rows x cols bf16 copy between strided buffers (cols % 8 == 0)
+__global__ void copy_rows_kernel(const bf16_t* __restrict__ src, int64_t lds_, bf16_t* __restrict__ dst,
+                                 int64_t ldd, int64_t rows, int cols) {
+  const int cpr = cols >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= rows * cpr) return;
+  const int64_t r = g / cpr;
+  const int c = (int)(g % cpr);
+  *reinterpret_cast<u32x4_t*>(dst + r * ldd + c * 8) = *reinterpret_cast<const u32x4_t*>(src + r * lds_ + c * 8);
+}
+hipError_t launch_copy_rows(const uint16_t* src, int64_t lds_, uint16_t* dst, int64_t ldd, int64_t rows,
+                            int cols, hipStream_t stream) {
+  const int64_t total = rows * (cols >> 3);
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, src, lds_,
+                     dst, ldd, rows, cols);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Velocity head split (arcflux.py:243-249): head row = [means K*ch | logw K*lw | logg (K-1)*lw | pad];
+// means and logg are copied, logw gets log_softmax over K (fp32 math on the bf16 logits, bf16 out).
+__global__ __launch_bounds__(256) void head_split_kernel(const bf16_t* __restrict__ head, int64_t ldh,
+                                                         bf16_t* __restrict__ means, bf16_t* __restrict__ logw,
+                                                         bf16_t* __restrict__ logg, int64_t rows, int K, int ch,
+                                                         int lw) {
+  const int64_t row = blockIdx.x;
+  const bf16_t* hr = head + row * ldh;
+  const int nm = K * ch, nw = K * lw, ng = (K - 1) * lw;
+  for (int i = threadIdx.x; i < nm; i += 256) means[row * nm + i] = hr[i];
+  for (int i = threadIdx.x; i < ng; i += 256) logg[row * ng + i] = hr[nm + nw + i];
+  if (threadIdx.x < lw) {
+    const int p = threadIdx.x;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, bf16_to_f32(hr[nm + k * lw + p]));
+    float se = 0.f;
+    for (int k = 0; k < K; ++k) se += expf(bf16_to_f32(hr[nm + k * lw + p]) - mx);
+    const float lse = mx + logf(se);
+    for (int k = 0; k < K; ++k) logw[row * nw + k * lw + p] = f32_to_bf16(bf16_to_f32(hr[nm + k * lw + p]) - lse);
+  }
+}
+hipError_t launch_head_split(const uint16_t* head, int64_t ldh, uint16_t* means, uint16_t* logw,
+                             uint16_t* logg, int64_t rows, int K, int ch, int lw, hipStream_t stream) {
+  if (rows == 0) return hipSuccess;
+  hipLaunchKernelGGL(head_split_kernel, dim3((unsigned)rows), dim3(256), 0, stream, head, ldh, means, logw, logg,
+                     rows, K, ch, lw);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// ArcFlow analytic step in the token layout (arcflux_pipeline.py:195-249 + the (un)pack permutes):
+// one wave per token, lane = packed channel (ch = C*p*p = 64 for FLUX/Qwen), the K mixture terms are
+// walked in registers.  21 MB of traffic per 1024^2 step -> pure HBM streaming.
+template <typename MixT> AFX_DEV float mix_load(const MixT* p, int64_t i);
+template <> AFX_DEV float mix_load<float>(const float* p, int64_t i) { return p[i]; }
+template <> AFX_DEV float mix_load<bf16_t>(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+
+constexpr int ARC_MAXK = 32;
+
+template <typename MixT>
+__global__ __launch_bounds__(256) void arcflow_step_kernel(
+    const float* __restrict__ x_in, const MixT* __restrict__ means, const MixT* __restrict__ logw,
+    const MixT* __restrict__ logg, float s_src, float s_start, float s_end,
+    const float* __restrict__ sigma_vec, float eps, float* __restrict__ x_out, int64_t tokens, int n_tok, int K,
+    int ch, int pp, int velocity_only) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  if (sigma_vec != nullptr) {
+    const int64_t b = tok / n_tok;
+    s_src = sigma_vec[3 * b];
+    s_start = sigma_vec[3 * b + 1];
+    s_end = sigma_vec[3 * b + 2];
+  }
+  const float d_past = s_src - s_start;
+  const float d_step = s_start - s_end;
+  const MixT* mt = means + tok * (int64_t)K * ch;
+  const MixT* wt = logw + tok * (int64_t)K * pp;
+  const MixT* gt = logg + tok * (int64_t)(K - 1) * pp;
+  for (int c = lane; c < ch; c += 64) {
+    const int q = c % pp;
+    float lw[ARC_MAXK];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < ARC_MAXK; ++k)
+      if (k < K) {
+        lw[k] = mix_load<MixT>(wt, k * pp + q);
+        mx = fmaxf(mx, lw[k]);
+      }
+    float den = 0.f;
+#pragma unroll
+    for (int k = 0; k < ARC_MAXK; ++k)
+      if (k < K) {
+        lw[k] = expf(lw[k] - mx);
+        den += lw[k];
+      }
+    const float inv = 1.0f / den;
+    // k = 0: straight-line component (d = phi = 1)
+    float acc = (lw[0] * inv) * mix_load<MixT>(mt, c) * (velocity_only ? 1.0f : d_step);
+#pragma unroll
+    for (int k = 1; k < ARC_MAXK; ++k)
+      if (k < K) {
+        const float g = mix_load<MixT>(gt, (k - 1) * pp + q);
+        const float m = mix_load<MixT>(mt, (int64_t)k * ch + c);
+        const float decay = expf(g * d_past);
+        float term;
+        if (velocity_only) {
+          term = m * decay;
+        } else {
+          const float z = g * d_step;
+          const float zs = (z < 0.f ? -1.0f : 1.0f) * fmaxf(fabsf(z), eps);
+          const float phi = expm1f(zs) / zs;
+          term = m * decay * d_step * phi;
+        }
+        acc += (lw[k] * inv) * term;
+      }
+    const int64_t xi = tok * ch + c;
+    x_out[xi] = velocity_only ? acc : (x_in[xi] - acc);
+  }
+}
+
+hipError_t launch_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg,
+                               int mix_bf16, float s_src, float s_start, float s_end,
+                               const float* sigma_vec, float eps, float* x_out, int B, int n_tok, int K,
+                               int ch, int pp, int velocity_only, hipStream_t stream) {
+  if (K < 1 || K > ARC_MAXK || pp < 1 || ch < 1) return hipErrorInvalidValue;
+  const int64_t tokens = (int64_t)B * n_tok;
+  if (tokens == 0) return hipSuccess;
+  dim3 grid((unsigned)((tokens + 3) / 4)), block(256);
+  if (mix_bf16)
+    hipLaunchKernelGGL(arcflow_step_kernel<bf16_t>, grid, block, 0, stream, x_in, (const bf16_t*)means,
+                       (const bf16_t*)logw, (const bf16_t*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out,
+                       tokens, n_tok, K, ch, pp, velocity_only);
+  else
+    hipLaunchKernelGGL(arcflow_step_kernel<float>, grid, block, 0, stream, x_in, (const float*)means,
+                       (const float*)logw, (const float*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out,
+                       tokens, n_tok, K, ch, pp, velocity_only);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -1,0 +1,546 @@
+// C-ABI layer + MMDiT forward engine (see include/arcflow_hip.h for the contract).
+//
+// The forward is a fixed launch plan over the kernels in afx_gemm / afx_attn / afx_elementwise:
+//   temb MLPs (gemv) -> ONE gemv over all stacked AdaLN modulation linears -> embedders (grouped GEMM)
+//   -> per block { LN+modulate, QKV GEMM (rows k|v|q), RMSNorm+RoPE in place, V transpose,
+//                  flash attention (O overwrites Q), out-proj GEMM with fused gate*x+residual,
+//                  LN+modulate, MLP-up GEMM + GELU, MLP-down GEMM with fused gate*x+residual }
+//   -> norm_out + head GEMM -> log_softmax split.
+// Activations live in the caller-provided workspace in the joint [B][text;image] token layout, so the
+// FLUX single-stream blocks run on the same buffers without a concat, and attention / proj_out read
+// the [O | mlp] operand in place (lda-strided) from the fused QKV+MLP buffer.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/arcflow_hip.h"
+#include "afx_kernels.h"
+
+using namespace afx;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                           \
+  do {                                                                                          \
+    hipError_t e_ = (expr);                                                                     \
+    if (e_ != hipSuccess) return fail(AFX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct Weight {
+  const void* ptr = nullptr;
+  int dtype = 0;
+  std::vector<int64_t> shape;
+};
+
+inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+struct afx_ctx {
+  afx_model_desc d;
+  std::unordered_map<std::string, Weight> w;
+  bool finalized = false;
+  char* ws = nullptr;
+  int64_t ws_bytes = 0;
+  int D = 0;
+  int64_t n_mod = 0;       // rows of the stacked modulation linear
+  int head_n = 0;          // padded head width
+  // optional per-launch-class timing (HIP events on the forward's stream)
+  bool prof_on = false;
+  struct ProfRec { hipEvent_t a, b; int klass; double flops; };
+  std::vector<ProfRec> prof_pool;
+  size_t prof_used = 0;
+};
+
+namespace {
+
+const uint16_t* W16(const afx_ctx* c, const std::string& n) {
+  auto it = c->w.find(n);
+  return it == c->w.end() ? nullptr : (const uint16_t*)it->second.ptr;
+}
+const float* W32(const afx_ctx* c, const std::string& n) {
+  auto it = c->w.find(n);
+  return it == c->w.end() ? nullptr : (const float*)it->second.ptr;
+}
+
+int need(const afx_ctx* c, const std::string& n, int dtype, std::vector<int64_t> shape) {
+  auto it = c->w.find(n);
+  if (it == c->w.end()) return fail(AFX_E_MISSING, "weight '%s' is not bound", n.c_str());
+  if (it->second.dtype != dtype) return fail(AFX_E_INVALID, "weight '%s': wrong dtype", n.c_str());
+  if (it->second.shape != shape) {
+    std::string got, want;
+    for (auto v : it->second.shape) got += std::to_string(v) + ",";
+    for (auto v : shape) want += std::to_string(v) + ",";
+    return fail(AFX_E_INVALID, "weight '%s': shape [%s] expected [%s]", n.c_str(), got.c_str(), want.c_str());
+  }
+  return AFX_OK;
+}
+
+int need_linear(const afx_ctx* c, const std::string& n, int64_t out_f, int64_t in_f) {
+  int r = need(c, n + ".weight", AFX_DT_BF16, {out_f, in_f});
+  if (r) return r;
+  return need(c, n + ".bias", AFX_DT_BF16, {out_f});
+}
+
+// modulation vector offsets inside one row of the stacked modulation output
+struct ModLayout {
+  int64_t D;
+  int nd, ns;
+  int64_t dbl(int i, int stream /*0 img, 1 txt*/, int chunk /*0..5*/) const {
+    return ((int64_t)i * 12 + stream * 6 + chunk) * D;
+  }
+  int64_t sgl(int i, int chunk /*0..2*/) const { return (int64_t)nd * 12 * D + ((int64_t)i * 3 + chunk) * D; }
+  int64_t fin(int chunk /*0 scale, 1 shift*/) const { return (int64_t)nd * 12 * D + (int64_t)ns * 3 * D + chunk * D; }
+  int64_t total() const { return (int64_t)nd * 12 * D + (int64_t)ns * 3 * D + 2 * D; }
+};
+
+struct Workspace {
+  uint16_t *X, *Xn, *F, *Vt, *head;
+  float *sincos, *tmp, *temb, *semb, *mod, *pooled;
+  int64_t total;
+};
+
+Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
+  const int64_t D = c->D, S = (int64_t)N + T, R = (int64_t)B * S;
+  Workspace w;
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  w.X = (uint16_t*)take(R * D * 2);
+  w.Xn = (uint16_t*)take(R * D * 2);
+  w.F = (uint16_t*)take(R * 7 * D * 2);   // single: fused [k|v|q|mlp]; double: [QKV 3D] then [H 4D]
+  w.Vt = (uint16_t*)take((int64_t)B * c->d.heads * 128 * attn_spad((int)S) * 2);
+  w.head = (uint16_t*)take((int64_t)B * N * c->head_n * 2);
+  w.sincos = (float*)take((int64_t)B * 256 * 4);
+  w.tmp = (float*)take((int64_t)B * D * 4);
+  w.temb = (float*)take((int64_t)B * D * 4);
+  w.semb = (float*)take((int64_t)B * D * 4);
+  w.pooled = (float*)take((int64_t)B * (c->d.pooled_dim > 0 ? c->d.pooled_dim : 8) * 4);
+  w.mod = (float*)take((int64_t)B * c->n_mod * 4);
+  w.total = off;
+  return w;
+}
+
+// RAII-free scoped timer: records an event pair around one launch when profiling is enabled.
+struct ProfScope {
+  afx_ctx* c; hipStream_t st; afx_ctx::ProfRec* r = nullptr;
+  ProfScope(afx_ctx* c_, hipStream_t st_, int klass, double flops) : c(c_), st(st_) {
+    if (!c->prof_on) return;
+    if (c->prof_used == c->prof_pool.size()) {
+      afx_ctx::ProfRec n{};
+      if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
+      c->prof_pool.push_back(n);
+    }
+    r = &c->prof_pool[c->prof_used++];
+    r->klass = klass; r->flops = flops;
+    (void)hipEventRecord(r->a, st);
+  }
+  ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
+};
+
+double gemm_flops(const GemmBatch& gb) {
+  double f = 0;
+  for (int i = 0; i < gb.nprob; ++i) f += 2.0 * gb.p[i].M * (double)gb.p[i].N * gb.p[i].K;
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* afx_last_error(void) { return g_err; }
+const char* afx_version(void) { return "arcflow_hip 0.1 (gfx950)"; }
+
+int afx_create(const afx_model_desc* desc, afx_ctx** out) {
+  if (!desc || !out) return fail(AFX_E_INVALID, "null argument");
+  if (desc->head_dim != 128) return fail(AFX_E_UNSUPPORTED, "head_dim must be 128");
+  if (desc->heads <= 0 || desc->num_double < 0 || desc->num_single < 0 || desc->num_gaussians < 1 ||
+      desc->num_gaussians > 32)
+    return fail(AFX_E_INVALID, "bad model description");
+  if (desc->in_channels % 64 != 0 || desc->joint_dim % 64 != 0)
+    return fail(AFX_E_UNSUPPORTED, "in_channels and joint_dim must be multiples of 64");
+  afx_ctx* c = new afx_ctx();
+  c->d = *desc;
+  c->D = desc->heads * desc->head_dim;
+  ModLayout ml{c->D, desc->num_double, desc->num_single};
+  c->n_mod = ml.total();
+  const int K = desc->num_gaussians, ch = desc->in_channels, lw = desc->logweights_channels;
+  const int raw = desc->head_mode == 0 ? K * ch + K * lw + (K - 1) * lw : ch;
+  c->head_n = (raw + 7) / 8 * 8;
+  *out = c;
+  return AFX_OK;
+}
+
+int afx_destroy(afx_ctx* ctx) {
+  if (ctx)
+    for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  delete ctx;
+  return AFX_OK;
+}
+
+int afx_bind_weight(afx_ctx* ctx, const char* name, const void* dptr, int32_t dtype, int32_t ndim,
+                    const int64_t* shape) {
+  if (!ctx || !name || !dptr || ndim < 1 || ndim > 4 || !shape) return fail(AFX_E_INVALID, "bad bind_weight argument");
+  if (dtype != AFX_DT_BF16 && dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad dtype for '%s'", name);
+  Weight w;
+  w.ptr = dptr;
+  w.dtype = dtype;
+  w.shape.assign(shape, shape + ndim);
+  ctx->w[name] = w;
+  ctx->finalized = false;
+  return AFX_OK;
+}
+
+int afx_finalize(afx_ctx* c) {
+  if (!c) return fail(AFX_E_INVALID, "null ctx");
+  const int64_t D = c->D;
+  const afx_model_desc& d = c->d;
+  int r;
+#define NEED(x) \
+  if ((r = (x)) != AFX_OK) return r
+  NEED(need_linear(c, "x_in", D, d.in_channels));
+  NEED(need_linear(c, "ctx_in", D, d.joint_dim));
+  if (d.family == 1) NEED(need(c, "txt_norm.weight", AFX_DT_F32, {d.joint_dim}));
+  NEED(need_linear(c, "temb.t.l1", D, 256));
+  NEED(need_linear(c, "temb.t.l2", D, D));
+  if (d.guidance_embeds) {
+    NEED(need_linear(c, "temb.g.l1", D, 256));
+    NEED(need_linear(c, "temb.g.l2", D, D));
+  }
+  if (d.pooled_dim > 0) {
+    NEED(need_linear(c, "temb.p.l1", D, d.pooled_dim));
+    NEED(need_linear(c, "temb.p.l2", D, D));
+  }
+  NEED(need_linear(c, "mod", c->n_mod, D));
+  for (int i = 0; i < d.num_double; ++i) {
+    const std::string p = "d" + std::to_string(i) + ".";
+    for (const char* s : {"img", "txt"}) {
+      NEED(need_linear(c, p + s + "_qkv", 3 * D, D));
+      NEED(need_linear(c, p + s + "_out", D, D));
+      NEED(need_linear(c, p + s + "_mlp1", 4 * D, D));
+      NEED(need_linear(c, p + s + "_mlp2", D, 4 * D));
+    }
+    NEED(need(c, p + "qknorm", AFX_DT_F32, {4, 128}));
+  }
+  for (int i = 0; i < d.num_single; ++i) {
+    const std::string p = "s" + std::to_string(i) + ".";
+    NEED(need_linear(c, p + "fused", 7 * D, D));
+    NEED(need_linear(c, p + "out", D, 5 * D));
+    NEED(need(c, p + "qknorm", AFX_DT_F32, {2, 128}));
+  }
+  NEED(need_linear(c, "head", c->head_n, D));
+#undef NEED
+  c->finalized = true;
+  return AFX_OK;
+}
+
+int64_t afx_workspace_bytes(const afx_ctx* ctx, int32_t batch, int32_t n_img, int32_t n_txt) {
+  if (!ctx || batch < 1 || n_img < 1 || n_txt < 0) return fail(AFX_E_INVALID, "bad workspace query");
+  return carve(ctx, nullptr, batch, n_img, n_txt).total;
+}
+
+int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes) {
+  if (!ctx || !dptr || bytes <= 0) return fail(AFX_E_INVALID, "bad workspace");
+  if (((uintptr_t)dptr & 255) != 0) return fail(AFX_E_INVALID, "workspace must be 256-byte aligned");
+  ctx->ws = (char*)dptr;
+  ctx->ws_bytes = bytes;
+  return AFX_OK;
+}
+
+int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void* pooled, const float* t,
+                      const float* g, const float* rope_cos, const float* rope_sin, int32_t B, int32_t N,
+                      int32_t T, void* means, void* logw, void* logg, void* stream_) {
+  if (!c || !x || !ctx_emb || !t || !rope_cos || !rope_sin || !means)
+    return fail(AFX_E_INVALID, "null argument to afx_mmdit_forward");
+  if (!c->finalized) return fail(AFX_E_MISSING, "afx_finalize() has not succeeded on this context");
+  const afx_model_desc& d = c->d;
+  if (B < 1 || B > 4 || N < 1 || T < 1) return fail(AFX_E_INVALID, "bad shape: batch must be 1..4, N,T >= 1");
+  if (d.guidance_embeds && !g) return fail(AFX_E_INVALID, "guidance vector required");
+  if (d.pooled_dim > 0 && !pooled) return fail(AFX_E_INVALID, "pooled projections required");
+  if (d.head_mode == 0 && (!logw || !logg)) return fail(AFX_E_INVALID, "logw/logg outputs required");
+  Workspace ws = carve(c, c->ws, B, N, T);
+  if (!c->ws || ws.total > c->ws_bytes)
+    return fail(AFX_E_WORKSPACE, "workspace too small: need %lld bytes, have %lld", (long long)ws.total,
+                (long long)c->ws_bytes);
+  hipStream_t st = (hipStream_t)stream_;
+  const int64_t D = c->D;
+  const int H = d.heads, S = N + T;
+  const int64_t R = (int64_t)B * S;
+  ModLayout ml{D, d.num_double, d.num_single};
+  const int64_t ldm = c->n_mod;
+
+  // ---- conditioning: temb = t_mlp(sincos(1000 t)) [+ g_mlp(sincos(1000 g))] [+ p_mlp(pooled)] ------
+  HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, st));
+  HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
+  HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 0, st));
+  if (d.guidance_embeds) {
+    HIP_TRY(launch_sincos(g, 1000.0f, ws.sincos, B, st));
+    HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.g.l1.weight"), W16(c, "temb.g.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
+    HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.g.l2.weight"), W16(c, "temb.g.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 1, st));
+  }
+  if (d.pooled_dim > 0) {
+    HIP_TRY(launch_bf16_to_f32((const uint16_t*)pooled, ws.pooled, (int64_t)B * d.pooled_dim, st));
+    HIP_TRY(launch_gemv(ws.pooled, W16(c, "temb.p.l1.weight"), W16(c, "temb.p.l1.bias"), ws.tmp, B, (int)D, d.pooled_dim, 1, 0, st));
+    HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.p.l2.weight"), W16(c, "temb.p.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 1, st));
+  }
+  HIP_TRY(launch_silu(ws.temb, ws.semb, (int64_t)B * D, st));
+  // every AdaLN modulation vector of the whole network in one weight-streaming pass
+  HIP_TRY(launch_gemv(ws.semb, W16(c, "mod.weight"), W16(c, "mod.bias"), ws.mod, B, (int)c->n_mod, (int)D, 0, 0, st));
+
+  // ---- embedders into the joint layout X[b][text T | image N] ---------------------------------------
+  const uint16_t* ctx_src = (const uint16_t*)ctx_emb;
+  if (d.family == 1) {   // Qwen: RMSNorm(joint_dim) on the text states before txt_in (arcqwen.py:129)
+    HIP_TRY(launch_norm_modulate(ctx_src, d.joint_dim, ws.F, d.joint_dim, B * T, d.joint_dim,
+                                 W32(c, "txt_norm.weight"), nullptr, 0, B * T, 1, st));
+    ctx_src = ws.F;
+  }
+  {
+    GemmBatch gb{};
+    for (int b = 0; b < B; ++b) {
+      GemmProblem& pi = gb.p[gb.nprob++];
+      pi = GemmProblem{};
+      pi.A = (const uint16_t*)x + (int64_t)b * N * d.in_channels; pi.lda = d.in_channels;
+      pi.W = W16(c, "x_in.weight"); pi.ldw = d.in_channels; pi.bias = W16(c, "x_in.bias");
+      pi.C = ws.X + ((int64_t)b * S + T) * D; pi.ldc = D; pi.M = N; pi.N = (int)D; pi.K = d.in_channels;
+      GemmProblem& pt = gb.p[gb.nprob++];
+      pt = GemmProblem{};
+      pt.A = ctx_src + (int64_t)b * T * d.joint_dim; pt.lda = d.joint_dim;
+      pt.W = W16(c, "ctx_in.weight"); pt.ldw = d.joint_dim; pt.bias = W16(c, "ctx_in.bias");
+      pt.C = ws.X + (int64_t)b * S * D; pt.ldc = D; pt.M = T; pt.N = (int)D; pt.K = d.joint_dim;
+    }
+    { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
+  }
+
+  // helper: one grouped GEMM over the image and text row ranges of every sample
+  auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const std::string& pre, const char* suffix,
+                         uint16_t* C, int64_t ldc, int Nout, int epi, int blk, int gate_chunk) -> int {
+    GemmBatch gb{};
+    for (int b = 0; b < B; ++b)
+      for (int s = 0; s < 2; ++s) {   // 0 image rows, 1 text rows
+        GemmProblem& p = gb.p[gb.nprob++];
+        p = GemmProblem{};
+        const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
+        const std::string wn = pre + (s == 0 ? "img_" : "txt_") + suffix;
+        p.A = A + row0 * lda; p.lda = lda;
+        p.W = W16(c, wn + ".weight"); p.ldw = K; p.bias = W16(c, wn + ".bias");
+        p.C = C + row0 * ldc; p.ldc = ldc;
+        p.M = (s == 0 ? N : T); p.N = Nout; p.K = K;
+        p.epi = epi; p.gelu_col0 = 0;
+        if (epi == EPI_GATE_RES) {
+          p.gate = ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, gate_chunk); p.ldg = 0; p.rows_per_batch = 1 << 30;
+          p.res = C + row0 * ldc; p.ldr = ldc;
+        }
+      }
+    { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
+    return AFX_OK;
+  };
+  auto stream_norm = [&](int blk, int shift_chunk, int scale_chunk) -> int {
+    for (int b = 0; b < B; ++b)
+      for (int s = 0; s < 2; ++s) {
+        const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
+        HIP_TRY(launch_norm_modulate(ws.X + row0 * D, D, ws.Xn + row0 * D, D, s == 0 ? N : T, (int)D,
+                                     ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, scale_chunk),
+                                     ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, shift_chunk), 0, 1 << 30, 0, st));
+      }
+    return AFX_OK;
+  };
+
+  int rc;
+  // ---- dual-stream blocks ---------------------------------------------------------------------------
+  uint16_t* QKV = ws.F;                 // [R, 3D]  rows k|v|q
+  uint16_t* Hb = ws.F + R * 3 * D;      // [R, 4D]  MLP hidden
+  for (int i = 0; i < d.num_double; ++i) {
+    const std::string p = "d" + std::to_string(i) + ".";
+    const float* qkn = W32(c, p + "qknorm");   // [img_q, img_k, txt_q, txt_k][128]
+    if ((rc = stream_norm(i, 0, 1))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "qkv", QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
+    HIP_TRY(launch_qk_norm_rope(QKV, 3 * D, qkn + 3 * 128, qkn + 1 * 128, rope_cos, rope_sin, B, S, T, H, st));            // k
+    HIP_TRY(launch_qk_norm_rope(QKV + 2 * D, 3 * D, qkn + 2 * 128, qkn + 0 * 128, rope_cos, rope_sin, B, S, T, H, st));    // q
+    HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
+    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
+    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, p, "out", ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
+    if ((rc = stream_norm(i, 3, 4))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "mlp1", Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0))) return rc;
+    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), p, "mlp2", ws.X, D, (int)D, EPI_GATE_RES, i, 5))) return rc;
+  }
+
+  // ---- single-stream blocks on the joint sequence -------------------------------------------------
+  for (int i = 0; i < d.num_single; ++i) {
+    const std::string p = "s" + std::to_string(i) + ".";
+    const float* qkn = W32(c, p + "qknorm");   // [q, k][128]
+    HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
+    GemmBatch gb{};
+    gb.nprob = 1;
+    GemmProblem& f = gb.p[0];
+    f = GemmProblem{};
+    f.A = ws.Xn; f.lda = D; f.W = W16(c, p + "fused.weight"); f.ldw = D; f.bias = W16(c, p + "fused.bias");
+    f.C = ws.F; f.ldc = 7 * D; f.M = (int)R; f.N = (int)(7 * D); f.K = (int)D; f.epi = EPI_GELU; f.gelu_col0 = (int)(3 * D);
+    { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
+    HIP_TRY(launch_qk_norm_rope(ws.F, 7 * D, qkn + 128, qkn + 128, rope_cos, rope_sin, B, S, T, H, st));                 // k
+    HIP_TRY(launch_qk_norm_rope(ws.F + 2 * D, 7 * D, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));                     // q
+    HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
+    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st)); }
+    GemmBatch go{};
+    go.nprob = 1;
+    GemmProblem& o = go.p[0];
+    o = GemmProblem{};
+    o.A = ws.F + 2 * D; o.lda = 7 * D; o.W = W16(c, p + "out.weight"); o.ldw = 5 * D; o.bias = W16(c, p + "out.bias");
+    o.C = ws.X; o.ldc = D; o.M = (int)R; o.N = (int)D; o.K = (int)(5 * D); o.epi = EPI_GATE_RES;
+    o.gate = ws.mod + ml.sgl(i, 2); o.ldg = ldm; o.rows_per_batch = S; o.res = ws.X; o.ldr = D;
+    { ProfScope ps_(c, st, 0, gemm_flops(go)); HIP_TRY(launch_gemm(go, st)); }
+  }
+
+  // ---- norm_out (scale first) + velocity head on the image tokens --------------------------------------
+  for (int b = 0; b < B; ++b)
+    HIP_TRY(launch_norm_modulate(ws.X + ((int64_t)b * S + T) * D, D, ws.Xn + (int64_t)b * N * D, D, N, (int)D,
+                                 ws.mod + (int64_t)b * ldm + ml.fin(0), ws.mod + (int64_t)b * ldm + ml.fin(1), 0,
+                                 1 << 30, 0, st));
+  {
+    GemmBatch gb{};
+    gb.nprob = 1;
+    GemmProblem& hp = gb.p[0];
+    hp = GemmProblem{};
+    hp.A = ws.Xn; hp.lda = D; hp.W = W16(c, "head.weight"); hp.ldw = D; hp.bias = W16(c, "head.bias");
+    hp.M = B * N; hp.N = c->head_n; hp.K = (int)D; hp.epi = EPI_NONE;
+    if (d.head_mode == 0) {
+      hp.C = ws.head; hp.ldc = c->head_n;
+    } else {
+      hp.C = (uint16_t*)means; hp.ldc = c->head_n;    // teacher: velocity [B*N, in_channels] written directly
+    }
+    { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
+  }
+  if (d.head_mode == 0)
+    HIP_TRY(launch_head_split(ws.head, c->head_n, (uint16_t*)means, (uint16_t*)logw, (uint16_t*)logg, (int64_t)B * N,
+                              d.num_gaussians, d.in_channels, d.logweights_channels, st));
+  return AFX_OK;
+}
+
+int afx_profile_enable(afx_ctx* ctx, int32_t on) {
+  if (!ctx) return fail(AFX_E_INVALID, "null ctx");
+  ctx->prof_on = on != 0;
+  ctx->prof_used = 0;
+  return AFX_OK;
+}
+
+int afx_profile_read(afx_ctx* ctx, int32_t klass, double* total_ms, int64_t* launches, double* flops) {
+  if (!ctx || !total_ms || !launches || !flops) return fail(AFX_E_INVALID, "null argument to afx_profile_read");
+  double ms = 0, fl = 0;
+  int64_t n = 0;
+  for (size_t i = 0; i < ctx->prof_used; ++i) {
+    auto& r = ctx->prof_pool[i];
+    if (r.klass != klass) continue;
+    HIP_TRY(hipEventSynchronize(r.b));
+    float t = 0;
+    HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+    ms += t; fl += r.flops; ++n;
+  }
+  *total_ms = ms; *launches = n; *flops = fl;
+  return AFX_OK;
+}
+
+int afx_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg, int32_t mix_dtype,
+                     float sigma_src, float sigma_start, float sigma_end, const float* sigma_vec, float eps,
+                     float* x_out, int32_t batch, int32_t n_tok, int32_t K, int32_t ch, int32_t pp, void* stream) {
+  if (!x_in || !means || !logw || !logg || !x_out) return fail(AFX_E_INVALID, "null argument to afx_arcflow_step");
+  if (mix_dtype != AFX_DT_BF16 && mix_dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad mix_dtype");
+  if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || pp < 1 || ch % pp != 0)
+    return fail(AFX_E_INVALID, "bad shape for afx_arcflow_step");
+  HIP_TRY(launch_arcflow_step(x_in, means, logw, logg, mix_dtype == AFX_DT_BF16, sigma_src, sigma_start, sigma_end,
+                              sigma_vec, eps, x_out, batch, n_tok, K, ch, pp, 0, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_arcflow_velocity(const void* means, const void* logw, const void* logg, int32_t mix_dtype, float sigma_src,
+                         float sigma_t, const float* sigma_vec, float* u_out, int32_t batch, int32_t n_tok,
+                         int32_t K, int32_t ch, int32_t pp, void* stream) {
+  if (!means || !logw || !logg || !u_out) return fail(AFX_E_INVALID, "null argument to afx_arcflow_velocity");
+  if (mix_dtype != AFX_DT_BF16 && mix_dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad mix_dtype");
+  if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || pp < 1 || ch % pp != 0)
+    return fail(AFX_E_INVALID, "bad shape for afx_arcflow_velocity");
+  HIP_TRY(launch_arcflow_step(u_out, means, logw, logg, mix_dtype == AFX_DT_BF16, sigma_src, sigma_t, sigma_t,
+                              sigma_vec, 1e-4f, u_out, batch, n_tok, K, ch, pp, 1, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
+                    int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
+                    int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, void* stream) {
+  if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16");
+  if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 8)
+    return fail(AFX_E_INVALID, "afx_linear_bf16: need K%%64==0, N%%8==0, strides%%8==0");
+  if (epi < 0 || epi > 2) return fail(AFX_E_INVALID, "bad epilogue");
+  if (epi == EPI_GATE_RES && (!gate || !res || ldr % 8 || rows_per_batch < 1))
+    return fail(AFX_E_INVALID, "gated residual epilogue needs gate, res, rows_per_batch");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = (const uint16_t*)bias;
+  p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
+  p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int64_t afx_attention_ws_bytes(int32_t batch, int32_t heads, int32_t S) {
+  if (batch < 1 || heads < 1 || S < 1) return fail(AFX_E_INVALID, "bad attention shape");
+  return (int64_t)batch * heads * 128 * attn_spad(S) * 2;
+}
+
+int afx_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                       int64_t ldo, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream) {
+  if (!q || !k || !v || !o || !vt_ws) return fail(AFX_E_INVALID, "null argument to afx_attention_bf16");
+  if (batch < 1 || heads < 1 || S < 1 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4)
+    return fail(AFX_E_INVALID, "bad attention shape / stride");
+  HIP_TRY(launch_v_transpose((const uint16_t*)v, ldv, (uint16_t*)vt_ws, batch, heads, S, (hipStream_t)stream));
+  HIP_TRY(launch_attention((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)vt_ws, (uint16_t*)o, ldo,
+                           batch, heads, S, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_norm_modulate_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t D,
+                           const float* scale, const float* shift, int64_t ldmod, int32_t rows_per_batch, int32_t rms,
+                           void* stream) {
+  if (!x || !out || !scale || (!rms && !shift)) return fail(AFX_E_INVALID, "null argument to afx_norm_modulate_bf16");
+  if (rows < 0 || D < 8 || D % 8 || D > 4096 || ldx % 8 || ldo % 8) return fail(AFX_E_INVALID, "bad norm shape");
+  HIP_TRY(launch_norm_modulate((const uint16_t*)x, ldx, (uint16_t*)out, ldo, rows, D, scale, shift, ldmod,
+                               rows_per_batch, rms, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_qk_norm_rope_bf16(void* x, int64_t ldx, const float* w_txt, const float* w_img, const float* rope_cos,
+                          const float* rope_sin, int32_t batch, int32_t S, int32_t n_txt, int32_t heads, void* stream) {
+  if (!x || !w_txt || !w_img || !rope_cos || !rope_sin) return fail(AFX_E_INVALID, "null argument to afx_qk_norm_rope_bf16");
+  if (batch < 1 || S < 1 || heads < 1 || ldx % 8) return fail(AFX_E_INVALID, "bad qk_norm_rope shape");
+  HIP_TRY(launch_qk_norm_rope((uint16_t*)x, ldx, w_txt, w_img, rope_cos, rope_sin, batch, S, n_txt, heads,
+                              (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_gemv_bf16(const float* x, const void* W, const void* bias, float* y, int32_t B, int32_t N, int32_t K,
+                  int32_t act, int32_t accumulate, void* stream) {
+  if (!x || !W || !y) return fail(AFX_E_INVALID, "null argument to afx_gemv_bf16");
+  if (B < 1 || B > 8 || N < 1 || K < 8 || K % 8) return fail(AFX_E_INVALID, "bad gemv shape (B<=8, K%%8==0)");
+  HIP_TRY(launch_gemv(x, (const uint16_t*)W, (const uint16_t*)bias, y, B, N, K, act, accumulate, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+}  // extern "C"

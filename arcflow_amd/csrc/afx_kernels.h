@@ -1,0 +1,65 @@
+// Internal launcher declarations shared by the C-ABI layer and the MMDiT engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afx {
+
+// ---- grouped bf16 GEMM  C = epi(A . W^T + bias) -------------------------------------------
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_GATE_RES = 2 };
+constexpr int GEMM_MAX_PROBLEMS = 8;
+
+struct GemmProblem {
+  const uint16_t* A;    // [M,K], row stride lda
+  const uint16_t* W;    // [N,K], row stride ldw (nn.Linear weight)
+  const uint16_t* bias; // [N] or nullptr
+  uint16_t* C;          // [M,N], row stride ldc
+  const float* gate;    // EPI_GATE_RES: [*, ldg] f32, row = m / rows_per_batch
+  const uint16_t* res;  // EPI_GATE_RES: [M,N] residual, row stride ldr (may alias C)
+  int64_t lda, ldw, ldc, ldg, ldr;
+  int32_t M, N, K;
+  int32_t epi, gelu_col0, rows_per_batch;
+  int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
+};
+
+struct GemmBatch {
+  int32_t nprob;
+  int32_t total_tiles;
+  GemmProblem p[GEMM_MAX_PROBLEMS];
+};
+
+hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
+
+// ---- attention ------------------------------------------------------------------------------
+// vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)
+hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
+                              hipStream_t stream);
+hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
+                            const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
+                            hipStream_t stream);
+inline int64_t attn_spad(int S) { return ((int64_t)S + 63) / 64 * 64; }
+
+// ---- element-wise / reductions -----------------------------------------------------------------
+hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,
+                                int D, const float* scale, const float* shift, int64_t ldmod,
+                                int rows_per_batch, int rms, hipStream_t stream);
+hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, const float* w_img,
+                               const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
+                               hipStream_t stream);
+hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
+                       int K, int act, int accumulate, hipStream_t stream);
+hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream);
+hipError_t launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
+hipError_t launch_bf16_to_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream);
+hipError_t launch_head_split(const uint16_t* head, int64_t ldh, uint16_t* means, uint16_t* logw,
+                             uint16_t* logg, int64_t rows, int K, int ch, int lw, hipStream_t stream);
+hipError_t launch_copy_rows(const uint16_t* src, int64_t lds_, uint16_t* dst, int64_t ldd, int64_t rows,
+                            int cols, hipStream_t stream);
+
+// ---- ArcFlow policy math --------------------------------------------------------------------------
+hipError_t launch_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg,
+                               int mix_bf16, float s_src, float s_start, float s_end,
+                               const float* sigma_vec, float eps, float* x_out, int B, int n_tok, int K,
+                               int ch, int pp, int velocity_only, hipStream_t stream);
+
+}  // namespace afx

@@ -1,0 +1,178 @@
+"""Python handle on one libarcflow_hip context: the MI355X denoiser that stands in for the reference's
+``transformer`` module (``_ArcFluxTransformer2DModel`` / ``_ArcQwenImageTransformer2DModel``,
+lakonlab/models/architecture/arcflow/arcflux.py:25-257, arcqwen.py:23-174).
+
+torch is used for device memory and the current HIP stream only; all math runs in the HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib, rope
+from .weights import pack_flux, pack_qwen
+
+
+@dataclass
+class ArcFlowModelOutput:
+    """Same fields as the reference's ArcFlowModelOutput (arc_output.py:9-25)."""
+    means: torch.Tensor        # [B, N, K, C]
+    logweights: torch.Tensor   # [B, N, K, L]   log_softmax over K
+    loggammas: torch.Tensor    # [B, N, K-1, L]
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def keys(self):
+        return ('means', 'logweights', 'loggammas')
+
+    def items(self):
+        return [(k, getattr(self, k)) for k in self.keys()]
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class MMDiTEngine:
+    """FLUX / Qwen-Image MMDiT trunk + ArcFlow heads on one GPU."""
+
+    def __init__(self, family: str, num_double: int, num_single: int = 0, heads: int = 24, head_dim: int = 128,
+                 in_channels: int = 64, joint_dim: int = 4096, pooled_dim: int = 768, guidance_embeds: bool = True,
+                 num_gaussians: int = 16, logweights_channels: int = 4, teacher_head: bool = False,
+                 axes_dims=(16, 56, 56), device='cuda'):
+        assert family in ('flux', 'qwen')
+        self.lib = _lib.load()
+        self.family = family
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self.num_double, self.num_single = num_double, num_single
+        self.heads, self.head_dim, self.dim = heads, head_dim, heads * head_dim
+        self.in_channels, self.joint_dim = in_channels, joint_dim
+        self.pooled_dim = pooled_dim if family == 'flux' else 0
+        self.guidance_embeds = bool(guidance_embeds) if family == 'flux' else False
+        self.num_gaussians, self.logweights_channels = num_gaussians, logweights_channels
+        self.teacher_head = teacher_head
+        self.axes_dims = tuple(axes_dims)
+        desc = _lib.ModelDesc(0 if family == 'flux' else 1, num_double, num_single, heads, head_dim, in_channels,
+                              joint_dim, self.pooled_dim, int(self.guidance_embeds), num_gaussians,
+                              logweights_channels, int(teacher_head))
+        self._ctx = C.c_void_p()
+        _lib.check(self.lib.afx_create(C.byref(desc), C.byref(self._ctx)))
+        self._weights: Dict[str, torch.Tensor] = {}
+        self._ws: Optional[torch.Tensor] = None
+        self._ws_key = (0, 0, 0)
+        self._rope_cache: Dict[Tuple[int, int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.config = dict(in_channels=in_channels, guidance_embeds=self.guidance_embeds, num_gaussians=num_gaussians)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_ctx', None) and self._ctx.value:
+                self.lib.afx_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ weights
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Fuse + upload a diffusers-keyed state dict (optionally already LoRA-merged) and bind it."""
+        if self.family == 'flux':
+            packed = pack_flux(sd, self.num_double, self.num_single, self.device, self.num_gaussians,
+                               self.in_channels, self.logweights_channels, self.guidance_embeds, self.teacher_head)
+        else:
+            packed = pack_qwen(sd, self.num_double, self.device, self.num_gaussians, self.in_channels,
+                               self.logweights_channels, self.teacher_head)
+        self.bind_packed(packed)
+
+    def bind_packed(self, packed: Dict[str, torch.Tensor]) -> None:
+        for name, t in packed.items():
+            assert t.is_contiguous() and t.device.type == 'cuda', name
+            dt = {torch.bfloat16: _lib.AFX_DT_BF16, torch.float32: _lib.AFX_DT_F32}[t.dtype]
+            shape = (C.c_int64 * t.dim())(*t.shape)
+            _lib.check(self.lib.afx_bind_weight(self._ctx, name.encode(), _ptr(t), dt, t.dim(), shape))
+        self._weights.update(packed)         # keep the storage alive
+        _lib.check(self.lib.afx_finalize(self._ctx))
+
+    # ------------------------------------------------------------------ helpers
+    def _workspace(self, B: int, N: int, T: int) -> None:
+        if self._ws is not None and all(a <= b for a, b in zip((B, N, T), self._ws_key)):
+            return
+        key = tuple(max(a, b) for a, b in zip((B, N, T), self._ws_key))
+        need = self.lib.afx_workspace_bytes(self._ctx, *key)
+        if need < 0:
+            _lib.check(int(need))
+        self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        base = (self._ws.data_ptr() + 255) // 256 * 256
+        _lib.check(self.lib.afx_set_workspace(self._ctx, C.c_void_p(base), need))
+        self._ws_key = key
+
+    def rope_tables(self, hp: int, wp: int, T: int):
+        k = (hp, wp, T)
+        if k not in self._rope_cache:
+            if self.family == 'flux':
+                cs = rope.flux_tables(hp, wp, T, self.axes_dims)
+            else:
+                cs = rope.qwen_tables(hp, wp, T, self.axes_dims)
+            self._rope_cache[k] = tuple(t.to(self.device) for t in cs)
+        return self._rope_cache[k]
+
+    # ------------------------------------------------------------------ instrumentation
+    def profile(self, on: bool) -> None:
+        _lib.check(self.lib.afx_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self, klass: int):
+        """(total_ms, launches, algorithmic_flops) of GEMM (klass 0) / attention (klass 1) launches."""
+        ms, n, fl = C.c_double(), C.c_int64(), C.c_double()
+        _lib.check(self.lib.afx_profile_read(self._ctx, klass, C.byref(ms), C.byref(n), C.byref(fl)))
+        return ms.value, n.value, fl.value
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                pooled_projections: Optional[torch.Tensor] = None, guidance: Optional[torch.Tensor] = None,
+                height_tokens: Optional[int] = None, width_tokens: Optional[int] = None):
+        """hidden_states [B,N,C] packed latents; timestep [B] sigma in [0,1]; encoder_hidden_states [B,T,joint];
+        returns ArcFlowModelOutput (student) or the velocity [B,N,C] (teacher head)."""
+        B, N, Cc = hidden_states.shape
+        T = encoder_hidden_states.shape[1]
+        if height_tokens is None:
+            height_tokens = width_tokens = int(round(N ** 0.5))
+        assert height_tokens * width_tokens == N, 'pass height_tokens/width_tokens for non-square latents'
+        if B > 4:   # the grouped launches hold 2 problems per sample
+            outs = [self.forward(hidden_states[i:i + 4], timestep[i:i + 4], encoder_hidden_states[i:i + 4],
+                                 None if pooled_projections is None else pooled_projections[i:i + 4],
+                                 None if guidance is None else guidance[i:i + 4], height_tokens, width_tokens)
+                    for i in range(0, B, 4)]
+            if self.teacher_head:
+                return torch.cat(outs)
+            return ArcFlowModelOutput(*[torch.cat([getattr(o, k) for o in outs]) for k in ('means', 'logweights', 'loggammas')])
+        dev = self.device
+        x = hidden_states.to(dev, torch.bfloat16).contiguous()
+        ctx = encoder_hidden_states.to(dev, torch.bfloat16).contiguous()
+        t = timestep.to(dev, torch.float32).expand(B).contiguous()
+        g = None if guidance is None else guidance.to(dev, torch.float32).expand(B).contiguous()
+        pooled = None if pooled_projections is None else pooled_projections.to(dev, torch.bfloat16).contiguous()
+        cos, sin = self.rope_tables(height_tokens, width_tokens, T)
+        self._workspace(B, N, T)
+        K, L = self.num_gaussians, self.logweights_channels
+        if self.teacher_head:
+            means = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=dev)
+            logw = logg = None
+        else:
+            means = torch.empty(B, N, K, Cc, dtype=torch.bfloat16, device=dev)
+            logw = torch.empty(B, N, K, L, dtype=torch.bfloat16, device=dev)
+            logg = torch.empty(B, N, K - 1, L, dtype=torch.bfloat16, device=dev)
+        _lib.check(self.lib.afx_mmdit_forward(self._ctx, _ptr(x), _ptr(ctx), _ptr(pooled), _ptr(t), _ptr(g), _ptr(cos),
+                                              _ptr(sin), B, N, T, _ptr(means), _ptr(logw), _ptr(logg), _stream()))
+        if self.teacher_head:
+            return means
+        return ArcFlowModelOutput(means, logw, logg)
+
+    __call__ = forward

@@ -1,0 +1,147 @@
+"""torch-tensor wrappers over the exported building-block kernels of libarcflow_hip.so.
+
+Used by the pipelines (analytic step), the distillation loop and the per-kernel parity tests.
+No fallback: every function launches a HIP kernel or raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _cuda(t: torch.Tensor, dtype) -> torch.Tensor:
+    if t.device.type != 'cuda':
+        raise _lib.ArcflowHipError('arcflow_amd.ops works on GPU tensors only (no CPU fallback)')
+    return t.to(dtype).contiguous()
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = 'none',
+           gelu_col0: int = 0, gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           rows_per_batch: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias); a [M,K] (last-dim contiguous, may be a strided view), w [N,K] bf16.
+    epilogue: 'none' | 'gelu' (tanh, on columns >= gelu_col0) | 'gate_res' (residual + gate[b] * (.))."""
+    lib = _lib.load()
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(-1) == 1 and w.stride(-1) == 1
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    epi = {'none': 0, 'gelu': 1, 'gate_res': 2}[epilogue]
+    if gate is not None:
+        gate = _cuda(gate, torch.float32)
+        if gate.dim() == 1:
+            gate = gate[None]
+    rpb = rows_per_batch if rows_per_batch > 0 else max(M, 1)
+    _lib.check(lib.afx_linear_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                   epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
+                                   _p(residual), 0 if residual is None else residual.stride(0), _s()))
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """q,k,v [B,S,H,128] bf16 (last two dims contiguous) -> [B,S,H*128]; softmax(q k^T/sqrt(128)) v."""
+    lib = _lib.load()
+    B, S, H, Dh = q.shape
+    assert Dh == 128 and q.dtype == torch.bfloat16
+    q2, k2, v2 = (t.reshape(B * S, H * Dh) for t in (q.contiguous(), k.contiguous(), v.contiguous()))
+    o = torch.empty(B * S, H * Dh, dtype=torch.bfloat16, device=q.device)
+    ws = torch.empty(lib.afx_attention_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.afx_attention_bf16(_p(q2), H * Dh, _p(k2), H * Dh, _p(v2), H * Dh, _p(o), H * Dh, _p(ws), B, H, S, _s()))
+    return o.reshape(B, S, H * Dh)
+
+
+def norm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: Optional[torch.Tensor], rows_per_batch: int = 0,
+                  rms: bool = False) -> torch.Tensor:
+    """x [R,D] bf16; AdaLN: scale/shift [B,D] f32 (row r uses batch r // rows_per_batch);
+    rms=True: x * rsqrt(mean x^2 + 1e-6) * scale[D]."""
+    lib = _lib.load()
+    R, D = x.shape
+    out = torch.empty_like(x)
+    scale = _cuda(scale, torch.float32)
+    shift = None if shift is None else _cuda(shift, torch.float32)
+    ldm = 0 if rms or scale.dim() == 1 else scale.stride(0)
+    _lib.check(lib.afx_norm_modulate_bf16(_p(x), x.stride(0), _p(out), out.stride(0), R, D, _p(scale), _p(shift), ldm,
+                                          rows_per_batch if rows_per_batch > 0 else max(R, 1), int(rms), _s()))
+    return out
+
+
+def qk_norm_rope_(x: torch.Tensor, w_txt: torch.Tensor, w_img: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor,
+                  n_txt: int) -> torch.Tensor:
+    """In place on x [B,S,H,128] bf16: per-head RMSNorm (rows < n_txt use w_txt) then pair RoPE."""
+    lib = _lib.load()
+    B, S, H, Dh = x.shape
+    assert x.is_contiguous() and Dh == 128
+    _lib.check(lib.afx_qk_norm_rope_bf16(_p(x), H * Dh, _p(_cuda(w_txt, torch.float32)), _p(_cuda(w_img, torch.float32)),
+                                         _p(_cuda(cos, torch.float32)), _p(_cuda(sin, torch.float32)), B, S, n_txt, H, _s()))
+    return x
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: str = 'none',
+         out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    lib = _lib.load()
+    x = _cuda(x, torch.float32)
+    B, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.zeros(B, N, dtype=torch.float32, device=x.device)
+    _lib.check(lib.afx_gemv_bf16(_p(x), _p(w), _p(bias), _p(out), B, N, K, 1 if act == 'silu' else 0, int(accumulate), _s()))
+    return out
+
+
+def _mix_dtype(means, logw, logg) -> Tuple[int, torch.Tensor, torch.Tensor, torch.Tensor]:
+    if means.dtype == torch.bfloat16:
+        return _lib.AFX_DT_BF16, means.contiguous(), logw.to(torch.bfloat16).contiguous(), logg.to(torch.bfloat16).contiguous()
+    return _lib.AFX_DT_F32, means.float().contiguous(), logw.float().contiguous(), logg.float().contiguous()
+
+
+def arcflow_step(x: torch.Tensor, means: torch.Tensor, logw: torch.Tensor, logg: torch.Tensor, sigma_src, sigma_start,
+                 sigma_end, eps: float = 1e-4, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Analytic ArcFlow transport in the token layout: x [B,N,ch] f32, means [B,N,K,ch], logw [B,N,K,pp],
+    logg [B,N,K-1,pp]  ->  x_end [B,N,ch] f32.  sigmas: python floats, or [B] tensors (per-sample)."""
+    lib = _lib.load()
+    B, N, K, ch = means.shape
+    pp = logw.shape[-1]
+    x = _cuda(x, torch.float32)
+    dt, means, logw, logg = _mix_dtype(means, logw, logg)
+    if out is None:
+        out = torch.empty_like(x)
+    sv = None
+    if any(isinstance(s, torch.Tensor) and s.numel() > 1 for s in (sigma_src, sigma_start, sigma_end)):
+        cols = [torch.as_tensor(s, dtype=torch.float32, device=x.device).flatten().expand(B) for s in (sigma_src, sigma_start, sigma_end)]
+        sv = torch.stack(cols, dim=1).contiguous()
+        s0 = s1 = s2 = 0.0
+    else:
+        s0, s1, s2 = (float(s) for s in (sigma_src, sigma_start, sigma_end))
+    _lib.check(lib.afx_arcflow_step(_p(x), _p(means), _p(logw), _p(logg), dt, s0, s1, s2, _p(sv), eps, _p(out),
+                                    B, N, K, ch, pp, _s()))
+    return out
+
+
+def arcflow_velocity(means: torch.Tensor, logw: torch.Tensor, logg: torch.Tensor, sigma_src, sigma_t) -> torch.Tensor:
+    """u(sigma_t) of the momentum mixture, token layout -> [B,N,ch] f32."""
+    lib = _lib.load()
+    B, N, K, ch = means.shape
+    pp = logw.shape[-1]
+    dt, means, logw, logg = _mix_dtype(means, logw, logg)
+    out = torch.empty(B, N, ch, dtype=torch.float32, device=means.device)
+    sv = None
+    if any(isinstance(s, torch.Tensor) and s.numel() > 1 for s in (sigma_src, sigma_t)):
+        cols = [torch.as_tensor(s, dtype=torch.float32, device=out.device).flatten().expand(B) for s in (sigma_src, sigma_t, sigma_t)]
+        sv = torch.stack(cols, dim=1).contiguous()
+        s0 = s1 = 0.0
+    else:
+        s0, s1 = float(sigma_src), float(sigma_t)
+    _lib.check(lib.afx_arcflow_velocity(_p(means), _p(logw), _p(logg), dt, s0, s1, _p(sv), _p(out), B, N, K, ch, pp, _s()))
+    return out

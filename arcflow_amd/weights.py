@@ -1,0 +1,185 @@
+"""Pack a diffusers-style state dict (the keys the reference loads,
+lakonlab/pipelines/arcflow_loader.py:241-263 and SURVEY App. B) into the engine's fused weight set.
+
+Fusions (all done once at load time, on the device):
+  * to_k | to_v | to_q (and add_k|add_v|add_q) stacked on the output dim -> one QKV GEMM per stream;
+    the FLUX single block additionally stacks proj_mlp: rows k|v|q|mlp.  (q last: attention writes O
+    over Q so that [O | mlp] is the contiguous-K operand of proj_out.)
+  * every AdaLN modulation linear of the network stacked into one [n_mod, D] matrix.
+  * the three ArcFlow heads stacked into one [K*C + K*L + (K-1)*L (+pad), D] matrix.
+  * LoRA (lora_A/lora_B, scale alpha/r = 1: arcflux.py:295-301) is merged into the base weight in
+    fp32 and rounded once to bf16 (the reference keeps the side GEMMs un-fused; merge changes only
+    rounding order -- see DESIGN.md).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+Tensor = torch.Tensor
+
+
+def merge_lora(sd: Dict[str, Tensor], lora: Optional[Dict[str, Tensor]], scale: float = 1.0) -> Dict[str, Tensor]:
+    """Return a copy of ``sd`` with every ``<mod>.lora_A.weight``/``lora_B.weight`` pair folded in."""
+    if not lora:
+        return sd
+    out = dict(sd)
+    mods = sorted({k.rsplit('.lora_', 1)[0] for k in lora if '.lora_A' in k})
+    for m in mods:
+        a = lora.get(m + '.lora_A.weight', lora.get(m + '.lora_A.default.weight'))
+        b = lora.get(m + '.lora_B.weight', lora.get(m + '.lora_B.default.weight'))
+        key = m + '.weight'
+        if key not in out:
+            key = m + '.base_layer.weight'
+        if a is None or b is None or key not in out:
+            raise KeyError(f'LoRA module {m}: missing lora_A/lora_B or base weight')
+        w = out[key]
+        delta = (b.to(w.device, torch.float32) @ a.to(w.device, torch.float32)) * scale
+        out[m + '.weight'] = (w.float() + delta).to(w.dtype)
+    return out
+
+
+def _bf16(t: Tensor, device) -> Tensor:
+    return t.to(device=device, dtype=torch.bfloat16).contiguous()
+
+
+def _cat(sd, names, device, dim=0) -> Tensor:
+    return torch.cat([sd[n].to(device=device, dtype=torch.bfloat16) for n in names], dim=dim).contiguous()
+
+
+def pack_head(sd, device, K: int, C: int, L: int, teacher: bool = False):
+    if teacher:
+        return _bf16(sd['proj_out.weight'], device), _bf16(sd['proj_out.bias'], device)
+    w = _cat(sd, ['proj_out_means.weight', 'proj_out_logweights.weight', 'proj_out_loggamma.weight'], device)
+    b = _cat(sd, ['proj_out_means.bias', 'proj_out_logweights.bias', 'proj_out_loggamma.bias'], device)
+    n = w.shape[0]
+    npad = (n + 7) // 8 * 8
+    if npad != n:
+        w = torch.cat([w, w.new_zeros(npad - n, w.shape[1])]).contiguous()
+        b = torch.cat([b, b.new_zeros(npad - n)]).contiguous()
+    return w, b
+
+
+def pack_flux(sd: Dict[str, Tensor], num_double: int, num_single: int, device, K=16, C=64, L=4,
+              guidance: bool = True, teacher: bool = False) -> Dict[str, Tensor]:
+    p: Dict[str, Tensor] = {}
+
+    def lin(dst, src):
+        p[dst + '.weight'] = _bf16(sd[src + '.weight'], device)
+        p[dst + '.bias'] = _bf16(sd[src + '.bias'], device)
+    lin('x_in', 'x_embedder')
+    lin('ctx_in', 'context_embedder')
+    for tag, nm in (('t', 'timestep_embedder'), ('p', 'text_embedder')) + ((('g', 'guidance_embedder'),) if guidance else ()):
+        lin(f'temb.{tag}.l1', f'time_text_embed.{nm}.linear_1')
+        lin(f'temb.{tag}.l2', f'time_text_embed.{nm}.linear_2')
+    mod_w, mod_b = [], []
+    for i in range(num_double):
+        s, d = f'transformer_blocks.{i}.', f'd{i}.'
+        for nm in ('norm1.linear', 'norm1_context.linear'):
+            mod_w.append(s + nm + '.weight'); mod_b.append(s + nm + '.bias')
+        for stream, (k, v, q, o, ff) in (('img', ('attn.to_k', 'attn.to_v', 'attn.to_q', 'attn.to_out.0', 'ff')),
+                                         ('txt', ('attn.add_k_proj', 'attn.add_v_proj', 'attn.add_q_proj',
+                                                  'attn.to_add_out', 'ff_context'))):
+            p[d + stream + '_qkv.weight'] = _cat(sd, [s + k + '.weight', s + v + '.weight', s + q + '.weight'], device)
+            p[d + stream + '_qkv.bias'] = _cat(sd, [s + k + '.bias', s + v + '.bias', s + q + '.bias'], device)
+            lin(d + stream + '_out', s + o)
+            lin(d + stream + '_mlp1', s + ff + '.net.0.proj')
+            lin(d + stream + '_mlp2', s + ff + '.net.2')
+        p[d + 'qknorm'] = torch.stack([sd[s + f'attn.{n}.weight'].float() for n in
+                                       ('norm_q', 'norm_k', 'norm_added_q', 'norm_added_k')]).to(device).contiguous()
+    for i in range(num_single):
+        s, d = f'single_transformer_blocks.{i}.', f's{i}.'
+        mod_w.append(s + 'norm.linear.weight'); mod_b.append(s + 'norm.linear.bias')
+        names = ['attn.to_k', 'attn.to_v', 'attn.to_q', 'proj_mlp']
+        p[d + 'fused.weight'] = _cat(sd, [s + n + '.weight' for n in names], device)
+        p[d + 'fused.bias'] = _cat(sd, [s + n + '.bias' for n in names], device)
+        lin(d + 'out', s + 'proj_out')
+        p[d + 'qknorm'] = torch.stack([sd[s + 'attn.norm_q.weight'].float(),
+                                       sd[s + 'attn.norm_k.weight'].float()]).to(device).contiguous()
+    mod_w.append('norm_out.linear.weight'); mod_b.append('norm_out.linear.bias')
+    p['mod.weight'] = _cat(sd, mod_w, device)
+    p['mod.bias'] = _cat(sd, mod_b, device)
+    p['head.weight'], p['head.bias'] = pack_head(sd, device, K, C, L, teacher)
+    return p
+
+
+def pack_qwen(sd: Dict[str, Tensor], num_layers: int, device, K=16, C=64, L=4, teacher: bool = False
+              ) -> Dict[str, Tensor]:
+    p: Dict[str, Tensor] = {}
+
+    def lin(dst, src):
+        p[dst + '.weight'] = _bf16(sd[src + '.weight'], device)
+        p[dst + '.bias'] = _bf16(sd[src + '.bias'], device)
+    lin('x_in', 'img_in')
+    lin('ctx_in', 'txt_in')
+    p['txt_norm.weight'] = sd['txt_norm.weight'].to(device=device, dtype=torch.float32).contiguous()
+    lin('temb.t.l1', 'time_text_embed.timestep_embedder.linear_1')
+    lin('temb.t.l2', 'time_text_embed.timestep_embedder.linear_2')
+    mod_w, mod_b = [], []
+    for i in range(num_layers):
+        s, d = f'transformer_blocks.{i}.', f'd{i}.'
+        for nm in ('img_mod.1', 'txt_mod.1'):
+            mod_w.append(s + nm + '.weight'); mod_b.append(s + nm + '.bias')
+        for stream, (k, v, q, o, ff) in (('img', ('attn.to_k', 'attn.to_v', 'attn.to_q', 'attn.to_out.0', 'img_mlp')),
+                                         ('txt', ('attn.add_k_proj', 'attn.add_v_proj', 'attn.add_q_proj',
+                                                  'attn.to_add_out', 'txt_mlp'))):
+            p[d + stream + '_qkv.weight'] = _cat(sd, [s + k + '.weight', s + v + '.weight', s + q + '.weight'], device)
+            p[d + stream + '_qkv.bias'] = _cat(sd, [s + k + '.bias', s + v + '.bias', s + q + '.bias'], device)
+            lin(d + stream + '_out', s + o)
+            lin(d + stream + '_mlp1', s + ff + '.net.0.proj')
+            lin(d + stream + '_mlp2', s + ff + '.net.2')
+        p[d + 'qknorm'] = torch.stack([sd[s + f'attn.{n}.weight'].float() for n in
+                                       ('norm_q', 'norm_k', 'norm_added_q', 'norm_added_k')]).to(device).contiguous()
+    mod_w.append('norm_out.linear.weight'); mod_b.append('norm_out.linear.bias')
+    p['mod.weight'] = _cat(sd, mod_w, device)
+    p['mod.bias'] = _cat(sd, mod_b, device)
+    p['head.weight'], p['head.bias'] = pack_head(sd, device, K, C, L, teacher)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------
+# Synthetic weights generated directly in the packed layout on the GPU (bench / scaling runs: there is
+# no network for checkpoints, and 12-20 B parameters are too slow to draw on the host).
+def random_packed(family: str, num_double: int, num_single: int, device, heads: int = 24, in_channels: int = 64,
+                  joint_dim: int = 4096, pooled_dim: int = 768, guidance: bool = True, K: int = 16, L: int = 4,
+                  seed: int = 0, teacher: bool = False) -> Dict[str, Tensor]:
+    """Random-init weights of the FLUX / Qwen-Image architecture, N(0, 0.02^2) linears, unit-ish norms."""
+    D = heads * 128
+    g = torch.Generator(device=device).manual_seed(seed)
+    p: Dict[str, Tensor] = {}
+
+    def lin(name, out_f, in_f, std=0.02, bstd=0.02):
+        w = torch.empty(out_f, in_f, dtype=torch.bfloat16, device=device)
+        # draw in slabs: a [12288, 15360] fp32 temporary would cost 750 MB
+        step = max(1, (1 << 26) // in_f)
+        for r0 in range(0, out_f, step):
+            r1 = min(out_f, r0 + step)
+            w[r0:r1] = (torch.randn(r1 - r0, in_f, generator=g, device=device) * std).to(torch.bfloat16)
+        p[name + '.weight'] = w
+        p[name + '.bias'] = (torch.randn(out_f, generator=g, device=device) * bstd).to(torch.bfloat16)
+
+    def norms(name, n):
+        p[name] = (1 + 0.02 * torch.randn(n, 128, generator=g, device=device)).float().contiguous()
+    lin('x_in', D, in_channels, std=0.1)
+    lin('ctx_in', D, joint_dim)
+    if family == 'qwen':
+        p['txt_norm.weight'] = (1 + 0.02 * torch.randn(joint_dim, generator=g, device=device)).float()
+    lin('temb.t.l1', D, 256, std=0.05); lin('temb.t.l2', D, D, std=0.03)
+    if family == 'flux':
+        if guidance:
+            lin('temb.g.l1', D, 256, std=0.05); lin('temb.g.l2', D, D, std=0.03)
+        lin('temb.p.l1', D, pooled_dim, std=0.05); lin('temb.p.l2', D, D, std=0.03)
+    n_mod = num_double * 12 * D + num_single * 3 * D + 2 * D
+    lin('mod', n_mod, D, bstd=0.3)
+    for i in range(num_double):
+        for s in ('img', 'txt'):
+            lin(f'd{i}.{s}_qkv', 3 * D, D); lin(f'd{i}.{s}_out', D, D)
+            lin(f'd{i}.{s}_mlp1', 4 * D, D); lin(f'd{i}.{s}_mlp2', D, 4 * D)
+        norms(f'd{i}.qknorm', 4)
+    for i in range(num_single):
+        lin(f's{i}.fused', 7 * D, D); lin(f's{i}.out', D, 5 * D)
+        norms(f's{i}.qknorm', 2)
+    raw = in_channels if teacher else K * in_channels + K * L + (K - 1) * L
+    lin('head', (raw + 7) // 8 * 8, D)
+    return p

@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 1024x1024 images/s at 2 NFE on the ArcFlow-FLUX-12B architecture (BASELINE.json
+configs[1]), one replica per GPU (images are independent units: weak scaling, no data-path collective).
+
+A "step" = one image: 2 x { denoiser forward (19 double + 38 single MMDiT blocks, 4096 image + 512 text
+tokens, bf16 MFMA) + analytic ArcFlow transport step } with the latents resident in HBM -- the loop of
+lakonlab/pipelines/arcflux_pipeline.py:457-510.  Text encoders and the VAE are outside the hot path
+ and outside the timed region; prompt embeddings are synthetic, weights are random-init of
+the exact architecture (no network for checkpoints).
+
+    python bench.py --gpus N --steps K --warmup W        (torchrun launches N ranks for N > 1)
+
+Prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel (the bf16 MFMA GEMM,
+timed live with HIP events on the launch stream) and a `cpu_baseline` object (the fp32 CPU oracle's
+FluxTransformerBlock on the host cores -- BASELINE.json configs[0] -- extrapolated by FLOPs).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TF = 2500.0        # dense, /opt/skills/guides/MI355X_MICROARCH.md:42
+N_IMG, N_TXT, D_MODEL = 4096, 512, 3072
+FLOPS_PER_FORWARD = 74.41e12      # 57 x (24 S D^2 + 4 S^2 D) + embed/head/mod, S = 4608
+
+
+def build_flux_engine(model: str = 'flux', device: str = 'cuda', seed: int = 0):
+    from arcflow_amd import MMDiTEngine
+    from arcflow_amd.weights import random_packed
+    if model == 'flux':
+        eng = MMDiTEngine('flux', 19, 38, device=device)
+        eng.bind_packed(random_packed('flux', 19, 38, device, seed=seed))
+        T, joint = N_TXT, 4096
+    else:
+        eng = MMDiTEngine('qwen', 60, 0, joint_dim=3584, device=device)
+        eng.bind_packed(random_packed('qwen', 60, 0, device, joint_dim=3584, seed=seed))
+        T, joint = 128, 3584
+    g = torch.Generator(device=device).manual_seed(42)
+    x = torch.randn(1, N_IMG, 64, generator=g, device=device)
+    ctx = (torch.randn(1, T, joint, generator=g, device=device) * 0.1).bfloat16()
+    pooled = (torch.randn(1, 768, generator=g, device=device) * 0.1).bfloat16() if model == 'flux' else None
+    guidance = torch.full((1,), 3.5, device=device) if model == 'flux' else None
+    t = torch.ones(1, device=device)
+    return eng, (x.bfloat16(), t, ctx, pooled, guidance, 64, 64)
+
+
+def cpu_baseline(budget_s: float = 15.0):
+    """BASELINE.json configs[0]: one FLUX double block, bs 1, 256 image + 77 text tokens, fp32, host cores."""
+    from oracle import dit_ref as D
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = D.FluxCfg(num_layers=1, num_single_layers=0)
+    g = torch.Generator().manual_seed(0)
+    w = {}
+    p = 'transformer_blocks.0.'
+    Dm = cfg.dim
+    for nm, o, i in [('norm1.linear', 6 * Dm, Dm), ('norm1_context.linear', 6 * Dm, Dm)] + \
+            [('attn.' + n, Dm, Dm) for n in ('to_q', 'to_k', 'to_v', 'add_q_proj', 'add_k_proj', 'add_v_proj', 'to_out.0', 'to_add_out')] + \
+            [('ff.net.0.proj', 4 * Dm, Dm), ('ff.net.2', Dm, 4 * Dm), ('ff_context.net.0.proj', 4 * Dm, Dm), ('ff_context.net.2', Dm, 4 * Dm)]:
+        w[p + nm + '.weight'] = torch.randn(o, i, generator=g) * 0.02
+        w[p + nm + '.bias'] = torch.randn(o, generator=g) * 0.02
+    for nm in ('norm_q', 'norm_k', 'norm_added_q', 'norm_added_k'):
+        w[p + f'attn.{nm}.weight'] = 1 + 0.02 * torch.randn(128, generator=g)
+    g1 = torch.Generator().manual_seed(1)
+    img, txt = torch.randn(1, 256, Dm, generator=g1), torch.randn(1, 77, Dm, generator=g1)
+    temb = torch.randn(1, Dm, generator=torch.Generator().manual_seed(2))
+    cos, sin = D.flux_rope_tables(16, 16, 77)
+    fn = lambda: D.flux_double_block(w, p, cfg, img, txt, temb, cos, sin)  # noqa: E731
+    for _ in range(3):
+        fn()
+    times = []
+    t_end = time.time() + budget_s
+    while time.time() < t_end or len(times) < 10:
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    med = sorted(times)[len(times) // 2]
+    S = 333
+    flops = 24 * S * Dm * Dm + 4 * S * S * Dm + 2 * 2 * 6 * Dm * Dm      # 77.0 GFLOP
+    gflops = flops / med / 1e9
+    return {
+        'value': gflops * 1e9 / (2 * FLOPS_PER_FORWARD), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+        'sample': f'oracle fp32 FluxTransformerBlock (configs[0]: 256 img + 77 txt tokens, bs 1), median of '
+                  f'{len(times)} runs = {med*1e3:.1f} ms = {gflops:.0f} GFLOP/s, extrapolated by FLOPs to a '
+                  f'148.8 TFLOP 2-NFE image',
+        'block_ms': med * 1e3, 'gflops': gflops,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='flux', choices=['flux', 'qwen'])
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = f'cuda:{local_rank if world > 1 else 0}'
+
+    from arcflow_amd import ops
+    from arcflow_amd.schedule import FlowMatchEulerDiscreteScheduler, retrieve_raw_timesteps
+
+    eng, (x0, t, ctx, pooled, guidance, hp, wp) = build_flux_engine(args.model, dev, seed=rank)
+    raw, counts, _ = retrieve_raw_timesteps(2, 128, 1.0)
+    sch = FlowMatchEulerDiscreteScheduler(shift=3.2)
+    ts = sch.set_timesteps(sigmas=raw)
+    sig = [float(ts[0]) / 1000, float(ts[counts[0]]) / 1000, 0.0]
+    tvec = [torch.full((1,), s, device=dev) for s in sig[:2]]
+    lat = torch.randn(1, N_IMG, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+
+    def one_image():
+        x = lat
+        for i in range(2):
+            out = eng(x.bfloat16(), tvec[i], ctx, pooled, guidance, hp, wp)
+            x = ops.arcflow_step(x, out.means, out.logweights, out.loggammas, sig[i], sig[i], sig[i + 1])
+        return x
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_image()
+    prof = not args.no_profile
+    eng.profile(prof)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = one_image()
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(res).all()
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    gemm_ms, gemm_n, gemm_fl = eng.profile_read(0) if prof else (0.0, 0, 0.0)
+    att_ms, att_n, att_fl = eng.profile_read(1) if prof else (0.0, 0, 0.0)
+    eng.profile(False)
+
+    if rank == 0:
+        flops_img = 2 * (FLOPS_PER_FORWARD if args.model == 'flux' else 70.6e12)
+        ips = world * args.steps / dt
+        line = {
+            'metric': f'1024x1024 images/sec @ 2 NFE ({"FLUX-12B" if args.model == "flux" else "Qwen-Image-20B"} '
+                      f'architecture, denoiser + ArcFlow integrator)',
+            'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt '
+                                     'embeddings, seeded noise latents)',
+            'config': {'workload': 'ArcFlow-FLUX-12B 2-NFE inference, 1024x1024, bs=1 per GPU' if args.model == 'flux'
+                       else 'ArcFlow-Qwen-Image-20B 2-NFE inference, 1024x1024, bs=1 per GPU, T=128',
+                       'image_tokens': N_IMG, 'text_tokens': int(ctx.shape[1]), 'nfe': 2, 'sigmas': sig,
+                       'parallelism': f'{world} independent replica(s), no collective', 'lora': 'merged into base weights'},
+            'mfma_frac_end_to_end': flops_img * ips / world / (MFMA_BF16_PEAK_TF * 1e12),
+        }
+        if prof and gemm_n:
+            ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+            line['roofline'] = {
+                'bound': 'mfma', 'kernel': 'afx::gemm_bf16_kernel', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
+                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': None,
+                'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
+                'algorithmic_flops_per_launch': gemm_fl / gemm_n,
+                'share_of_step_time': gemm_ms * 1e-3 / dt,
+            }
+            if att_n:
+                a2 = att_fl / (att_ms * 1e-3) / 1e12
+                line['roofline_attention'] = {
+                    'bound': 'mfma', 'kernel': 'afx::attention_kernel', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
+                    'unit': 'TFLOP/s', 'frac': a2 / MFMA_BF16_PEAK_TF, 'launches': att_n,
+                    'avg_launch_us': att_ms * 1e3 / att_n, 'share_of_step_time': att_ms * 1e-3 / dt}
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,83 @@
+"""GPU parity of the whole denoiser forward (HIP engine through the C ABI) against the fp32 CPU oracle
+on identical bf16-rounded weights, reduced sizes (the oracle needs seconds)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2.5e-2     # rel-L2 of bf16 trunk outputs vs fp32 oracle (stated tolerance)
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+
+
+def _inputs(B, hp, wp, T, joint, pooled_dim, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    hid = torch.randn(B, hp * wp, 64, generator=g).bfloat16()
+    ctx = torch.randn(B, T, joint, generator=g).bfloat16()
+    pooled = torch.randn(B, pooled_dim, generator=g).bfloat16() if pooled_dim else None
+    return hid, ctx, pooled
+
+
+@pytest.mark.parametrize('B,hp,wp,T,nd,ns', [(1, 8, 8, 16, 2, 2), (2, 6, 10, 7, 1, 3), (1, 16, 16, 77, 1, 0)])
+def test_flux_forward_vs_oracle(B, hp, wp, T, nd, ns):
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=nd, num_single_layers=ns, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=3)
+    hid, ctx, pooled = _inputs(B, hp, wp, T, 128, 64)
+    t = torch.tensor([1.0, 0.7619][:B])
+    gd = torch.full((B,), 3.5)
+    rm, rlw, rlg = D.flux_forward(w, cfg, hid.float(), ctx.float(), pooled.float(), t, gd, hp, wp)
+    eng = MMDiTEngine('flux', nd, ns, heads=2, joint_dim=128, pooled_dim=64)
+    eng.load_state_dict(w)
+    out = eng(hid.cuda(), t.cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), hp, wp)
+    torch.cuda.synchronize()
+    assert out.means.shape == rm.shape and out.logweights.shape == rlw.shape and out.loggammas.shape == rlg.shape
+    assert rel_l2(out.means.float(), rm) < TOL
+    assert rel_l2(out.loggammas.float(), rlg) < TOL
+    assert (out.logweights.float().cpu() - rlw).abs().max().item() < 0.08
+    # log_softmax over K is normalised
+    assert torch.allclose(out.logweights.float().exp().sum(dim=2).cpu(), torch.ones(B, hp * wp, 4), atol=2e-2)
+
+
+def test_flux_teacher_head():
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=1, num_single_layers=1, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=4, teacher_head=True)
+    hid, ctx, pooled = _inputs(1, 8, 8, 12, 128, 64, seed=2)
+    t, gd = torch.tensor([0.6]), torch.tensor([3.5])
+    ref = D.flux_teacher_forward(w, cfg, hid.float(), ctx.float(), pooled.float(), t, gd, 8, 8)
+    eng = MMDiTEngine('flux', 1, 1, heads=2, joint_dim=128, pooled_dim=64, teacher_head=True)
+    eng.load_state_dict(w)
+    out = eng(hid.cuda(), t.cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8)
+    assert out.shape == ref.shape
+    assert rel_l2(out.float(), ref) < TOL
+
+
+@pytest.mark.parametrize('B,hp,wp,T,nl', [(1, 8, 8, 11, 2), (2, 6, 8, 20, 1)])
+def test_qwen_forward_vs_oracle(B, hp, wp, T, nl):
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    cfg = D.QwenCfg(num_layers=nl, heads=2, joint_dim=192)
+    w = D.make_qwen_weights(cfg, seed=5)
+    hid, ctx, _ = _inputs(B, hp, wp, T, 192, 0)
+    t = torch.tensor([1.0, 0.5][:B])
+    rm, rlw, rlg = D.qwen_forward(w, cfg, hid.float(), ctx.float(), t, hp, wp)
+    eng = MMDiTEngine('qwen', nl, 0, heads=2, joint_dim=192)
+    eng.load_state_dict(w)
+    out = eng(hid.cuda(), t.cuda(), ctx.cuda(), None, None, hp, wp)
+    assert rel_l2(out.means.float(), rm) < TOL
+    assert rel_l2(out.loggammas.float(), rlg) < TOL
+    assert (out.logweights.float().cpu() - rlw).abs().max().item() < 0.08
+
+
+def test_engine_errors_are_loud():
+    from arcflow_amd import MMDiTEngine, _lib
+    eng = MMDiTEngine('flux', 1, 0, heads=2, joint_dim=128, pooled_dim=64)
+    with pytest.raises(_lib.ArcflowHipError):      # nothing bound yet
+        eng(torch.zeros(1, 4, 64).cuda(), torch.ones(1).cuda(), torch.zeros(1, 3, 128).cuda(),
+            torch.zeros(1, 64).cuda(), torch.ones(1).cuda(), 2, 2)

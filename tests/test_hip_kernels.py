@@ -1,0 +1,229 @@
+"""GPU parity tests of the HIP kernels, through the C ABI (ctypes), against the CPU oracle / fp32 torch.
+
+bf16 kernels: tolerance stated per test (inputs are bf16-rounded, the oracle computes in fp32).
+fp32 ArcFlow step: rel 1e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from arcflow_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def rel_l2(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (300, 264, 128), (77, 3072, 4096), (1000, 520, 3072), (513, 1152, 192)])
+def test_linear_plain(ops, M, N, K):
+    g = torch.Generator().manual_seed(M + N + K)
+    a = bf(torch.randn(M, K, generator=g)).to(dev())
+    w = bf(torch.randn(N, K, generator=g) * 0.05).to(dev())
+    b = bf(torch.randn(N, generator=g)).to(dev())
+    out = ops.linear(a, w, b)
+    ref = a.float() @ w.float().T + b.float()
+    assert rel_l2(out, ref) < 4e-3            # bf16 output rounding only (fp32 accumulate)
+    assert (out.float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+
+
+def test_linear_identity_asymmetric(ops):
+    """A = I against an asymmetric W catches row/col swaps in the MFMA -> C mapping exactly."""
+    n = 512
+    a = torch.eye(n, dtype=torch.bfloat16, device=dev())
+    w = bf(torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251 - 125).to(dev())   # exact in bf16
+    out = ops.linear(a, w, None)
+    assert torch.equal(out.float(), w.float().T)
+
+
+def test_linear_strided_gelu_cols(ops):
+    g = torch.Generator().manual_seed(5)
+    M, K, N = 333, 256, 512
+    big = bf(torch.randn(M, 3 * K, generator=g)).to(dev())
+    a = big[:, K:2 * K]                                   # lda = 3K
+    w = bf(torch.randn(N, K, generator=g) * 0.06).to(dev())
+    b = bf(torch.randn(N, generator=g)).to(dev())
+    outbuf = torch.zeros(M, N + 64, dtype=torch.bfloat16, device=dev())
+    out = ops.linear(a, w, b, epilogue='gelu', gelu_col0=256, out=outbuf[:, :N])
+    y = a.float() @ w.float().T + b.float()
+    ref = torch.cat([y[:, :256], torch.nn.functional.gelu(y[:, 256:], approximate='tanh')], dim=1)
+    assert rel_l2(out, ref) < 4e-3
+    assert outbuf[:, N:].abs().max().item() == 0           # nothing written past N
+
+
+def test_linear_gate_residual_inplace(ops):
+    g = torch.Generator().manual_seed(6)
+    B, S, K, N = 2, 150, 512, 256
+    a = bf(torch.randn(B * S, K, generator=g)).to(dev())
+    w = bf(torch.randn(N, K, generator=g) * 0.05).to(dev())
+    b = bf(torch.randn(N, generator=g)).to(dev())
+    gate = torch.randn(B, N, generator=g).to(dev())
+    x = bf(torch.randn(B * S, N, generator=g)).to(dev())
+    ref = x.float() + gate.repeat_interleave(S, 0) * (a.float() @ w.float().T + b.float())
+    out = ops.linear(a, w, b, epilogue='gate_res', gate=gate, residual=x, rows_per_batch=S, out=x)
+    assert out.data_ptr() == x.data_ptr()
+    assert rel_l2(out, ref) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2), (1, 129, 1)])
+def test_attention(ops, B, S, H):
+    g = torch.Generator().manual_seed(S)
+    q = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
+    k = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
+    v = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
+    out = ops.attention(q, k, v)
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2).reshape(B, S, H * 128)
+    assert rel_l2(out, ref) < 1.2e-2           # P is rounded to bf16 before P.V, output bf16
+    assert torch.isfinite(out.float()).all()
+
+
+def test_attention_spiked_rows(ops):
+    """One key dominating a query row late in the sequence forces a large online-softmax rescale."""
+    g = torch.Generator().manual_seed(3)
+    B, S, H = 1, 320, 1
+    q = torch.randn(B, S, H, 128, generator=g)
+    k = torch.randn(B, S, H, 128, generator=g)
+    v = torch.randn(B, S, H, 128, generator=g)
+    k[0, 300, 0] = q[0, 7, 0] * 3.0
+    k[0, 10, 0] = q[0, 100, 0] * 3.0
+    q, k, v = (bf(t).to(dev()) for t in (q, k, v))
+    out = ops.attention(q, k, v)
+    ref = torch.nn.functional.scaled_dot_product_attention(
+        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2).reshape(B, S, 128)
+    assert (out.float() - ref).abs().max().item() < 0.06
+    assert rel_l2(out, ref) < 1.2e-2
+
+
+# ------------------------------------------------------------------------------------------ norms / rope / gemv
+@pytest.mark.parametrize('D', [256, 3072, 3584])
+def test_norm_modulate(ops, D):
+    g = torch.Generator().manual_seed(D)
+    B, S = 2, 37
+    x = bf(torch.randn(B * S, D, generator=g) * 2 + 0.3).to(dev())
+    sc = torch.randn(B, D, generator=g).to(dev())
+    sh = torch.randn(B, D, generator=g).to(dev())
+    out = ops.norm_modulate(x, sc, sh, rows_per_batch=S)
+    xf = x.float()
+    ref = torch.nn.functional.layer_norm(xf, (D,), eps=1e-6) * (1 + sc.repeat_interleave(S, 0)) + sh.repeat_interleave(S, 0)
+    assert rel_l2(out, ref) < 4e-3
+    w = (1 + 0.1 * torch.randn(D, generator=g)).to(dev())
+    out = ops.norm_modulate(x, w, None, rms=True)
+    ref = xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    assert rel_l2(out, ref) < 4e-3
+
+
+def test_qk_norm_rope(ops):
+    from oracle import dit_ref as D
+    g = torch.Generator().manual_seed(11)
+    B, hp, wp, T, H = 2, 5, 6, 9, 3
+    S = T + hp * wp
+    x = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
+    wt = (1 + 0.1 * torch.randn(128, generator=g))
+    wi = (1 + 0.1 * torch.randn(128, generator=g))
+    cos, sin = D.flux_rope_tables(hp, wp, T)
+    ref_t = D.apply_rope(D.rms_norm(x.float().cpu()[:, :T], wt), cos[:T], sin[:T])
+    ref_i = D.apply_rope(D.rms_norm(x.float().cpu()[:, T:], wi), cos[T:], sin[T:])
+    ref = torch.cat([ref_t, ref_i], dim=1)
+    out = ops.qk_norm_rope_(x.clone(), wt.to(dev()), wi.to(dev()), cos.to(dev()), sin.to(dev()), T)
+    assert rel_l2(out, ref) < 4e-3
+    # Qwen tables through the same kernel
+    from arcflow_amd import rope
+    ia, ta = D.qwen_rope_angles(hp, wp, T)
+    c2, s2 = rope.qwen_tables(hp, wp, T)
+    assert torch.allclose(c2, torch.cat([torch.cos(ta), torch.cos(ia)]), atol=1e-6)
+    assert torch.allclose(s2, torch.cat([torch.sin(ta), torch.sin(ia)]), atol=1e-6)
+
+
+def test_gemv(ops):
+    g = torch.Generator().manual_seed(12)
+    B, N, K = 3, 1030, 3072
+    x = torch.randn(B, K, generator=g).to(dev())
+    w = bf(torch.randn(N, K, generator=g) * 0.02).to(dev())
+    b = bf(torch.randn(N, generator=g)).to(dev())
+    ref = x @ w.float().T + b.float()
+    out = ops.gemv(x, w, b)
+    assert rel_l2(out, ref) < 1e-5
+    out2 = ops.gemv(x, w, b, act='silu', out=out.clone(), accumulate=True)
+    assert rel_l2(out2, ref + torch.nn.functional.silu(ref)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ ArcFlow step
+def test_arcflow_step_golden(ops, golden):
+    """The HIP step in the token layout == the reference's unpack -> policy -> integrate -> repack."""
+    g = golden('g5_layouts')
+    x, m, lw, lg = (torch.from_numpy(g[k]).to(dev()) for k in ('x_tok', 'means_tok', 'logw_tok', 'logg_tok'))
+    out = ops.arcflow_step(x, m, lw, lg, 1.0, 1.0, float(np.float32(761.9047761) / 1000))
+    ref = torch.from_numpy(g['x_end_tok'])
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+def test_arcflow_step_vs_oracle_edge_cases(ops):
+    from oracle import arcflow_ref as R
+    g = torch.Generator().manual_seed(21)
+    B, N, K, ch, pp = 2, 50, 16, 64, 4
+    x = torch.randn(B, N, ch, generator=g)
+    m = torch.randn(B, N, K, ch, generator=g)
+    lw = torch.log_softmax(torch.randn(B, N, K, pp, generator=g) * 2, dim=2)
+    lg = torch.randn(B, N, K - 1, pp, generator=g)
+    lg[0, 0] = 0.0            # phi clamp, z == 0 -> +eps branch
+    lg[0, 1] = 1e-5
+    lg[0, 2] = -1e-5
+    lw[1, 3, 5] = float('-inf')   # dropped component (GM dropout)
+    for (s0, s1, s2) in [(1.0, 1.0, 0.7619), (0.7619, 0.7619, 0.0), (1.0, 0.9, 0.4), (0.5, 0.5, 0.5)]:
+        ref = R.momentum_step_packed(x, m, lw, lg, s0, s1, s2)
+        out = ops.arcflow_step(x.to(dev()), m.to(dev()), lw.to(dev()), lg.to(dev()), s0, s1, s2)
+        assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=2e-5), (s0, s1, s2)
+    # per-sample sigmas (training form) + bf16 mixture inputs
+    sv = [torch.tensor([1.0, 0.8]), torch.tensor([0.9, 0.6]), torch.tensor([0.5, 0.1])]
+    out = ops.arcflow_step(x.to(dev()), m.to(dev()), lw.to(dev()), lg.to(dev()), *[s.to(dev()) for s in sv])
+    for b in range(B):
+        ref = R.momentum_step_packed(x[b:b + 1], m[b:b + 1], lw[b:b + 1], lg[b:b + 1], *[float(s[b]) for s in sv])
+        assert torch.allclose(out[b:b + 1].cpu(), ref, rtol=1e-5, atol=2e-5)
+    mb, lwb, lgb = bf(m), bf(lw), bf(lg)
+    out = ops.arcflow_step(x.to(dev()), mb.to(dev()), lwb.to(dev()), lgb.to(dev()), 1.0, 1.0, 0.7619)
+    ref = R.momentum_step_packed(x, mb.float(), lwb.float(), lgb.float(), 1.0, 1.0, 0.7619)
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=2e-5)
+    # velocity
+    u = ops.arcflow_velocity(m.to(dev()), lw.to(dev()), lg.to(dev()), 1.0, 0.8)
+    hp, wp = 5, 10
+    ml, lwl, lgl = R.unpack_mixture(m, lw, lg, hp, wp)
+    uref = R.pack_latents(R.policy_velocity(ml, lwl, lgl, 1.0, 0.8))
+    assert torch.allclose(u.cpu(), uref, rtol=1e-5, atol=2e-5)
+
+
+def test_arcflow_step_full_size_properties(ops):
+    """1024^2 sizes: (i) a mixture with all rates -> 0 and equal means is an Euler step; (ii) steps compose
+    exactly when sigma_src is kept (semigroup of the closed-form transport)."""
+    g = torch.Generator().manual_seed(31)
+    B, N, K, ch, pp = 1, 4096, 16, 64, 4
+    x = torch.randn(B, N, ch, generator=g).to(dev())
+    m1 = torch.randn(B, N, 1, ch, generator=g).expand(B, N, K, ch).contiguous().to(dev())
+    lw = torch.log_softmax(torch.randn(B, N, K, pp, generator=g), dim=2).to(dev())
+    z = torch.zeros(B, N, K - 1, pp, device=dev())
+    out = ops.arcflow_step(x, m1, lw, z, 1.0, 1.0, 0.25)
+    phi_eps = float(np.expm1(np.float32(1e-4)) / np.float32(1e-4))
+    assert torch.allclose(out, x - 0.75 * m1[:, :, 0], rtol=2e-4, atol=2e-4)
+    m = torch.randn(B, N, K, ch, generator=g).to(dev())
+    lg = (torch.randn(B, N, K - 1, pp, generator=g)).to(dev())
+    a = ops.arcflow_step(x, m, lw, lg, 1.0, 1.0, 0.3)
+    mid = ops.arcflow_step(x, m, lw, lg, 1.0, 1.0, 0.7)
+    b = ops.arcflow_step(mid, m, lw, lg, 1.0, 0.7, 0.3)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
