@@ -50,11 +50,10 @@ def build_flux_engine(model: str = 'flux', device: str = 'cuda', seed: int = 0):
     return eng, (x.bfloat16(), t, ctx, pooled, guidance, 64, 64)
 
 
-def cpu_baseline(budget_s: float = 15.0):
+def cpu_baseline(budget_s: float = 12.0):
     """BASELINE.json configs[0]: one FLUX double block, bs 1, 256 image + 77 text tokens, fp32, host cores."""
     from oracle import dit_ref as D
     cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     cfg = D.FluxCfg(num_layers=1, num_single_layers=0)
     g = torch.Generator().manual_seed(0)
     w = {}
@@ -72,11 +71,24 @@ def cpu_baseline(budget_s: float = 15.0):
     temb = torch.randn(1, Dm, generator=torch.Generator().manual_seed(2))
     cos, sin = D.flux_rope_tables(16, 16, 77)
     fn = lambda: D.flux_double_block(w, p, cfg, img, txt, temb, cos, sin)  # noqa: E731
-    for _ in range(3):
+    # the box may expose far more hardware threads than torch's CPU GEMM can use: calibrate the thread
+    # count on one run each (a candidate slower than 4 s is abandoned), then sample the best one.
+    best_thr, best_t = 1, float('inf')
+    for thr in sorted({min(cores, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(thr)
         fn()
+        t0 = time.perf_counter()
+        fn()
+        el = time.perf_counter() - t0
+        if el < best_t:
+            best_thr, best_t = thr, el
+        if el > 4.0:
+            break
+    torch.set_num_threads(best_thr)
+    cores_used = best_thr
     times = []
     t_end = time.time() + budget_s
-    while time.time() < t_end or len(times) < 10:
+    while (time.time() < t_end or len(times) < 3) and len(times) < 200:
         t0 = time.perf_counter()
         fn()
         times.append(time.perf_counter() - t0)
@@ -85,7 +97,7 @@ def cpu_baseline(budget_s: float = 15.0):
     flops = 24 * S * Dm * Dm + 4 * S * S * Dm + 2 * 2 * 6 * Dm * Dm      # 77.0 GFLOP
     gflops = flops / med / 1e9
     return {
-        'value': gflops * 1e9 / (2 * FLOPS_PER_FORWARD), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+        'value': gflops * 1e9 / (2 * FLOPS_PER_FORWARD), 'unit': 'images/s', 'cores': cores_used, 'host_cpus': cores, 'kind': 'port',
         'sample': f'oracle fp32 FluxTransformerBlock (configs[0]: 256 img + 77 txt tokens, bs 1), median of '
                   f'{len(times)} runs = {med*1e3:.1f} ms = {gflops:.0f} GFLOP/s, extrapolated by FLOPs to a '
                   f'148.8 TFLOP 2-NFE image',
