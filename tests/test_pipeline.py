@@ -1,0 +1,129 @@
+"""Drop-in surface: adapter loader contract (CPU) and the 2-NFE pipeline end to end against the oracle (GPU)."""
+import json
+import os
+import warnings
+
+import pytest
+import torch
+
+
+def _write_adapter(tmp, cls_name, sd, meta=True):
+    from safetensors.torch import save_file
+    d = os.path.join(tmp, 'arcflow-flux-2steps')
+    os.makedirs(d, exist_ok=True)
+    json.dump({'_class_name': cls_name, 'num_gaussians': 16, 'logweights_channels': 4}, open(os.path.join(d, 'config.json'), 'w'))
+    save_file({k: v.contiguous() for k, v in sd.items()}, os.path.join(d, 'diffusion_pytorch_model.safetensors'),
+              metadata={'policy_config': json.dumps({'type': 'ArcFlow'})} if meta else None)
+    return tmp
+
+
+def _tiny():
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=1, num_single_layers=1, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=9, teacher_head=True)
+    tcfg = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, attention_head_dim=128, in_channels=64,
+                joint_attention_dim=128, pooled_projection_dim=64, guidance_embeds=True)
+    return cfg, w, tcfg
+
+
+def test_loader_contract_cpu(tmp_path):
+    from arcflow_amd.pipelines import ArcFluxPipeline
+    cfg, w, tcfg = _tiny()
+    pipe = ArcFluxPipeline()
+    pipe._transformer_config, pipe._base_state_dict = tcfg, w
+    heads = {k: v for k, v in w.items() if k.startswith('proj_out_')}
+    root = _write_adapter(str(tmp_path / 'a'), 'SomethingElse', heads)
+    with pytest.raises(ValueError, match="Can't find a model linked to SomethingElse"):
+        pipe.load_arcflow_adapter(root, subfolder='arcflow-flux-2steps')
+    root = _write_adapter(str(tmp_path / 'b'), 'ArcFluxTransformer2DModel', heads)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        assert pipe.load_arcflow_adapter(root, subfolder='arcflow-flux-2steps', target_module_name='transformer') is None
+    assert any('No LoRA weights' in str(r.message) for r in rec)
+    with pytest.raises(TypeError):
+        pipe.load_arcflow_adapter(root, subfolder='arcflow-flux-2steps', bogus=1)
+    with pytest.raises(EnvironmentError):
+        pipe.load_arcflow_adapter('ymyy307/ArcFlow', subfolder='arcflow-flux-2steps')     # no network: local dirs only
+    with pytest.raises(AssertionError):
+        ArcFluxPipeline(policy_type='GMFlow')
+
+
+@pytest.mark.gpu
+def test_flux_pipeline_two_nfe_vs_oracle(tmp_path):
+    from arcflow_amd import FlowMatchEulerDiscreteScheduler
+    from arcflow_amd.pipelines import ArcFluxPipeline
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg, w, tcfg = _tiny()
+    g = torch.Generator().manual_seed(2)
+    name = 'single_transformer_blocks.0.proj_mlp'
+    lora = {name + '.lora_A.weight': (torch.randn(8, 256, generator=g) * 0.05).bfloat16(),
+            name + '.lora_B.weight': (torch.randn(1024, 8, generator=g) * 0.05).bfloat16()}
+    adapter = {k: v for k, v in w.items() if k.startswith('proj_out_') or k.startswith('norm_out')}
+    adapter['norm_out.linear.bias'] = adapter['norm_out.linear.bias'] + 0.125      # overlay must win over the base
+    adapter.update(lora)
+    root = _write_adapter(str(tmp_path), 'ArcFluxTransformer2DModel', adapter)
+
+    base = {k: v for k, v in w.items() if not k.startswith('proj_out_')}
+    pipe = ArcFluxPipeline.from_state_dict(tcfg, base, student=False)                # plain FLUX (teacher head)
+    name_ret = pipe.load_arcflow_adapter(root, subfolder='arcflow-flux-2steps', target_module_name='transformer')
+    assert name_ret == 'transformer_arcflow'
+    pipe.scheduler = FlowMatchEulerDiscreteScheduler.from_config(pipe.scheduler.config, shift=3.2, shift_terminal=None,
+                                                                 use_dynamic_shifting=False)
+    pipe = pipe.to('cuda')
+    T = 12
+    pe = (torch.randn(1, T, 128, generator=g) * 0.5).bfloat16()
+    pp = (torch.randn(1, 64, generator=g) * 0.5).bfloat16()
+    gen = torch.Generator(device='cuda').manual_seed(42)
+    out = pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, num_images_per_prompt=1, width=128, height=128,
+               num_inference_steps=2, generator=gen, timestep_ratio=1.0, output_type='latent').images
+    assert out.shape == (1, 64, 64) and out.dtype == torch.float32
+
+    # oracle: same noise, LoRA merged the same way, fp32 math
+    gen = torch.Generator(device='cuda').manual_seed(42)
+    noise = torch.randn(1, 16, 16, 16, generator=gen, device='cuda').cpu()
+    x = R.pack_latents(noise)
+    wm = dict(w)
+    wm.update({k: v for k, v in adapter.items() if 'lora' not in k})
+    wm[name + '.weight'] = (w[name + '.weight'].float() + lora[name + '.lora_B.weight'].float() @ lora[name + '.lora_A.weight'].float()).bfloat16()
+    sig, _ = R.inference_sigmas(2)
+    for i in range(2):
+        m, lw, lg = D.flux_forward(wm, cfg, x.bfloat16().float(), pe.float(), pp.float(), torch.tensor([sig[i]]),
+                                   torch.tensor([3.5]), 8, 8)
+        x = R.momentum_step_packed(x, m, lw, lg, sig[i], sig[i], sig[i + 1])
+    err = ((out.cpu() - x).norm() / x.norm()).item()
+    assert err < 2.5e-2, err
+
+    # nfe=4 / ratio 0.5 default path also runs and the callback sees every step
+    seen = []
+    pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, output_type='latent',
+         callback_on_step_end=lambda p, i, t, kw: (seen.append(i), kw)[1])
+    assert seen == [0, 1, 2, 3]
+    with pytest.raises(RuntimeError, match='VAE'):
+        pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, num_inference_steps=2)
+
+
+@pytest.mark.gpu
+def test_qwen_pipeline_runs_vs_oracle():
+    from arcflow_amd import FlowMatchEulerDiscreteScheduler
+    from arcflow_amd.pipelines import ArcQwenImagePipeline
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg = D.QwenCfg(num_layers=2, heads=2, joint_dim=192)
+    w = D.make_qwen_weights(cfg, seed=5)
+    tcfg = dict(num_layers=2, num_attention_heads=2, attention_head_dim=128, in_channels=64, joint_attention_dim=192)
+    pipe = ArcQwenImagePipeline.from_state_dict(tcfg, w, scheduler=FlowMatchEulerDiscreteScheduler(shift=3.2))
+    g = torch.Generator().manual_seed(3)
+    pe = (torch.randn(1, 20, 192, generator=g) * 0.5).bfloat16()
+    mask = torch.zeros(1, 20, dtype=torch.long)
+    mask[:, :13] = 1
+    lat = torch.randn(1, 64, 64, generator=g)
+    out = pipe(prompt_embeds=pe, prompt_embeds_mask=mask, latents=lat, width=128, height=128, num_inference_steps=2,
+               timestep_ratio=1.0, output_type='latent', return_dict=False)[0]
+    x = lat.clone()
+    sig, _ = R.inference_sigmas(2)
+    for i in range(2):
+        m, lw, lg = D.qwen_forward(w, cfg, x.bfloat16().float(), pe[:, :13].float(), torch.tensor([sig[i]]), 8, 8)
+        x = R.momentum_step_packed(x, m, lw, lg, sig[i], sig[i], sig[i + 1])
+    err = ((out.cpu() - x).norm() / x.norm()).item()
+    assert err < 2.5e-2, err
