@@ -12,6 +12,8 @@
 //     bias / GELU / gate*x+residual run on row-contiguous data and C is stored 16 B per lane.
 //   * several problems (image + text stream, or per-sample slices) share one launch; the 1-D
 //     grid is remapped so every XCD owns a contiguous run of tiles (private-L2 reuse of A/W panels).
+#include <cstdlib>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -173,6 +175,221 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   }
 }
 
+
+// =================================================================================================
+// v2: 8-phase schedule -- two wave groups ping-pong on every SIMD, 4-deep counted DMA pipeline.
+//
+// Same 256x256x64 tile / 8 waves (wr = wave>>2 in M, wc = wave&3 in N) / 128 accumulators per lane,
+// but the K-tile is consumed in FOUR phases of 16 MFMAs (one 64x32 quadrant of the wave's 128x64 patch
+// each) and the operand tile is cut into four 16 KiB "half tiles", each consumed in exactly ONE phase:
+//     X0 / X1 : A rows of quadrant row-half mh = 0 / 1 of both wave rows   (local row = wr*64 + r)
+//     Y0 / Y1 : W rows of quadrant col-half nh = 0 / 1 of all four wave cols (local row = wc*32 + c)
+//     phase q : 0 -> (mh0,nh0) reads X0+Y0   1 -> (mh0,nh1) reads Y1   2 -> (mh1,nh1) reads X1
+//               3 -> (mh1,nh0) reads nothing (the nh0 fragments stay in registers)
+// Every phase also issues the LDS-DMA of ONE half tile (2 x global_load_lds_dwordx4 per lane):
+//     q=0: Y1(t+1)   q=1: X1(t+1)   q=2: Y0(t+2)   q=3: X0(t+2)
+// A slot is re-staged >= 2 phases after its only read and >= 4 phases before its next read, so the
+// wait in front of a phase's first barrier is always `s_waitcnt vmcnt(8)` (4 half tiles stay in
+// flight across the barriers; never vmcnt(0) in the loop).  Wave group wr=1 runs one barrier behind
+// group wr=0: on every SIMD one wave issues its 16 MFMAs while its partner does ds_reads + DMA issue.
+// Phase anatomy:  ds_read quadrant | stage | vmcnt(8) | s_barrier | lgkmcnt(0) | 16 MFMA | s_barrier.
+// RAW: a half tile is waited for (by its issuing waves) before the first barrier of phase r-1 and read in
+// phase r; WAR: see above.  Loads for tiles past K are clamped to the last tile (keeps the count uniform).
+constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
+
+AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int kbyte, char* slot, int wave) {
+  const char* s0 = reinterpret_cast<const char*>(p0) + kbyte;
+  const char* s1 = reinterpret_cast<const char*>(p1) + kbyte;
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)s0, (lds_void_t*)(slot + (wave * 64) * 16), 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((gbl_void_t*)s1, (lds_void_t*)(slot + (GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
+}
+
+#define AFX_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define AFX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const GemmBatch batch) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
+  const GemmProblem& P = batch.p[pi];
+  wg -= P.tile_start;
+  const int per_group = GROUP_M * P.tiles_n;
+  const int grp = wg / per_group;
+  const int first_m = grp * GROUP_M;
+  const int gsz = min(P.tiles_m - first_m, GROUP_M);
+  const int in_grp = wg - grp * per_group;
+  const int tm = first_m + in_grp % gsz;
+  const int tn = in_grp / gsz;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int nk = P.K / BK;
+
+  // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
+  const bf16_t* src[4][2];     // [X0, X1, Y0, Y1][chunk i]
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int p = i * GEMM_THREADS + tid;
+    const int lr = p >> 3;                              // local row of the half tile
+    const int c = (p & 7) ^ ((lr >> 1) & 7);            // logical 16-byte chunk stored at physical p & 7
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int ar = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
+      ar = ar < P.M ? ar : P.M - 1;
+      src[h][i] = P.A + (int64_t)ar * P.lda + c * 8;
+      int br = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
+      br = br < P.N ? br : P.N - 1;
+      src[2 + h][i] = P.W + (int64_t)br * P.ldw + c * 8;
+    }
+  }
+  // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
+  auto slot = [&](int t, int h) -> char* { return smem + (((t & 1) << 2) + h) * HALF_BYTES; };
+  auto kb = [&](int t) -> int { return (t < nk ? t : nk - 1) * (BK * 2); };
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue = the staging of virtual phases -6..-1 -------------------------------------
+  stage_half(src[2][0], src[2][1], kb(0), slot(0, 2), wave);   // Y0(0)
+  stage_half(src[0][0], src[0][1], kb(0), slot(0, 0), wave);   // X0(0)
+  stage_half(src[3][0], src[3][1], kb(0), slot(0, 3), wave);   // Y1(0)
+  stage_half(src[1][0], src[1][1], kb(0), slot(0, 1), wave);   // X1(0)
+  stage_half(src[2][0], src[2][1], kb(1), slot(1, 2), wave);   // Y0(1)
+  stage_half(src[0][0], src[0][1], kb(1), slot(1, 0), wave);   // X0(1)
+  AFX_WAIT_VM8();                       // Y0(0), X0(0) landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();         // ... and everybody else's
+  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int arow = wr * 64 + frow;      // + i*16
+  const int brow = wc * 32 + frow;      // + j*16
+  bf16x8_t af[2][4], b0[2][2], b1[2][2];    // [kk][tile]
+
+#define AFX_MFMA_QUAD(MH, NH, BF)                                                                   \
+  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
+    acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
+        af[kk][i], BF[kk][j], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);
+
+#define AFX_PHASE_TAIL(MH, NH, BF)                                                                  \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  AFX_WAIT_LGKM0();                                                                                 \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_setprio(1);                                                                    \
+  AFX_MFMA_QUAD(MH, NH, BF)                                                                         \
+  __builtin_amdgcn_s_setprio(0);                                                                    \
+  __builtin_amdgcn_sched_barrier(0);                                                                \
+  __builtin_amdgcn_s_barrier();                                                                     \
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int t = 0; t < nk; ++t) {
+    const char* x0 = slot(t, 0);
+    const char* x1 = slot(t, 1);
+    const char* y0 = slot(t, 2);
+    const char* y1 = slot(t, 3);
+    // ---- phase 0: quadrant (mh0, nh0) -----------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b0[kk][j] = lds_frag(y0, brow + j * 16, kk * 4 + fq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = lds_frag(x0, arow + i * 16, kk * 4 + fq);
+    }
+    stage_half(src[3][0], src[3][1], kb(t + 1), slot(t + 1, 3), wave);   // Y1(t+1)
+    AFX_WAIT_VM8();
+    AFX_PHASE_TAIL(0, 0, b0)
+    // ---- phase 1: quadrant (mh0, nh1) -----------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b1[kk][j] = lds_frag(y1, brow + j * 16, kk * 4 + fq);
+    stage_half(src[1][0], src[1][1], kb(t + 1), slot(t + 1, 1), wave);   // X1(t+1)
+    AFX_WAIT_VM8();
+    AFX_PHASE_TAIL(0, 1, b1)
+    // ---- phase 2: quadrant (mh1, nh1) -----------------------------------------------------
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[kk][i] = lds_frag(x1, arow + i * 16, kk * 4 + fq);
+    stage_half(src[2][0], src[2][1], kb(t + 2), slot(t, 2), wave);       // Y0(t+2)
+    AFX_PHASE_TAIL(1, 1, b1)
+    // ---- phase 3: quadrant (mh1, nh0), operands already in registers --------------------------
+    stage_half(src[0][0], src[0][1], kb(t + 2), slot(t, 0), wave);       // X0(t+2)
+    AFX_WAIT_VM8();
+    AFX_PHASE_TAIL(1, 0, b0)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail DMAs must land before LDS is reused
+  if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
+  __syncthreads();
+
+  // ---- epilogue (identical to v1) -------------------------------------------------------------
+  float* patch = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+  const int wm = wr, wn = wc;
+  const int er = lane >> 3;
+  const int ec = (lane & 7) * 8;
+  const int gcol = n0 + wn * 64 + ec;
+  const bool col_ok = gcol < P.N;
+  float bias[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+  if (P.bias != nullptr && col_ok) {
+    const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol);
+    unpack8(bw, bias);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {
+      const int lr = ps * 8 + er;
+      const int grow = m0 + wm * 128 + h * 64 + lr;
+      if (grow < P.M && col_ok) {
+        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
+        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
+        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bias[e];
+        if (P.epi == EPI_GELU) {
+          if (gcol >= P.gelu_col0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+          }
+        } else if (P.epi == EPI_GATE_RES) {
+          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
+          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
+          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
+          const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
+          float rr[8];
+          unpack8(rw, rr);
+          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
+        }
+        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
+      }
+    }
+  }
+}
+
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < batch.nprob; ++i) {
@@ -184,14 +401,21 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   }
   batch.total_tiles = total;
   if (total == 0) return hipSuccess;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("AFX_GEMM_IMPL");
+    impl = (e && e[0] == '1') ? 1 : 2;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel_v2),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    if (r != hipSuccess) return r;
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+  if (impl == 1)
+    hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+  else
+    hipLaunchKernelGGL(gemm_bf16_kernel_v2, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   return hipGetLastError();
 }
 
