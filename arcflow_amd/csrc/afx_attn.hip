@@ -27,6 +27,7 @@ constexpr int ATT_WAVES = 4;
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int QB = ATT_WAVES * QW; // queries per work-group
 constexpr int STAGE_BYTES = 2 * KVB * HD * 2;
+constexpr float RESCALE_LOG2 = 5.0f;   // defer the O rescale until a row max grew by > 2^5
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -79,14 +80,22 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
-    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad) {
+    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B) {
   // two stages of { K tile [64][128] | V^T tile [128][64] }, 16 KiB each -> 64 KiB
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hi = lane >> 5;
-  const int h = blockIdx.y, b = blockIdx.z;
-  const int q0 = blockIdx.x * QB + wave * QW;
+  // 1-D grid, head -> XCD affinity: block id x runs on XCD x % 8 (observed dispatch order; speed only),
+  // so XCD x owns heads x, x+8, x+16, ...: the K / V^T of the 1-2 heads an XCD works on at a time
+  // (2.4 MB per head at S = 4608) stay resident in that XCD's private 4 MiB L2 while its q-tiles sweep them.
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int per_head = nq * B;
+  const int h = xcd + 8 * (slot_id / per_head);
+  if (h >= H) return;
+  const int rem = slot_id % per_head;
+  const int b = rem / nq;
+  const int q0 = (rem % nq) * QB + wave * QW;
   const int qrow = min(q0 + ql, S - 1);
   const int ntiles = S_pad / KVB;
 
@@ -114,42 +123,75 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const int kv0 = t * KVB;
     char* kd = smem + buf * STAGE_BYTES;
     char* vd = kd + KVB * HD * 2;
+    // keep the per-lane source addresses a short recomputation (opaque seed) instead of 8 live 64-bit
+    // induction pointers: those 16 VGPRs are what pushed the loop into scratch spills.
+    int seed = tid;
+    asm volatile("" : "+v"(seed));
+    const int r0 = seed >> 4, cp = seed & 15;        // K: row r0 + 16 i, physical chunk cp
+    const int kswz = (cp ^ (r0 & 15)) << 3;
+    const int d0 = seed >> 3, vp = seed & 7;         // V^T: row d0 + 32 i, physical chunk vp
+    const int vswz = (vp ^ ((d0 >> 1) & 7)) << 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int p = i * ATT_THREADS + tid;
-      const int r = p >> 4, cp = p & 15;
-      const int kr = min(kv0 + r, S - 1);
-      const bf16_t* ksrc = kbase + (int64_t)kr * ldk + ((cp ^ (r & 15)) << 3);
+      const int kr = min(kv0 + r0 + 16 * i, S - 1);
+      const bf16_t* ksrc = kbase + (int64_t)kr * ldk + kswz;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
-      const int d = p >> 3, vp = p & 7;
-      const bf16_t* vsrc = vbase + (int64_t)d * S_pad + kv0 + ((vp ^ ((d >> 1) & 7)) << 3);
+      const bf16_t* vsrc = vbase + (int64_t)(d0 + 32 * i) * S_pad + kv0 + vswz;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)vsrc, (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
     }
   };
 
   stage_tile(0, 0);
+  if (ntiles > 1) stage_tile(1, 1);
   __syncthreads();
+  // Pin the Q fragments as landed HERE: otherwise their pending global loads reach the loop header and
+  // hipcc's conservative merge turns the first in-loop wait into vmcnt(0).
+#pragma unroll
+  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
+
+  // Software pipeline per KV tile t (buffer t&1):
+  //   A  ds_read all 16 K fragments of tile t
+  //   B  16 MFMAs  S^T = K Q^T
+  //   C  ds_read all 16 V^T fragments of tile t                  [latency hides under the softmax VALU]
+  //   D  online softmax in registers -> P^T fragments
+  //   E  __syncthreads: tile t+1 landed (vmcnt 0), nobody reads buffer t&1 any more
+  //   F  LDS-DMA tile t+2 into buffer t&1                              [hides under G and the next B..D]
+  //   G  16 MFMAs  O^T += V^T P^T
+  bf16x8_t kf0[8], kf1[8], vf[4][4];
 
   for (int t = 0; t < ntiles; ++t) {
     const char* ks = smem + (t & 1) * STAGE_BYTES;
     const char* vs = ks + KVB * HD * 2;
-    if (t + 1 < ntiles) stage_tile(t + 1, (t + 1) & 1);   // DMA of the next tile runs under this tile's MFMAs
-
-    // ---- S^T = K Q^T : two 32-key blocks ---------------------------------------------------
-    f32x16_t sacc[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-      const int krow = kb * 32 + ql;
+    // ---- A ----
+    {
+      const int krow = 32 + ql;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        const int chunk = (s * 2 + hi) ^ (krow & 15);
-        const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(ks + krow * 256 + (chunk << 4));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[s], sacc[kb], 0, 0, 0);
+        kf0[s] = *reinterpret_cast<const bf16x8_t*>(ks + ql * 256 + (((s * 2 + hi) ^ (ql & 15)) << 4));
+        kf1[s] = *reinterpret_cast<const bf16x8_t*>(ks + krow * 256 + (((s * 2 + hi) ^ (krow & 15)) << 4));
       }
     }
-    // mask keys past the end of the sequence (last tile only)
+    // ---- B ----
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 8; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- C ----
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int vrow = d * 32 + ql;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        vf[d][g] = *reinterpret_cast<const bf16x8_t*>(vs + vrow * 128 + (((g * 2 + hi) ^ ((vrow >> 1) & 7)) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- D ---- mask keys past the end of the sequence (last tile only)
     if (t == ntiles - 1 && S_pad != S) {
       const int kv0 = t * KVB;
 #pragma unroll
@@ -160,53 +202,50 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
           if (key >= S) sacc[kb][r] = -INFINITY;
         }
     }
-    // ---- online softmax (per lane = per query) ------------------------------------------------
     float mt = sacc[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
     mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    // Deferred rescale: the running max is only advanced (and O, l rescaled: 64 VALU per lane) when some
+    // row of this wave grew by more than 2^RESCALE_LOG2; otherwise P is exponentiated against the stale max
+    // (values <= 2^RESCALE_LOG2, harmless in bf16/fp32) and O needs no touch.  Exact algebra either way.
     const float m_new = fmaxf(m_run, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float psum = 0.f;
-    bf16x8_t pf[2][2];
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int ksub = 0; ksub < 2; ++ksub) {
-        float pv[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          pv[j] = __builtin_amdgcn_exp2f(sacc[kb][ksub * 8 + j] * c - mc);
-          psum += pv[j];
-        }
-        const u32x4_t w = pack8(pv);
-        pf[kb][ksub] = __builtin_bit_cast(bf16x8_t, w);
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
-
-    // ---- O^T += V^T P^T ----------------------------------------------------------------------
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int vrow = d * 32 + ql;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int ksub = 0; ksub < 2; ++ksub) {
-          const int chunk = (kb * 4 + ksub * 2 + hi) ^ ((vrow >> 1) & 7);
-          const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(vs + vrow * 128 + (chunk << 4));
-          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, pf[kb][ksub], oacc[d], 0, 0, 0);
-        }
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
-
-    __syncthreads();   // next tile landed (vmcnt(0)) and every wave is done reading this one
+    const float mc = m_run * c;
+    float psum = 0.f;
+    bf16x8_t pf[4];          // [16-key group g = kb*2 + ksub]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pv[j] = __builtin_amdgcn_exp2f(sacc[g >> 1][(g & 1) * 8 + j] * c - mc);
+        psum += pv[j];
+      }
+      const u32x4_t w = pack8(pv);
+      pf[g] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    l_run += psum;
+    // ---- E ----
+    __syncthreads();
+    // ---- F ----
+    if (t + 2 < ntiles) stage_tile(t + 2, t & 1);
+    // ---- G ----
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][g], pf[g], oacc[d], 0, 0, 0);
   }
 
   // ---- normalise and store: lane (q, hi) holds O[q][32*d + 8*g + 4*hi + 0..3] -------------------
@@ -230,8 +269,10 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
                             hipStream_t stream) {
   const int S_pad = (int)attn_spad(S);
-  dim3 grid((S + QB - 1) / QB, H, B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad);
+  const int nq = (S + QB - 1) / QB;
+  const int heads_per_xcd = (H + 7) / 8;
+  dim3 grid(8 * heads_per_xcd * nq * B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B);
   return hipGetLastError();
 }
 

@@ -16,17 +16,18 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 AFX_DEV float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
-// round-to-nearest-even, NaN preserved (matches torch .to(bfloat16))
-AFX_DEV bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 on the gfx950 conversion unit (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN quieted --
+// the same result as torch .to(bfloat16)).  A hand-rolled integer rounding costs ~10 VALU + a divergent
+// NaN branch per element; in the attention loop that was the largest single VALU item.
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
 AFX_DEV uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+
+AFX_DEV bf16_t f32_to_bf16(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 AFX_DEV void unpack8(const u32x4_t& w, float (&f)[8]) {
 #pragma unroll

@@ -49,6 +49,20 @@ def attn():
         print(f'B={B} S={S} H={H}  {dt*1e6:9.1f} us  {fl/dt/1e12:7.1f} TF   (torch SDPA {fl/ref/1e12:7.1f} TF)')
 
 
+def attn1():
+    q, k, v = (torch.randn(1, 4608, 24, 128, device='cuda').bfloat16() for _ in range(3))
+    dt = timeit(lambda: ops.attention(q, k, v), iters=10)
+    print(f'attn S=4608: {dt*1e6:.1f} us {4.0*24*4608*4608*128/dt/1e12:.1f} TF')
+
+
+def gemm1():
+    M, N, K = 4608, 21504, 3072
+    a = torch.randn(M, K, device='cuda').bfloat16(); w = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()
+    out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    dt = timeit(lambda: ops.linear(a, w, None, out=out))
+    print(f'gemm {M}x{N}x{K}: {dt*1e6:.1f} us {2*M*N*K/dt/1e12:.1f} TF')
+
+
 def elem():
     print('--- HBM-bound kernels')
     R, D = 4608, 3072
