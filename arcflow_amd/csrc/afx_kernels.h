@@ -25,6 +25,7 @@ struct GemmProblem {
 struct GemmBatch {
   int32_t nprob;
   int32_t total_tiles;
+  int32_t group_m;     // tile-order super-row height (set by the launcher)
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
 
