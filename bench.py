@@ -105,6 +105,16 @@ def cpu_baseline(budget_s: float = 12.0):
     }
 
 
+def _traffic(model):
+    """HBM-side bytes per GEMM launch from the last committed PMC pass (profiles/traffic.json); bench.py cannot
+    run rocprofv3 on itself, so the corrected counter value is recorded there per round, or null."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            return json.load(f)[model]['bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -192,7 +202,7 @@ def main():
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
                 'bound': 'mfma', 'kernel': 'afx::gemm_bf16_kernel', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
-                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': None,
+                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': _traffic(args.model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,
                 'share_of_step_time': gemm_ms * 1e-3 / dt,
