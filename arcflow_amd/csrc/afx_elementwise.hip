@@ -286,18 +286,19 @@ __global__ __launch_bounds__(256) void arcflow_step_kernel(
     const float* __restrict__ x_in, const MixT* __restrict__ means, const MixT* __restrict__ logw,
     const MixT* __restrict__ logg, float s_src, float s_start, float s_end,
     const float* __restrict__ sigma_vec, float eps, float* __restrict__ x_out, int64_t tokens, int n_tok, int K,
-    int ch, int pp, int velocity_only) {
+    int ch, int pp, int velocity_only, const uint8_t* __restrict__ drop) {
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= tokens) return;
+  const int64_t bidx = tok / n_tok;
   if (sigma_vec != nullptr) {
-    const int64_t b = tok / n_tok;
-    s_src = sigma_vec[3 * b];
-    s_start = sigma_vec[3 * b + 1];
-    s_end = sigma_vec[3 * b + 2];
+    s_src = sigma_vec[3 * bidx];
+    s_start = sigma_vec[3 * bidx + 1];
+    s_end = sigma_vec[3 * bidx + 2];
   }
   const float d_past = s_src - s_start;
   const float d_step = s_start - s_end;
+  const uint8_t* dr = drop ? drop + bidx * K : nullptr;      // GM dropout: component k of sample b removed
   const MixT* mt = means + tok * (int64_t)K * ch;
   const MixT* wt = logw + tok * (int64_t)K * pp;
   const MixT* gt = logg + tok * (int64_t)(K - 1) * pp;
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void arcflow_step_kernel(
 #pragma unroll
     for (int k = 0; k < ARC_MAXK; ++k)
       if (k < K) {
-        lw[k] = mix_load<MixT>(wt, k * pp + q);
+        lw[k] = (dr && dr[k]) ? -INFINITY : mix_load<MixT>(wt, k * pp + q);
         mx = fmaxf(mx, lw[k]);
       }
     float den = 0.f;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void arcflow_step_kernel(
 hipError_t launch_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg,
                                int mix_bf16, float s_src, float s_start, float s_end,
                                const float* sigma_vec, float eps, float* x_out, int B, int n_tok, int K,
-                               int ch, int pp, int velocity_only, hipStream_t stream) {
+                               int ch, int pp, int velocity_only, const uint8_t* drop, hipStream_t stream) {
   if (K < 1 || K > ARC_MAXK || pp < 1 || ch < 1) return hipErrorInvalidValue;
   const int64_t tokens = (int64_t)B * n_tok;
   if (tokens == 0) return hipSuccess;
@@ -354,11 +355,11 @@ hipError_t launch_arcflow_step(const float* x_in, const void* means, const void*
   if (mix_bf16)
     hipLaunchKernelGGL(arcflow_step_kernel<bf16_t>, grid, block, 0, stream, x_in, (const bf16_t*)means,
                        (const bf16_t*)logw, (const bf16_t*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out,
-                       tokens, n_tok, K, ch, pp, velocity_only);
+                       tokens, n_tok, K, ch, pp, velocity_only, drop);
   else
     hipLaunchKernelGGL(arcflow_step_kernel<float>, grid, block, 0, stream, x_in, (const float*)means,
                        (const float*)logw, (const float*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out,
-                       tokens, n_tok, K, ch, pp, velocity_only);
+                       tokens, n_tok, K, ch, pp, velocity_only, drop);
   return hipGetLastError();
 }
 

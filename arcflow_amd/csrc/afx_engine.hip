@@ -23,23 +23,19 @@
 
 using namespace afx;
 
-namespace {
+#include "afx_api_util.h"
 
-thread_local char g_err[512] = "";
+thread_local char afx_g_err[512] = "";
 
-int fail(int code, const char* fmt, ...) {
+int afx_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  vsnprintf(afx_g_err, sizeof(afx_g_err), fmt, ap);
   va_end(ap);
   return code;
 }
 
-#define HIP_TRY(expr)                                                                           \
-  do {                                                                                          \
-    hipError_t e_ = (expr);                                                                     \
-    if (e_ != hipSuccess) return fail(AFX_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
+namespace {
 
 struct Weight {
   const void* ptr = nullptr;
@@ -166,7 +162,7 @@ double gemm_flops(const GemmBatch& gb) {
 
 extern "C" {
 
-const char* afx_last_error(void) { return g_err; }
+const char* afx_last_error(void) { return afx_g_err; }
 const char* afx_version(void) { return "arcflow_hip 0.1 (gfx950)"; }
 
 int afx_create(const afx_model_desc* desc, afx_ctx** out) {
@@ -464,7 +460,60 @@ int afx_arcflow_step(const float* x_in, const void* means, const void* logw, con
   if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || pp < 1 || ch % pp != 0)
     return fail(AFX_E_INVALID, "bad shape for afx_arcflow_step");
   HIP_TRY(launch_arcflow_step(x_in, means, logw, logg, mix_dtype == AFX_DT_BF16, sigma_src, sigma_start, sigma_end,
-                              sigma_vec, eps, x_out, batch, n_tok, K, ch, pp, 0, (hipStream_t)stream));
+                              sigma_vec, eps, x_out, batch, n_tok, K, ch, pp, 0, nullptr, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_arcflow_step_dropout(const float* x_in, const void* means, const void* logw, const void* logg, int32_t mix_dtype,
+                             const float* sigma_vec, const uint8_t* drop_mask, float eps, float* x_out, int32_t batch,
+                             int32_t n_tok, int32_t K, int32_t ch, int32_t pp, void* stream) {
+  if (!x_in || !means || !logw || !logg || !x_out || !sigma_vec)
+    return fail(AFX_E_INVALID, "null argument to afx_arcflow_step_dropout");
+  if (mix_dtype != AFX_DT_BF16 && mix_dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad mix_dtype");
+  if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || pp < 1 || ch % pp != 0)
+    return fail(AFX_E_INVALID, "bad shape for afx_arcflow_step_dropout");
+  HIP_TRY(launch_arcflow_step(x_in, means, logw, logg, mix_dtype == AFX_DT_BF16, 0.f, 0.f, 0.f, sigma_vec, eps, x_out,
+                              batch, n_tok, K, ch, pp, 0, drop_mask, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int32_t M,
+                           int32_t N, int32_t K, int32_t accumulate, void* stream) {
+  if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16_f32out");
+  if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 4)
+    return fail(AFX_E_INVALID, "afx_linear_bf16_f32out: need K%%64==0, N%%8==0, lda/ldw%%8==0, ldc%%4==0");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.C = (uint16_t*)C; p.ldc = ldc;
+  p.M = M; p.N = N; p.K = K; p.epi = EPI_NONE; p.rows_per_batch = 1; p.out_f32 = accumulate ? 2 : 1;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt, void* stream) {
+  if (!c || !what || !dst || !c->ws) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_export");
+  Workspace ws = carve(c, c->ws, batch, n_img, n_txt);
+  const int64_t D = c->D;
+  ModLayout ml{D, c->d.num_double, c->d.num_single};
+  hipStream_t st = (hipStream_t)stream;
+  const std::string w(what);
+  if (w == "head_in") {            // [B*N, D] bf16: norm_out output = input of the velocity head
+    HIP_TRY(hipMemcpyAsync(dst, ws.Xn, (size_t)batch * n_img * D * 2, hipMemcpyDeviceToDevice, st));
+  } else if (w == "x_final") {     // [B*N, D] bf16: image tokens entering norm_out
+    for (int b = 0; b < batch; ++b)
+      HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)b * n_img * D * 2, ws.X + ((int64_t)b * (n_img + n_txt) + n_txt) * D,
+                             (size_t)n_img * D * 2, hipMemcpyDeviceToDevice, st));
+  } else if (w == "silu_temb") {   // [B, D] f32
+    HIP_TRY(hipMemcpyAsync(dst, ws.semb, (size_t)batch * D * 4, hipMemcpyDeviceToDevice, st));
+  } else if (w == "mod_final") {   // [B, 2D] f32: (scale | shift) of norm_out
+    for (int b = 0; b < batch; ++b)
+      HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)b * 2 * D * 4, ws.mod + (int64_t)b * c->n_mod + ml.fin(0), (size_t)2 * D * 4,
+                             hipMemcpyDeviceToDevice, st));
+  } else {
+    return fail(AFX_E_INVALID, "afx_mmdit_export: unknown buffer '%s'", what);
+  }
   return AFX_OK;
 }
 
@@ -476,7 +525,7 @@ int afx_arcflow_velocity(const void* means, const void* logw, const void* logg, 
   if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || pp < 1 || ch % pp != 0)
     return fail(AFX_E_INVALID, "bad shape for afx_arcflow_velocity");
   HIP_TRY(launch_arcflow_step(u_out, means, logw, logg, mix_dtype == AFX_DT_BF16, sigma_src, sigma_t, sigma_t,
-                              sigma_vec, 1e-4f, u_out, batch, n_tok, K, ch, pp, 1, (hipStream_t)stream));
+                              sigma_vec, 1e-4f, u_out, batch, n_tok, K, ch, pp, 1, nullptr, (hipStream_t)stream));
   return AFX_OK;
 }
 

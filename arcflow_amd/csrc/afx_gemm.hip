@@ -52,6 +52,54 @@ AFX_DEV bf16x8_t lds_frag(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + phys * 16);
 }
 
+// Row-contiguous part of the epilogue, shared by every kernel variant: each lane owns 8 consecutive
+// columns of 8 rows of the wave's 64x64 fp32 patch; bias / GELU / gate*x+residual are applied here and C is
+// stored 16 B per lane (bf16) or 2 x 16 B (fp32 output, optionally accumulated -- weight gradients).
+AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, int gcol, bool col_ok, int er, int ec,
+                            const float (&bias)[8]) {
+#pragma unroll
+  for (int ps = 0; ps < 8; ++ps) {
+    const int lr = ps * 8 + er;
+    const int grow = row0 + lr;
+    if (grow < P.M && col_ok) {
+      const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
+      const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
+      float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      if (P.epi == EPI_GELU) {
+        if (gcol >= P.gelu_col0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+        }
+      } else if (P.epi == EPI_GATE_RES) {
+        const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
+        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
+        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
+        const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
+        float rr[8];
+        unpack8(rw, rr);
+        const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
+      }
+      if (P.out_f32 == 0) {
+        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
+      } else {
+        float* cp = reinterpret_cast<float*>(P.C) + (int64_t)grow * P.ldc + gcol;
+        f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        if (P.out_f32 == 2) {
+          o0 += *reinterpret_cast<const f32x4_t*>(cp);
+          o1 += *reinterpret_cast<const f32x4_t*>(cp + 4);
+        }
+        *reinterpret_cast<f32x4_t*>(cp) = o0;
+        *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
+      }
+    }
+  }
+}
+
+
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -144,35 +192,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
         for (int r = 0; r < 4; ++r)
           patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int lr = ps * 8 + er;
-      const int grow = m0 + wm * 128 + h * 64 + lr;
-      if (grow < P.M && col_ok) {
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias[e];
-        if (P.epi == EPI_GELU) {
-          if (gcol >= P.gelu_col0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-          }
-        } else if (P.epi == EPI_GATE_RES) {
-          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
-          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
-          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
-          const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
-          float rr[8];
-          unpack8(rw, rr);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
-        }
-        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
-      }
-    }
+    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
   }
 }
 
@@ -360,35 +380,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
         for (int r = 0; r < 4; ++r)
           patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int lr = ps * 8 + er;
-      const int grow = m0 + wm * 128 + h * 64 + lr;
-      if (grow < P.M && col_ok) {
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias[e];
-        if (P.epi == EPI_GELU) {
-          if (gcol >= P.gelu_col0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-          }
-        } else if (P.epi == EPI_GATE_RES) {
-          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
-          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
-          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
-          const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
-          float rr[8];
-          unpack8(rw, rr);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
-        }
-        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
-      }
-    }
+    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
   }
 }
 
@@ -537,35 +529,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v4(const Gem
         for (int r = 0; r < 4; ++r)
           patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int lr = ps * 8 + er;
-      const int grow = m0 + wm * 128 + h * 64 + lr;
-      if (grow < P.M && col_ok) {
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias[e];
-        if (P.epi == EPI_GELU) {
-          if (gcol >= P.gelu_col0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-          }
-        } else if (P.epi == EPI_GATE_RES) {
-          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
-          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
-          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
-          const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
-          float rr[8];
-          unpack8(rw, rr);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
-        }
-        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
-      }
-    }
+    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
   }
 }
 
@@ -723,35 +687,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v3(const Gem
         for (int r = 0; r < 16; ++r)
           patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq) * EPI_LD + j * 32 + frow] = acc[h * 2 + i][j][r];
     __syncthreads();
-#pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {
-      const int lr = ps * 8 + er;
-      const int grow = m0 + wm * 128 + h * 64 + lr;
-      if (grow < P.M && col_ok) {
-        const f32x4_t v0 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec);
-        const f32x4_t v1 = *reinterpret_cast<const f32x4_t*>(patch + lr * EPI_LD + ec + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bias[e];
-        if (P.epi == EPI_GELU) {
-          if (gcol >= P.gelu_col0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
-          }
-        } else if (P.epi == EPI_GATE_RES) {
-          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
-          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
-          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
-          const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
-          float rr[8];
-          unpack8(rw, rr);
-          const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
-        }
-        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
-      }
-    }
+    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
   }
 }
 

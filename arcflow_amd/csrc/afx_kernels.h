@@ -19,6 +19,7 @@ struct GemmProblem {
   int64_t lda, ldw, ldc, ldg, ldr;
   int32_t M, N, K;
   int32_t epi, gelu_col0, rows_per_batch;
+  int32_t out_f32;      // 0: C is bf16; 1: C is float (ldc in floats); 2: C (float) += result
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 
@@ -61,6 +62,11 @@ hipError_t launch_copy_rows(const uint16_t* src, int64_t lds_, uint16_t* dst, in
 hipError_t launch_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg,
                                int mix_bf16, float s_src, float s_start, float s_end,
                                const float* sigma_vec, float eps, float* x_out, int B, int n_tok, int K,
-                               int ch, int pp, int velocity_only, hipStream_t stream);
+                               int ch, int pp, int velocity_only, const uint8_t* drop, hipStream_t stream);
+hipError_t launch_arcflow_bwd(const float* g, const void* means, const void* logw, const void* logg, int mix_bf16,
+                              float s_src, float s_start, float s_end, const float* sigma_vec,
+                              const float* gscale_vec, float gscale, float eps, float* d_means, float* d_logw,
+                              float* d_logg, int B, int n_tok, int K, int ch, int pp, int velocity_only,
+                              int accumulate, hipStream_t stream);
 
 }  // namespace afx

@@ -1,0 +1,502 @@
+// Kernels of the distillation step that the reference runs as eager torch autograd:
+//   * backward of the analytic ArcFlow transport / policy velocity w.r.t. the mixture parameters
+//     (lakonlab/models/diffusions/arcflow.py:81-110 under autograd; policies/arcflow.py:52-76)
+//   * flow MSE loss + gradient (lakonlab/models/losses/diffusion_loss.py:44-83)
+//   * head / norm_out gradient helpers (log-softmax backward, column reductions, transposes)
+//   * fused AdamW, global grad-norm, clip, Karras-EMA lerp (lakonlab/models/base.py:76-103,
+//     lakonlab/runner/hooks/ema_hook.py:86-124)
+// All HBM-bound streaming kernels: 16 B per lane where the layout allows, wave64 shuffle reductions.
+#include <algorithm>
+
+#include "afx_api_util.h"
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// ------------------------------------------------------------------------------------------------
+// d/d(means, logw, logg) of   D[c] = sum_k softmax(logw)_k * m[k,c] * e_k
+//   step mode:      e_0 = Dt,  e_k = exp(g_k Dp) * Dt * phi(g_k Dt)       (D = displacement, x_end = x - D)
+//   velocity mode:  e_0 = 1,   e_k = exp(g_k Dp)                           (D = u)
+// given the upstream gradient gD = gscale[b] * g[c].  One wave per token, lane = packed channel (ch <= 64,
+// pp a power of two dividing 64): the reductions over the channels that share a sub-pixel q = c % pp are
+// xor-shuffles over lane bits >= log2(pp).
+constexpr int TR_MAXK = 32;
+
+template <typename MixT> AFX_DEV float tr_load(const MixT* p, int64_t i);
+template <> AFX_DEV float tr_load<float>(const float* p, int64_t i) { return p[i]; }
+template <> AFX_DEV float tr_load<bf16_t>(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+
+template <typename MixT>
+__global__ __launch_bounds__(256) void arcflow_bwd_kernel(
+    const float* __restrict__ g, const MixT* __restrict__ means, const MixT* __restrict__ logw,
+    const MixT* __restrict__ logg, float s_src, float s_start, float s_end, const float* __restrict__ sigma_vec,
+    const float* __restrict__ gscale_vec, float gscale, float eps, float* __restrict__ d_means,
+    float* __restrict__ d_logw, float* __restrict__ d_logg, int64_t tokens, int n_tok, int K, int ch, int pp,
+    int velocity_only, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  const int64_t b = tok / n_tok;
+  if (sigma_vec != nullptr) {
+    s_src = sigma_vec[3 * b];
+    s_start = sigma_vec[3 * b + 1];
+    s_end = sigma_vec[3 * b + 2];
+  }
+  if (gscale_vec != nullptr) gscale *= gscale_vec[b];
+  const float d_past = s_src - s_start;
+  const float d_step = s_start - s_end;
+  const bool active = lane < ch;
+  const int c = active ? lane : 0;
+  const int q = c % pp;
+  const MixT* mt = means + tok * (int64_t)K * ch;
+  const MixT* wt = logw + tok * (int64_t)K * pp;
+  const MixT* gt = logg + tok * (int64_t)(K - 1) * pp;
+  const float gD = active ? gscale * g[tok * ch + c] : 0.f;
+
+  float w[TR_MAXK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < TR_MAXK; ++k)
+    if (k < K) {
+      w[k] = tr_load<MixT>(wt, k * pp + q);
+      mx = fmaxf(mx, w[k]);
+    }
+  float den = 0.f;
+#pragma unroll
+  for (int k = 0; k < TR_MAXK; ++k)
+    if (k < K) {
+      w[k] = expf(w[k] - mx);
+      den += w[k];
+    }
+  const float inv = 1.0f / den;
+
+  float* dm = d_means + tok * (int64_t)K * ch;
+  float* dw = d_logw + tok * (int64_t)K * pp;
+  float* dg = d_logg + tok * (int64_t)(K - 1) * pp;
+  float a[TR_MAXK];       // a_k = e_k * sum_{c in q} gD_c m_{k,c}
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < TR_MAXK; ++k)
+    if (k < K) {
+      w[k] *= inv;
+      const float m = tr_load<MixT>(mt, (int64_t)k * ch + c);
+      float e, de;
+      if (k == 0) {
+        e = velocity_only ? 1.0f : d_step;
+        de = 0.f;
+      } else {
+        const float gam = tr_load<MixT>(gt, (k - 1) * pp + q);
+        const float dec = expf(gam * d_past);
+        if (velocity_only) {
+          e = dec;
+          de = d_past * dec;
+        } else {
+          const float z = gam * d_step;
+          const bool clamped = fabsf(z) < eps;
+          const float zs = (z < 0.f ? -1.0f : 1.0f) * fmaxf(fabsf(z), eps);
+          const float em1 = expm1f(zs);
+          const float phi = em1 / zs;
+          const float dphi = clamped ? 0.f : (em1 + 1.0f - phi) / zs;   // phi'(z), 0 inside the clamp
+          e = dec * d_step * phi;
+          de = d_past * e + dec * d_step * dphi * d_step;
+        }
+      }
+      // gradient w.r.t. the mean of this lane's channel
+      if (active) {
+        const float v = gD * w[k] * e;
+        dm[(int64_t)k * ch + c] = accumulate ? dm[(int64_t)k * ch + c] + v : v;
+      }
+      // r_k = sum over the channels of sub-pixel q of gD_c m_{k,c}
+      float r = gD * m;
+      for (int o = pp; o < 64; o <<= 1) r += __shfl_xor(r, o, 64);
+      a[k] = e * r;
+      s += w[k] * a[k];
+      if (k > 0 && lane < pp) {
+        const float v = w[k] * de * r;
+        dg[(k - 1) * pp + q] = accumulate ? dg[(k - 1) * pp + q] + v : v;
+      }
+    }
+  if (lane < pp) {
+#pragma unroll
+    for (int k = 0; k < TR_MAXK; ++k)
+      if (k < K) {
+        const float v = w[k] * (a[k] - s);
+        dw[k * pp + q] = accumulate ? dw[k * pp + q] + v : v;
+      }
+  }
+}
+
+hipError_t launch_arcflow_bwd(const float* g, const void* means, const void* logw, const void* logg, int mix_bf16,
+                              float s_src, float s_start, float s_end, const float* sigma_vec,
+                              const float* gscale_vec, float gscale, float eps, float* d_means, float* d_logw,
+                              float* d_logg, int B, int n_tok, int K, int ch, int pp, int velocity_only,
+                              int accumulate, hipStream_t stream) {
+  if (K < 1 || K > TR_MAXK || ch < 1 || ch > 64 || pp < 1 || (pp & (pp - 1)) || 64 % pp || ch % pp)
+    return hipErrorInvalidValue;
+  const int64_t tokens = (int64_t)B * n_tok;
+  if (tokens == 0) return hipSuccess;
+  dim3 grid((unsigned)((tokens + 3) / 4)), block(256);
+  if (mix_bf16)
+    hipLaunchKernelGGL(arcflow_bwd_kernel<bf16_t>, grid, block, 0, stream, g, (const bf16_t*)means, (const bf16_t*)logw,
+                       (const bf16_t*)logg, s_src, s_start, s_end, sigma_vec, gscale_vec, gscale, eps, d_means, d_logw,
+                       d_logg, tokens, n_tok, K, ch, pp, velocity_only, accumulate);
+  else
+    hipLaunchKernelGGL(arcflow_bwd_kernel<float>, grid, block, 0, stream, g, (const float*)means, (const float*)logw,
+                       (const float*)logg, s_src, s_start, s_end, sigma_vec, gscale_vec, gscale, eps, d_means, d_logw,
+                       d_logg, tokens, n_tok, K, ch, pp, velocity_only, accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------
+// loss += coef * 0.5 * sum (p - t)^2 ;  grad = coef * (p - t)       (coef folds scale / numel / segment size)
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                  float coef, float* __restrict__ grad, float* __restrict__ loss,
+                                                  int64_t n) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float d = p[i] - t[i];
+    acc += d * d;
+    if (grad) grad[i] = coef * d;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, 0.5f * coef * (part[0] + part[1] + part[2] + part[3]));
+}
+
+// sum of squares of a flat fp32 buffer -> atomicAdd into out[0]  (global grad norm)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n) {
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += x[i] * x[i];
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+
+// AdamW (decoupled weight decay), bias-corrected, fp32 state; gscale folds 1/world and the clip factor.
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, float lr, float b1,
+                                                    float b2, float eps, float wd, float bc1, float bc2, float gscale,
+                                                    int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * gscale;
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  float pi = p[i] * (1.0f - lr * wd);
+  pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  p[i] = pi;
+}
+
+// ema = net + (ema - net) * beta        (mmgen lerp; lakonlab/runner/hooks/ema_hook.py:118-124)
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ net, float beta,
+                                                  int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) ema[i] = net[i] + (ema[i] - net[i]) * beta;
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    *reinterpret_cast<uint32_t*>(y + i) = pack_bf16x2(x[i], x[i + 1]);
+  } else if (i < n) {
+    y[i] = f32_to_bf16(x[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Head-logit gradient row:  dY = [ d_means | log_softmax-backward(d_logw) | d_logg | 0-pad ]   (bf16)
+//   d raw[k,q] = d_lw[k,q] - exp(logw_out[k,q]) * sum_k d_lw[k,q]          (arcflux.py:246-247 backward)
+__global__ __launch_bounds__(256) void head_grad_kernel(const float* __restrict__ d_means, const float* __restrict__ d_logw,
+                                                        const float* __restrict__ d_logg, const bf16_t* __restrict__ logw_out,
+                                                        bf16_t* __restrict__ dy, int64_t ldy, int K, int ch, int lw) {
+  const int64_t row = blockIdx.x;
+  const int nm = K * ch, nw = K * lw, ng = (K - 1) * lw;
+  bf16_t* out = dy + row * ldy;
+  for (int i = threadIdx.x; i < nm; i += 256) out[i] = f32_to_bf16(d_means[row * nm + i]);
+  for (int i = threadIdx.x; i < ng; i += 256) out[nm + nw + i] = f32_to_bf16(d_logg[row * ng + i]);
+  for (int i = nm + nw + ng + threadIdx.x; i < ldy; i += 256) out[i] = 0;
+  if (threadIdx.x < lw) {
+    const int q = threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += d_logw[row * nw + k * lw + q];
+    for (int k = 0; k < K; ++k) {
+      const float p = expf(bf16_to_f32(logw_out[row * nw + k * lw + q]));
+      out[nm + k * lw + q] = f32_to_bf16(d_logw[row * nw + k * lw + q] - p * s);
+    }
+  }
+}
+
+// [R, C] bf16 -> [C, R] bf16 (64x64 LDS tiles; R, C multiples of 8)
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y,
+                                                        int64_t ldy, int R, int C) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < R && c0 + c < C) ? x[(int64_t)(r0 + r) * ldx + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < C && r0 + r < R) y[(int64_t)(c0 + c) * ldy + r0 + r] = tile[r][c];
+  }
+}
+
+// column sums of a bf16 [R, C] matrix into fp32 out[C] (accumulating): bias gradients
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ out, int R,
+                                                     int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += bf16_to_f32(x[(int64_t)r * ldx + c]);
+  atomicAdd(out + c, acc);
+}
+
+// AdaLayerNormContinuous backward w.r.t. its modulation:  xn = LN(x) (1 + scale) + shift
+//   d_scale[b, c] += sum_rows dxn * LN(x),   d_shift[b, c] += sum_rows dxn     (rows of batch b)
+// One wave per row computes the row statistics, then every lane adds its 8-column chunks atomically into the
+// [B, 2, D] fp32 result (scale first, like the reference's chunk order).
+__global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                          const bf16_t* __restrict__ dxn, int64_t ldd, float* __restrict__ dmod,
+                                                          int rows, int D, int rows_per_batch, int rows_per_wave) {
+  const int lane = threadIdx.x & 63;
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row0 = wv * rows_per_wave;
+  if (row0 >= rows) return;
+  const int nchunk = D >> 3;
+  const int b = row0 / rows_per_batch;            // rows_per_wave divides rows_per_batch
+  float ds[8][8], dh[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ds[i][e] = dh[i][e] = 0.f;
+  for (int row = row0; row < min(rows, row0 + rows_per_wave); ++row) {
+    float v[8][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(x + (int64_t)row * ldx + c * 8), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float qv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mean;
+          qv += d * d;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(qv) / (float)D + 1e-6f);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        float gr[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dxn + (int64_t)row * ldd + c * 8), gr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          ds[i][e] += gr[e] * (v[i][e] - mean) * rstd;
+          dh[i][e] += gr[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(dmod + ((int64_t)b * 2 + 0) * D + c * 8 + e, ds[i][e]);
+        atomicAdd(dmod + ((int64_t)b * 2 + 1) * D + c * 8 + e, dh[i][e]);
+      }
+    }
+  }
+}
+
+// dW[j, k] += sum_b dmod[b, j] * x[b, k]   (rank-B update of the norm_out.linear weight, B <= 8)
+__global__ __launch_bounds__(256) void outer_accum_kernel(const float* __restrict__ dmod, const float* __restrict__ x,
+                                                          float* __restrict__ dW, int B, int J, int Kd) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)J * Kd) return;
+  const int j = (int)(i / Kd), k = (int)(i % Kd);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) acc += dmod[(int64_t)b * J + j] * x[(int64_t)b * Kd + k];
+  dW[i] += acc;
+}
+
+// x_out = x_a + u * (sb[b] - sa[b])     teacher Euler roll of the scheduled trajectory mixing (arcflow.py:189-192)
+__global__ __launch_bounds__(256) void euler_kernel(const float* __restrict__ xa, const float* __restrict__ u,
+                                                    const float* __restrict__ sa, const float* __restrict__ sb,
+                                                    float* __restrict__ out, int64_t per_sample, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = i / per_sample;
+  out[i] = xa[i] + u[i] * (sb[b] - sa[b]);
+}
+
+// classifier-free guidance of the teacher:  u = pos + (pos - neg) * (scale - 1)    (gaussian_flow.py:18-26, non-orthogonal)
+__global__ __launch_bounds__(256) void cfg_kernel(const float* __restrict__ pos, const float* __restrict__ neg, float scale,
+                                                  float* __restrict__ out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = pos[i] + (pos[i] - neg[i]) * (scale - 1.0f);
+}
+
+}  // namespace afx
+
+using namespace afx;
+
+static inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+int afx_arcflow_backward(const float* g, const void* means, const void* logw, const void* logg, int32_t mix_dtype,
+                         float sigma_src, float sigma_start, float sigma_end, const float* sigma_vec,
+                         const float* gscale_vec, float gscale, float eps, float* d_means, float* d_logw,
+                         float* d_logg, int32_t batch, int32_t n_tok, int32_t K, int32_t ch, int32_t pp,
+                         int32_t velocity_only, int32_t accumulate, void* stream) {
+  if (!g || !means || !logw || !logg || !d_means || !d_logw || !d_logg)
+    return fail(AFX_E_INVALID, "null argument to afx_arcflow_backward");
+  if (mix_dtype != AFX_DT_BF16 && mix_dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad mix_dtype");
+  if (batch < 0 || n_tok < 0 || K < 1 || K > 32 || ch < 1 || ch > 64 || pp < 1 || (pp & (pp - 1)) || 64 % pp || ch % pp)
+    return fail(AFX_E_INVALID, "afx_arcflow_backward: need K<=32, ch<=64, pp a power of two dividing ch");
+  HIP_TRY(launch_arcflow_bwd(g, means, logw, logg, mix_dtype == AFX_DT_BF16, sigma_src, sigma_start, sigma_end, sigma_vec,
+                             gscale_vec, gscale, eps, d_means, d_logw, d_logg, batch, n_tok, K, ch, pp, velocity_only,
+                             accumulate, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_mse_loss(const float* pred, const float* target, float coef, float* grad, float* loss_accum, int64_t n,
+                 void* stream) {
+  if (!pred || !target || !loss_accum || n < 0) return fail(AFX_E_INVALID, "bad argument to afx_mse_loss");
+  if (n == 0) return AFX_OK;
+  const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(mse_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, pred, target, coef, grad, loss_accum, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_sumsq(const float* x, float* out_accum, int64_t n, void* stream) {
+  if (!x || !out_accum || n < 0) return fail(AFX_E_INVALID, "bad argument to afx_sumsq");
+  if (n == 0) return AFX_OK;
+  const unsigned nb = (unsigned)std::min<int64_t>((n + 255) / 256, 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, out_accum, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, float grad_scale, int64_t n, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return fail(AFX_E_INVALID, "bad argument to afx_adamw_step");
+  if (n == 0) return AFX_OK;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
+                     lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_ema_lerp(float* ema, const float* net, float beta, int64_t n, void* stream) {
+  if (!ema || !net || n < 0) return fail(AFX_E_INVALID, "bad argument to afx_ema_lerp");
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(ema_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, ema, net, beta, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream) {
+  if (!x || !y || n < 0) return fail(AFX_E_INVALID, "bad argument to afx_cast_f32_bf16");
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(cast_kernel, dim3(blocks_for((n + 1) / 2)), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_head_grad(const float* d_means, const float* d_logw, const float* d_logg, const void* logw_out, void* dy,
+                  int64_t ldy, int64_t rows, int32_t K, int32_t ch, int32_t lw, void* stream) {
+  if (!d_means || !d_logw || !d_logg || !logw_out || !dy || rows < 0 || lw < 1 || lw > 256 ||
+      ldy < (int64_t)K * ch + K * lw + (K - 1) * lw)
+    return fail(AFX_E_INVALID, "bad argument to afx_head_grad");
+  if (rows == 0) return AFX_OK;
+  hipLaunchKernelGGL(head_grad_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, d_means, d_logw, d_logg,
+                     (const bf16_t*)logw_out, (bf16_t*)dy, ldy, K, ch, lw);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_transpose_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, void* stream) {
+  if (!x || !y || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_transpose_bf16");
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, int32_t cols, void* stream) {
+  if (!x || !out_accum || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_colsum_bf16");
+  const int rpb = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, out_accum, rows, cols, rpb);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
+                         int32_t D, int32_t rows_per_batch, void* stream) {
+  if (!x || !dxn || !dmod_accum || rows < 1 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1 || rows % rows_per_batch)
+    return fail(AFX_E_INVALID, "bad argument to afx_normout_backward");
+  int rpw = 16;
+  while (rows_per_batch % rpw) rpw >>= 1;
+  const int waves = rows / rpw;
+  hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dxn, ldd, dmod_accum, rows, D, rows_per_batch, rpw);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t B, int32_t J, int32_t Kd, void* stream) {
+  if (!dmod || !x || !dW_accum || B < 1 || J < 1 || Kd < 1) return fail(AFX_E_INVALID, "bad argument to afx_outer_accum");
+  hipLaunchKernelGGL(outer_accum_kernel, dim3(blocks_for((int64_t)J * Kd)), dim3(256), 0, (hipStream_t)stream, dmod, x,
+                     dW_accum, B, J, Kd);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_euler_roll(const float* x_a, const float* u, const float* sigma_a, const float* sigma_b, float* out,
+                   int32_t batch, int64_t per_sample, void* stream) {
+  if (!x_a || !u || !sigma_a || !sigma_b || !out || batch < 0 || per_sample < 1) return fail(AFX_E_INVALID, "bad argument to afx_euler_roll");
+  const int64_t n = (int64_t)batch * per_sample;
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(euler_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x_a, u, sigma_a, sigma_b, out,
+                     per_sample, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_cfg_combine(const float* pos, const float* neg, float scale, float* out, int64_t n, void* stream) {
+  if (!pos || !neg || !out || n < 0) return fail(AFX_E_INVALID, "bad argument to afx_cfg_combine");
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(cfg_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, pos, neg, scale, out, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+}  // extern "C"

@@ -145,3 +145,147 @@ def arcflow_velocity(means: torch.Tensor, logw: torch.Tensor, logg: torch.Tensor
         s0, s1 = float(sigma_src), float(sigma_t)
     _lib.check(lib.afx_arcflow_velocity(_p(means), _p(logw), _p(logg), dt, s0, s1, _p(sv), _p(out), B, N, K, ch, pp, _s()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# distillation-step kernels
+def _sigma_vec(B, device, *sig):
+    cols = [torch.as_tensor(x, dtype=torch.float32, device=device).flatten().expand(B) for x in sig]
+    return torch.stack(cols, dim=1).contiguous()
+
+
+def arcflow_step_dropout(x, means, logw, logg, sigma_src, sigma_start, sigma_end, drop_mask=None, eps: float = 1e-4):
+    """Roll-out step of the detached policy with per-sample sigmas and GM dropout mask [B,K] (bool/uint8)."""
+    lib = _lib.load()
+    B, N, K, ch = means.shape
+    pp = logw.shape[-1]
+    x = _cuda(x, torch.float32)
+    dt, means, logw, logg = _mix_dtype(means, logw, logg)
+    sv = _sigma_vec(B, x.device, sigma_src, sigma_start, sigma_end)
+    dm = None if drop_mask is None else drop_mask.to(device=x.device, dtype=torch.uint8).reshape(B, K).contiguous()
+    out = torch.empty_like(x)
+    _lib.check(lib.afx_arcflow_step_dropout(_p(x), _p(means), _p(logw), _p(logg), dt, _p(sv), _p(dm), eps, _p(out),
+                                            B, N, K, ch, pp, _s()))
+    return out
+
+
+def arcflow_backward(g, means, logw, logg, sigma_src, sigma_start, sigma_end, gscale=None, velocity: bool = False,
+                     grads=None, eps: float = 1e-4):
+    """Gradients of the displacement (or velocity) w.r.t. the mixture.  g [B,N,ch] upstream gradient, gscale [B]
+    optional per-sample factor.  grads = (d_means, d_logw, d_logg) fp32 to accumulate into, else fresh tensors."""
+    lib = _lib.load()
+    B, N, K, ch = means.shape
+    pp = logw.shape[-1]
+    g = _cuda(g, torch.float32)
+    dt, means, logw, logg = _mix_dtype(means, logw, logg)
+    sv = _sigma_vec(B, g.device, sigma_src, sigma_start, sigma_end)
+    gs = None if gscale is None else _cuda(torch.as_tensor(gscale, device=g.device).flatten().expand(B), torch.float32)
+    acc = grads is not None
+    if not acc:
+        grads = (torch.empty(B, N, K, ch, dtype=torch.float32, device=g.device),
+                 torch.empty(B, N, K, pp, dtype=torch.float32, device=g.device),
+                 torch.empty(B, N, K - 1, pp, dtype=torch.float32, device=g.device))
+    _lib.check(lib.afx_arcflow_backward(_p(g), _p(means), _p(logw), _p(logg), dt, 0.0, 0.0, 0.0, _p(sv), _p(gs), 1.0, eps,
+                                        _p(grads[0]), _p(grads[1]), _p(grads[2]), B, N, K, ch, pp, int(velocity), int(acc), _s()))
+    return grads
+
+
+def mse_loss(pred, target, coef: float, loss_accum: torch.Tensor, want_grad: bool = True):
+    lib = _lib.load()
+    pred, target = _cuda(pred, torch.float32), _cuda(target, torch.float32)
+    grad = torch.empty_like(pred) if want_grad else None
+    _lib.check(lib.afx_mse_loss(_p(pred), _p(target), coef, _p(grad), _p(loss_accum), pred.numel(), _s()))
+    return grad
+
+
+def euler_roll(x_a, u, sigma_a, sigma_b):
+    lib = _lib.load()
+    x_a, u = _cuda(x_a, torch.float32), _cuda(u, torch.float32)
+    B = x_a.shape[0]
+    sa = _cuda(sigma_a.flatten().expand(B), torch.float32)
+    sb = _cuda(sigma_b.flatten().expand(B), torch.float32)
+    out = torch.empty_like(x_a)
+    _lib.check(lib.afx_euler_roll(_p(x_a), _p(u), _p(sa), _p(sb), _p(out), B, x_a[0].numel(), _s()))
+    return out
+
+
+def cfg_combine(pos, neg, scale: float):
+    lib = _lib.load()
+    pos, neg = _cuda(pos, torch.float32), _cuda(neg, torch.float32)
+    out = torch.empty_like(pos)
+    _lib.check(lib.afx_cfg_combine(_p(pos), _p(neg), scale, _p(out), pos.numel(), _s()))
+    return out
+
+
+def head_grad(d_means, d_logw, d_logg, logw_out, ldy: int):
+    lib = _lib.load()
+    B, N, K, ch = d_means.shape
+    lw = d_logw.shape[-1]
+    dy = torch.empty(B * N, ldy, dtype=torch.bfloat16, device=d_means.device)
+    _lib.check(lib.afx_head_grad(_p(d_means), _p(d_logw), _p(d_logg), _p(logw_out.contiguous()), _p(dy), ldy, B * N, K, ch, lw, _s()))
+    return dy
+
+
+def linear_f32out(a, w, out=None, accumulate: bool = False):
+    """out (fp32) [M,N] (+)= a [M,K] @ w[N,K].T, bf16 operands."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+    _lib.check(lib.afx_linear_bf16_f32out(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K,
+                                          int(accumulate), _s()))
+    return out
+
+
+def transpose(x):
+    lib = _lib.load()
+    R, Cc = x.shape
+    y = torch.empty(Cc, R, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.afx_transpose_bf16(_p(x), x.stride(0), _p(y), R, R, Cc, _s()))
+    return y
+
+
+def colsum(x, out_accum):
+    lib = _lib.load()
+    _lib.check(lib.afx_colsum_bf16(_p(x), x.stride(0), _p(out_accum), x.shape[0], x.shape[1], _s()))
+    return out_accum
+
+
+def normout_backward(x, dxn, dmod_accum, rows_per_batch: int):
+    lib = _lib.load()
+    _lib.check(lib.afx_normout_backward(_p(x), x.stride(0), _p(dxn), dxn.stride(0), _p(dmod_accum), x.shape[0], x.shape[1],
+                                        rows_per_batch, _s()))
+    return dmod_accum
+
+
+def outer_accum(dmod, x, dW_accum):
+    lib = _lib.load()
+    B, J = dmod.shape
+    _lib.check(lib.afx_outer_accum(_p(_cuda(dmod, torch.float32)), _p(_cuda(x, torch.float32)), _p(dW_accum), B, J, x.shape[1], _s()))
+    return dW_accum
+
+
+def sumsq(x, out_accum):
+    lib = _lib.load()
+    _lib.check(lib.afx_sumsq(_p(x), _p(out_accum), x.numel(), _s()))
+    return out_accum
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    lib = _lib.load()
+    _lib.check(lib.afx_adamw_step(_p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), lr, betas[0], betas[1], eps,
+                                  weight_decay, step, grad_scale, param.numel(), _s()))
+
+
+def ema_lerp(ema, net, beta: float):
+    lib = _lib.load()
+    _lib.check(lib.afx_ema_lerp(_p(ema), _p(net), beta, ema.numel(), _s()))
+
+
+def cast_bf16(x, out=None):
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.afx_cast_f32_bf16(_p(x), _p(out), x.numel(), _s()))
+    return out

@@ -133,6 +133,65 @@ int afx_arcflow_velocity(const void* means, const void* logw, const void* logg, 
                          float sigma_src, float sigma_t, const float* sigma_vec, float* u_out,
                          int32_t batch, int32_t n_tok, int32_t K, int32_t ch, int32_t pp, void* stream);
 
+/* ---- distillation-step kernels (training side) ------------------------------------------------
+ * The reference runs these as eager torch + autograd; shapes are the token layout of afx_arcflow_step. */
+
+/* Analytic step with per-sample sigmas sigma_vec[3*B] = {src,start,end} and GM dropout: component k of
+ * sample b is removed (log-weight -> -inf) when drop_mask[b*K+k] != 0 (policies/arcflow.py:96-106);
+ * roll-outs of the detached policy in piid_segment_momentum (arcflow.py:141-144,176-178,201-205). */
+int afx_arcflow_step_dropout(const float* x_in, const void* means, const void* logw, const void* logg,
+                             int32_t mix_dtype, const float* sigma_vec, const uint8_t* drop_mask, float eps,
+                             float* x_out, int32_t batch, int32_t n_tok, int32_t K, int32_t ch, int32_t pp,
+                             void* stream);
+
+/* Gradients of D = sum_k softmax(logw)_k m_k e_k w.r.t. (means, logw, logg) given gD = gscale * gscale_vec[b] * g:
+ * step form (velocity_only = 0): e_0 = Dt, e_k = exp(g_k Dp) Dt phi(g_k Dt)  -- x_end = x - D
+ * velocity form (1):             e_0 = 1,  e_k = exp(g_k Dp)                  -- u = D
+ * = autograd of policy_average_u_momentum (arcflow.py:81-110).  accumulate != 0 adds into the outputs.
+ * d_means [B,N,K,ch], d_logw [B,N,K,pp], d_logg [B,N,K-1,pp] fp32.  ch <= 64, pp power of two. */
+int afx_arcflow_backward(const float* g, const void* means, const void* logw, const void* logg, int32_t mix_dtype,
+                         float sigma_src, float sigma_start, float sigma_end, const float* sigma_vec,
+                         const float* gscale_vec, float gscale, float eps, float* d_means, float* d_logw,
+                         float* d_logg, int32_t batch, int32_t n_tok, int32_t K, int32_t ch, int32_t pp,
+                         int32_t velocity_only, int32_t accumulate, void* stream);
+
+/* *loss_accum += coef * 0.5 * sum (pred-target)^2 ; grad (optional) = coef * (pred-target)
+ * (DiffusionMSELoss, losses/diffusion_loss.py:44-83; coef folds the x30 rescale, the mean and the segment size) */
+int afx_mse_loss(const float* pred, const float* target, float coef, float* grad, float* loss_accum, int64_t n,
+                 void* stream);
+/* x_out = x_a + u * (sigma_b[b] - sigma_a[b])   teacher Euler roll (arcflow.py:189-192) */
+int afx_euler_roll(const float* x_a, const float* u, const float* sigma_a, const float* sigma_b, float* out,
+                   int32_t batch, int64_t per_sample, void* stream);
+/* out = pos + (pos - neg) * (scale - 1)   teacher CFG (gaussian_flow.py:18-26, orthogonal=False) */
+int afx_cfg_combine(const float* pos, const float* neg, float scale, float* out, int64_t n, void* stream);
+
+/* Head-logit gradient rows dY = [d_means | log_softmax^T(d_logw) | d_logg | 0] as bf16 (arcflux.py:243-249 backward) */
+int afx_head_grad(const float* d_means, const float* d_logw, const float* d_logg, const void* logw_out, void* dy,
+                  int64_t ldy, int64_t rows, int32_t K, int32_t ch, int32_t lw, void* stream);
+/* C(float)[M,N] (+)= A[M,K] . W[N,K]^T, bf16 operands, fp32 result: weight gradients dW = dY^T . X on transposed copies */
+int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int32_t M,
+                           int32_t N, int32_t K, int32_t accumulate, void* stream);
+int afx_transpose_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, void* stream);
+int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, int32_t cols, void* stream);
+/* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn) */
+int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
+                         int32_t D, int32_t rows_per_batch, void* stream);
+/* dW_accum[J,Kd] += sum_b dmod[b,J] x[b,Kd]   (norm_out.linear weight gradient, B <= 8) */
+int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t B, int32_t J, int32_t Kd, void* stream);
+/* Copy an activation of the LAST afx_mmdit_forward out of the workspace: "head_in" [B*N,D] bf16,
+ * "x_final" [B*N,D] bf16, "silu_temb" [B,D] f32, "mod_final" [B,2D] f32 (scale|shift of norm_out). */
+int afx_mmdit_export(afx_ctx* ctx, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt,
+                     void* stream);
+
+/* Optimiser step of lakonlab/models/base.py:76-103 + ema_hook.py:86-124 on flat fp32 buffers:
+ * global grad-norm (afx_sumsq accumulates sum of squares), AdamW with decoupled decay (grad_scale folds
+ * 1/world and the clip factor; step >= 1 for bias correction), Karras EMA  ema = net + (ema - net) * beta. */
+int afx_sumsq(const float* x, float* out_accum, int64_t n, void* stream);
+int afx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, float grad_scale, int64_t n, void* stream);
+int afx_ema_lerp(float* ema, const float* net, float beta, int64_t n, void* stream);
+int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
+
 /* ---- building-block kernels (exported for the per-kernel parity tests and micro benches) -- */
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias)   bf16 in/out, fp32 accumulate (nn.Linear semantics).

@@ -1,0 +1,166 @@
+"""GPU parity of the distillation-step kernels against torch autograd on the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from arcflow_amd import ops as _ops
+    return _ops
+
+
+def close(a, b, rtol=2e-5, atol=2e-5):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f'max abs err {err}, ref scale {b.abs().max().item()}'
+
+
+def _mix(seed=0, B=2, N=24, K=16, ch=64, pp=4):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, N, ch, generator=g)
+    m = torch.randn(B, N, K, ch, generator=g)
+    lw = torch.log_softmax(torch.randn(B, N, K, pp, generator=g) * 1.5, dim=2)
+    lg = torch.randn(B, N, K - 1, pp, generator=g)
+    lg[0, 0] = 0.0
+    lg[0, 1] = 3e-5
+    lg[1, 2] = -3e-5
+    up = torch.randn(B, N, ch, generator=g)
+    return x, m, lw, lg, up
+
+
+def test_arcflow_backward_step_and_velocity(ops):
+    from oracle import arcflow_ref as R
+    x, m, lw, lg, up = _mix()
+    B = x.shape[0]
+    s_src = torch.tensor([1.0, 0.8])
+    s_a = torch.tensor([0.9, 0.55])
+    s_b = torch.tensor([0.4, 0.1])
+    gs = torch.tensor([0.7, -1.3])
+    mr, lwr, lgr = (t.clone().requires_grad_(True) for t in (m, lw, lg))
+    tot = 0
+    for b in range(B):
+        xe = R.momentum_step_packed(x[b:b + 1], mr[b:b + 1], lwr[b:b + 1], lgr[b:b + 1], float(s_src[b]), float(s_a[b]), float(s_b[b]))
+        disp = x[b:b + 1] - xe
+        tot = tot + (disp * up[b:b + 1]).sum() * gs[b]
+    tot.backward()
+    dm, dw, dg = ops.arcflow_backward(up.cuda(), m.cuda(), lw.cuda(), lg.cuda(), s_src.cuda(), s_a.cuda(), s_b.cuda(), gscale=gs.cuda())
+    close(dm, mr.grad)
+    close(dw, lwr.grad, atol=2e-4)
+    close(dg, lgr.grad, atol=2e-4)
+    # velocity form + accumulation into the same buffers
+    mr2, lwr2, lgr2 = (t.clone().requires_grad_(True) for t in (m, lw, lg))
+    hp, wp = 4, 6
+    ml, lwl, lgl = R.unpack_mixture(mr2, lwr2, lgr2, hp, wp)
+    u = R.pack_latents(R.policy_velocity(ml, lwl, lgl, s_src, s_a))
+    (u * up).sum().backward()
+    ops.arcflow_backward(up.cuda(), m.cuda(), lw.cuda(), lg.cuda(), s_src.cuda(), s_a.cuda(), s_a.cuda(), velocity=True, grads=(dm, dw, dg))
+    close(dm, mr.grad + mr2.grad)
+    close(dw, lwr.grad + lwr2.grad, atol=2e-4)
+    close(dg, lgr.grad + lgr2.grad, atol=2e-4)
+
+
+def test_step_dropout_euler_cfg_mse(ops):
+    from oracle import arcflow_ref as R
+    x, m, lw, lg, up = _mix(1)
+    B, N, K = x.shape[0], x.shape[1], m.shape[2]
+    drop = torch.zeros(B, K, dtype=torch.bool)
+    drop[0, 3] = drop[0, 7] = drop[1, 0] = True
+    s_src, s_a, s_b = torch.tensor([1.0, 0.7]), torch.tensor([0.95, 0.7]), torch.tensor([0.5, 0.2])
+    out = ops.arcflow_step_dropout(x.cuda(), m.cuda(), lw.cuda(), lg.cuda(), s_src.cuda(), s_a.cuda(), s_b.cuda(), drop.cuda())
+    lwm = lw.masked_fill(drop[:, None, :, None], float('-inf'))
+    for b in range(B):
+        ref = R.momentum_step_packed(x[b:b + 1], m[b:b + 1], lwm[b:b + 1], lg[b:b + 1], float(s_src[b]), float(s_a[b]), float(s_b[b]))
+        close(out[b:b + 1], ref)
+    close(ops.euler_roll(x.cuda(), up.cuda(), s_a.cuda(), s_b.cuda()), x + up * (s_b - s_a).reshape(B, 1, 1))
+    close(ops.cfg_combine(x.cuda(), up.cuda(), 4.0), x + R.cfg_bias(x, up, 4.0))
+    loss = torch.zeros(1, device='cuda')
+    coef = 30.0 / x[0].numel() / B * 0.5
+    g = ops.mse_loss(x.cuda(), up.cuda(), coef, loss)
+    ref_loss = R.flow_mse_loss(x.reshape(B, -1), up.reshape(B, -1)) * 0.5        # x segment size 0.5
+    close(loss[0], ref_loss, rtol=1e-5)
+    close(g, coef * (x - up))
+
+
+def test_head_grad_and_weight_grads(ops):
+    g = torch.Generator().manual_seed(3)
+    B, N, K, ch, lw_ch, D = 2, 96, 16, 64, 4, 256
+    M = B * N
+    xn = torch.randn(M, D, generator=g).bfloat16()
+    w = (torch.randn(1152, D, generator=g) * 0.05).bfloat16()
+    w[1148:] = 0
+    wr = w.float().clone().requires_grad_(True)
+    y = xn.float() @ wr.T
+    means = y[:, :1024].reshape(B, N, K, ch)
+    logw = y[:, 1024:1088].reshape(B, N, K, lw_ch).log_softmax(dim=2)
+    logg = y[:, 1088:1148].reshape(B, N, K - 1, lw_ch)
+    dm = torch.randn(B, N, K, ch, generator=g)
+    dw = torch.randn(B, N, K, lw_ch, generator=g)
+    dg = torch.randn(B, N, K - 1, lw_ch, generator=g)
+    ((means * dm).sum() + (logw * dw).sum() + (logg * dg).sum()).backward()
+    dy = ops.head_grad(dm.cuda(), dw.cuda(), dg.cuda(), logw.detach().bfloat16().cuda(), 1152)
+    # reference dY from autograd: recompute via y.grad is not retained, so rebuild analytically
+    yl = y.detach().clone().requires_grad_(True)
+    ml = yl[:, :1024].reshape(B, N, K, ch)
+    ll = yl[:, 1024:1088].reshape(B, N, K, lw_ch).log_softmax(dim=2)
+    gl = yl[:, 1088:1148].reshape(B, N, K - 1, lw_ch)
+    ((ml * dm).sum() + (ll * dw).sum() + (gl * dg).sum()).backward()
+    close(dy.float()[:, :1148], yl.grad[:, :1148], rtol=1e-2, atol=2e-2)      # bf16 rows
+    assert dy[:, 1148:].abs().max().item() == 0
+    # dW = dY^T X through the transposed-operand GEMM with fp32 output
+    dyt, xt = ops.transpose(dy), ops.transpose(xn.cuda())
+    assert torch.equal(dyt.cpu(), dy.cpu().T) and torch.equal(xt.cpu(), xn.T)
+    Mp = (M + 63) // 64 * 64
+    assert Mp == M
+    dW = ops.linear_f32out(dyt, xt)
+    ref = dy.float().cpu().T @ xn.float()
+    close(dW, ref, rtol=1e-4, atol=1e-3)
+    dW2 = ops.linear_f32out(dyt, xt, out=dW.clone(), accumulate=True)
+    close(dW2, 2 * ref, rtol=1e-4, atol=2e-3)
+    rel = ((dW[:1148].cpu() - wr.grad[:1148]).norm() / wr.grad[:1148].norm()).item()
+    assert rel < 5e-3, rel                                                       # vs autograd (dY rounded to bf16)
+    db = ops.colsum(dy, torch.zeros(1152, device='cuda'))
+    close(db, dy.float().cpu().sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_normout_backward_and_outer(ops):
+    g = torch.Generator().manual_seed(4)
+    B, N, D = 2, 64, 512
+    x = (torch.randn(B * N, D, generator=g) * 2 + 0.5).bfloat16()
+    dxn = torch.randn(B * N, D, generator=g).bfloat16()
+    sc = torch.randn(B, D, generator=g).requires_grad_(True)
+    sh = torch.randn(B, D, generator=g).requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6).reshape(B, N, D) * (1 + sc[:, None]) + sh[:, None]
+    (xn * dxn.float().reshape(B, N, D)).sum().backward()
+    dmod = ops.normout_backward(x.cuda(), dxn.cuda(), torch.zeros(B, 2, D, device='cuda'), N)
+    close(dmod[:, 0], sc.grad, rtol=1e-4, atol=1e-3)
+    close(dmod[:, 1], sh.grad, rtol=1e-4, atol=1e-3)
+    semb = torch.randn(B, 128, generator=g)
+    dflat = dmod.reshape(B, 2 * D)
+    dW = ops.outer_accum(dflat, semb.cuda(), torch.ones(2 * D, 128, device='cuda'))
+    close(dW, 1 + dflat.cpu().T @ semb, rtol=1e-5, atol=1e-4)
+
+
+def test_adamw_ema_sumsq_cast(ops):
+    g = torch.Generator().manual_seed(5)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01)
+    p = p0.clone().cuda()
+    m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g)
+        pr.grad = gr.clone() * 0.5
+        opt.step()
+        ops.adamw_step(p, gr.cuda(), m, v, 1e-3, step, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.01, grad_scale=0.5)
+    close(p, pr.data, rtol=1e-5, atol=1e-6)
+    ema = torch.randn(n, generator=g)
+    e = ema.clone().cuda()
+    ops.ema_lerp(e, p, 0.93)
+    close(e, p.cpu() + (ema - p.cpu()) * 0.93)
+    acc = ops.sumsq(p, torch.zeros(1, device='cuda'))
+    close(acc[0], (p.cpu().double() ** 2).sum().float(), rtol=1e-4, atol=1e-2)
+    close(ops.cast_bf16(p).float(), p.cpu().bfloat16().float(), rtol=0, atol=0)
