@@ -144,7 +144,7 @@ constexpr int GEMV_MAXB = 8;
 
 __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, const bf16_t* __restrict__ W,
                                                    const bf16_t* __restrict__ bias, float* __restrict__ y,
-                                                   int B, int N, int K, int act, int accumulate) {
+                                                   int B, int N, int K, int act, int accumulate, int64_t ldy) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
       float r = wave_sum(acc[b]) + bv;
       if (act == 1) r = silu(r);
       if (lane == 0) {
-        float* yp = y + (int64_t)b * N + n;
+        float* yp = y + (int64_t)b * ldy + n;
         *yp = accumulate ? (*yp + r) : r;
       }
     }
@@ -180,10 +180,11 @@ __global__ __launch_bounds__(256) void gemv_kernel(const float* __restrict__ x, 
 }
 
 hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
-                       int K, int act, int accumulate, hipStream_t stream) {
+                       int K, int act, int accumulate, hipStream_t stream, int64_t ldy) {
+  if (ldy <= 0) ldy = N;
   if (B > GEMV_MAXB || (K & 7)) return hipErrorInvalidValue;
   if (N == 0 || B == 0) return hipSuccess;
-  hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, W, bias, y, B, N, K, act, accumulate);
+  hipLaunchKernelGGL(gemv_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, x, W, bias, y, B, N, K, act, accumulate, ldy);
   return hipGetLastError();
 }
 

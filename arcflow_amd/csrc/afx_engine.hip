@@ -243,6 +243,7 @@ int afx_finalize(afx_ctx* c) {
     NEED(need(c, p + "qknorm", AFX_DT_F32, {2, 128}));
   }
   NEED(need_linear(c, "head", c->head_n, D));
+  if (c->w.count("mod_final.weight")) NEED(need_linear(c, "mod_final", 2 * D, D));
 #undef NEED
   c->finalized = true;
   return AFX_OK;
@@ -300,6 +301,11 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   HIP_TRY(launch_silu(ws.temb, ws.semb, (int64_t)B * D, st));
   // every AdaLN modulation vector of the whole network in one weight-streaming pass
   HIP_TRY(launch_gemv(ws.semb, W16(c, "mod.weight"), W16(c, "mod.bias"), ws.mod, B, (int)c->n_mod, (int)D, 0, 0, st));
+  // a separately bound norm_out.linear (the distillation student trains its own copy while the teacher keeps the
+  // frozen one inside the stacked matrix: lakonlab/configs/flux/arcflux_2nfe_k16.py:20-25 freeze_exclude 'norm_out')
+  if (W16(c, "mod_final.weight") != nullptr)
+    HIP_TRY(launch_gemv(ws.semb, W16(c, "mod_final.weight"), W16(c, "mod_final.bias"), ws.mod + ml.fin(0), B, (int)(2 * D),
+                        (int)D, 0, 0, st, ldm));
 
   // ---- embedders into the joint layout X[b][text T | image N] ---------------------------------------
   const uint16_t* ctx_src = (const uint16_t*)ctx_emb;

@@ -49,7 +49,7 @@ hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, con
                                const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
                                hipStream_t stream);
 hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
-                       int K, int act, int accumulate, hipStream_t stream);
+                       int K, int act, int accumulate, hipStream_t stream, int64_t ldy = 0);
 hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream);
 hipError_t launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
 hipError_t launch_bf16_to_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream);

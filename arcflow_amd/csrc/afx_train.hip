@@ -353,6 +353,16 @@ __global__ __launch_bounds__(256) void euler_kernel(const float* __restrict__ xa
   out[i] = xa[i] + u[i] * (sb[b] - sa[b]);
 }
 
+// out = alpha[b] * a + beta[b] * b   (per-sample blend: mean velocity (x_a - x_e)/(sigma_a - sigma_e), short/long select)
+__global__ __launch_bounds__(256) void axpby_kernel(const float* __restrict__ a, const float* __restrict__ alpha,
+                                                    const float* __restrict__ bb, const float* __restrict__ beta,
+                                                    float* __restrict__ out, int64_t per_sample, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int64_t s = i / per_sample;
+  out[i] = alpha[s] * a[i] + beta[s] * bb[i];
+}
+
 // classifier-free guidance of the teacher:  u = pos + (pos - neg) * (scale - 1)    (gaussian_flow.py:18-26, non-orthogonal)
 __global__ __launch_bounds__(256) void cfg_kernel(const float* __restrict__ pos, const float* __restrict__ neg, float scale,
                                                   float* __restrict__ out, int64_t n) {
@@ -487,6 +497,16 @@ int afx_euler_roll(const float* x_a, const float* u, const float* sigma_a, const
   if (n == 0) return AFX_OK;
   hipLaunchKernelGGL(euler_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, x_a, u, sigma_a, sigma_b, out,
                      per_sample, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_axpby_rows(const float* a, const float* alpha, const float* b, const float* beta, float* out, int32_t batch,
+                   int64_t per_sample, void* stream) {
+  if (!a || !alpha || !b || !beta || !out || batch < 0 || per_sample < 1) return fail(AFX_E_INVALID, "bad argument to afx_axpby_rows");
+  const int64_t n = (int64_t)batch * per_sample;
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, a, alpha, b, beta, out, per_sample, n);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -123,6 +123,12 @@ class MMDiTEngine:
             self._rope_cache[k] = tuple(t.to(self.device) for t in cs)
         return self._rope_cache[k]
 
+    def export(self, what: str, dst: torch.Tensor, B: int, N: int, T: int) -> torch.Tensor:
+        """Copy an activation of the last forward out of the workspace ('head_in', 'x_final', 'silu_temb',
+        'mod_final'); the distillation step needs them for the head / norm_out gradients."""
+        _lib.check(self.lib.afx_mmdit_export(self._ctx, what.encode(), _ptr(dst), B, N, T, _stream()))
+        return dst
+
     # ------------------------------------------------------------------ instrumentation
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.afx_profile_enable(self._ctx, int(on)))

@@ -209,6 +209,17 @@ def euler_roll(x_a, u, sigma_a, sigma_b):
     return out
 
 
+def axpby_rows(a, alpha, b, beta):
+    """alpha[s] * a + beta[s] * b with per-sample scalars alpha, beta [B]."""
+    lib = _lib.load()
+    a, b = _cuda(a, torch.float32), _cuda(b, torch.float32)
+    B = a.shape[0]
+    al, be = _cuda(alpha.flatten().expand(B), torch.float32), _cuda(beta.flatten().expand(B), torch.float32)
+    out = torch.empty_like(a)
+    _lib.check(lib.afx_axpby_rows(_p(a), _p(al), _p(b), _p(be), _p(out), B, a[0].numel(), _s()))
+    return out
+
+
 def cfg_combine(pos, neg, scale: float):
     lib = _lib.load()
     pos, neg = _cuda(pos, torch.float32), _cuda(neg, torch.float32)

@@ -1,0 +1,2 @@
+from .distill import ArcFlowDistiller, DistillConfig  # noqa: F401
+from .reducer import GradReducer  # noqa: F401

@@ -1,0 +1,308 @@
+"""Data-free trajectory-matching distillation step (the reference's ``ArcFlowImitationDataFree``,
+lakonlab/models/diffusions/arcflow.py:338-426, driven by ``train_fwd_bwd`` lakonlab/models/base_diffusion.py:14-62
+and ``BaseModel.train_step`` lakonlab/models/base.py:76-103,162-189) on one MI355X per process.
+
+Per iteration and student step (nfe = 2):
+    student forward (HIP engine)  ->  K-component momentum policy
+    piid_segment_momentum (arcflow.py:120-209): 4 x { roll the detached (GM-dropout) policy to t_a,
+        teacher forward at (x_a, t_a), predicted mean velocity of the FULL policy over [t_b - window, t_a],
+        teacher Euler roll to t_b }, MSE x 30 x 0.5 x segment size, roll to the segment end
+    backward of the policy math -> head logits -> {velocity heads, norm_out.linear}  (fp32 gradients)
+then: gradient all-reduce (RCCL, launched per student step so it overlaps the next one), global-norm clip (50 from
+iteration 100, non-finite -> skip), AdamW (loggamma rows lr x 0.1, linear warm-up), Karras EMA of the trainables.
+
+Every tensor op on [B,N,*] data is a HIP kernel from libarcflow_hip (arcflow_amd.ops); torch supplies device memory,
+the RNG draws and the tiny [B]-sized schedule arithmetic.
+
+Scope of THIS round: the trainable set is {proj_out_means, proj_out_logweights, proj_out_loggamma, norm_out} of the
+reference's ``freeze_exclude`` (configs/flux/arcflux_2nfe_k16.py:20-25); the LoRA adapters (the fifth entry) need the
+trunk backward and arrive with it -- see DESIGN.md section 6.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+from .. import ops
+from ..engine import MMDiTEngine
+from ..weights import pack_flux, pack_head, pack_qwen
+from .reducer import GradReducer
+
+
+@dataclass
+class DistillConfig:
+    """train_cfg / optimizer values of configs/flux/arcflux_2nfe_k16.py:89-99 and _ddp_train.py:13-31."""
+    nfe: int = 2
+    timestep_ratio: float = 1.0
+    total_substeps: int = 128
+    window_substeps: int = 3
+    gm_dropout: float = 0.1
+    num_intermediate_states: int = 4
+    num_decay_iters: int = 2000
+    shift: float = 3.2
+    eps: float = 1e-4
+    loss_scale: float = 30.0
+    guidance: float = 3.5                 # distilled guidance fed to student and teacher (FLUX)
+    teacher_guidance_scale: float = 1.0   # > 1: true CFG with negative prompt embeds (Qwen: 4.0)
+    lr: float = 1e-4
+    betas: tuple = (0.9, 0.95)
+    weight_decay: float = 0.0
+    loggamma_lr_mult: float = 0.1
+    warmup_iters: int = 100
+    warmup_ratio: float = 0.001
+    grad_clip: float = 50.0
+    grad_clip_begin_iter: int = 100
+    ema_gamma: float = 7.0
+    ema_start_iter: int = 100
+
+
+def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
+    """sigma = s t / (1 + (s-1) t)   (ContinuousTimeStepSampler.warp_t, sampler.py:46-48)."""
+    return shift * t / (1 + (shift - 1) * t)
+
+
+class ArcFlowDistiller:
+    def __init__(self, family: str, engine_kwargs: dict, state_dict: Dict[str, torch.Tensor], cfg: DistillConfig,
+                 device='cuda', process_group=None):
+        """state_dict: diffusers keys of the teacher (with ``proj_out``) plus the student heads ``proj_out_*``."""
+        self.cfg, self.family, self.device = cfg, family, torch.device(device)
+        kw = dict(engine_kwargs)
+        nd, ns = kw.pop('num_double'), kw.pop('num_single', 0)
+        self.student = MMDiTEngine(family, nd, ns, device=device, **kw)
+        self.teacher = MMDiTEngine(family, nd, ns, device=device, teacher_head=True, **kw)
+        K, C, L = self.student.num_gaussians, self.student.in_channels, self.student.logweights_channels
+        if family == 'flux':
+            packed = pack_flux(state_dict, nd, ns, self.device, K, C, L, self.student.guidance_embeds)
+        else:
+            packed = pack_qwen(state_dict, nd, self.device, K, C, L)
+        # frozen trunk weights exist ONCE and are bound into both contexts (tie_untrained_submodules, utils/misc.py:116-133)
+        t_packed = dict(packed)
+        t_packed['head.weight'], t_packed['head.bias'] = pack_head(state_dict, self.device, K, C, L, teacher=True)
+        self.teacher.bind_packed(t_packed)
+        D = self.student.dim
+        self.D, self.K, self.C, self.L = D, K, C, L
+        self.head_n = packed['head.weight'].shape[0]
+        # ---- trainable set, flat fp32: [head.weight | head.bias | norm_out.weight | norm_out.bias] --------------
+        no_w = state_dict['norm_out.linear.weight'].to(self.device, torch.float32)
+        no_b = state_dict['norm_out.linear.bias'].to(self.device, torch.float32)
+        sizes = [self.head_n * D, self.head_n, 2 * D * D, 2 * D]
+        self._off = [0]
+        for s in sizes:
+            self._off.append(self._off[-1] + s)
+        n = self._off[-1]
+        self.params = torch.empty(n, dtype=torch.float32, device=self.device)
+        self._view(self.params, 0).copy_(packed['head.weight'].float().flatten())
+        self._view(self.params, 1).copy_(packed['head.bias'].float())
+        self._view(self.params, 2).copy_(no_w.flatten())
+        self._view(self.params, 3).copy_(no_b)
+        self.exp_avg = torch.zeros_like(self.params)
+        self.exp_avg_sq = torch.zeros_like(self.params)
+        self.ema = self.params.clone()
+        self.grads = [torch.zeros_like(self.params) for _ in range(cfg.nfe)]   # one buffer per student step
+        # bf16 working copies the engine reads
+        self.w_head = packed['head.weight']
+        self.b_head = packed['head.bias']
+        self.w_no = torch.empty(2 * D, D, dtype=torch.bfloat16, device=self.device)
+        self.b_no = torch.empty(2 * D, dtype=torch.bfloat16, device=self.device)
+        packed['mod_final.weight'], packed['mod_final.bias'] = self.w_no, self.b_no
+        self._sync_working_copies()
+        self.student.bind_packed(packed)
+        self.reducer = GradReducer(process_group)
+        self.iteration = 0
+        self.opt_steps = 0
+        self._norm_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    def _view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
+        return flat[self._off[i]:self._off[i + 1]]
+
+    def _sync_working_copies(self):
+        ops.cast_bf16(self._view(self.params, 0), self.w_head.view(-1))
+        ops.cast_bf16(self._view(self.params, 1), self.b_head)
+        ops.cast_bf16(self._view(self.params, 2), self.w_no.view(-1))
+        ops.cast_bf16(self._view(self.params, 3), self.b_no)
+
+    def trainable_state_dict(self, ema: bool = False) -> Dict[str, torch.Tensor]:
+        """diffusers-keyed trainables (the adapter file layout of export_arcflow_to_diffusers.py:100-127)."""
+        src = self.ema if ema else self.params
+        K, C, L, D = self.K, self.C, self.L, self.D
+        hw = self._view(src, 0).view(self.head_n, D)
+        hb = self._view(src, 1)
+        n1, n2 = K * C, K * C + K * L
+        n3 = n2 + (K - 1) * L
+        return {
+            'proj_out_means.weight': hw[:n1].clone(), 'proj_out_means.bias': hb[:n1].clone(),
+            'proj_out_logweights.weight': hw[n1:n2].clone(), 'proj_out_logweights.bias': hb[n1:n2].clone(),
+            'proj_out_loggamma.weight': hw[n2:n3].clone(), 'proj_out_loggamma.bias': hb[n2:n3].clone(),
+            'norm_out.linear.weight': self._view(src, 2).view(2 * D, D).clone(),
+            'norm_out.linear.bias': self._view(src, 3).clone(),
+        }
+
+    def _student(self, x, sigma, cond):
+        return self.student(x.to(torch.bfloat16), sigma, cond['prompt_embeds'], cond.get('pooled'),
+                            self._guid(x.shape[0]), cond['hp'], cond['wp'])
+
+    def _guid(self, B):
+        if self.family != 'flux' or not self.student.guidance_embeds:
+            return None
+        return torch.full((B,), self.cfg.guidance, device=self.device)
+
+    def _teacher_u(self, x, sigma, cond):
+        """Teacher velocity (GaussianFlow.forward_u, gaussian_flow.py:224-254): optional true CFG on a 2B batch."""
+        xb = x.to(torch.bfloat16)
+        g = self._guid(x.shape[0])
+        pos = self.teacher(xb, sigma, cond['prompt_embeds'], cond.get('pooled'), g, cond['hp'], cond['wp']).float()
+        if self.cfg.teacher_guidance_scale == 1.0:
+            return pos
+        neg = self.teacher(xb, sigma, cond['negative_prompt_embeds'], cond.get('negative_pooled'), g, cond['hp'], cond['wp']).float()
+        return ops.cfg_combine(pos, neg, self.cfg.teacher_guidance_scale)
+
+    # ------------------------------------------------------------------ one student segment
+    def _segment(self, step_id: int, x_src, raw_src, cond, teacher_ratio: float, segment: float, rng, draws=None):
+        """piid_segment_momentum + the head backward of this student step.  Returns (x_dst, raw_dst)."""
+        c = self.cfg
+        B, N, ch = x_src.shape
+        dev = self.device
+        K, pp = self.K, self.L
+        sigma_src = warp(raw_src, c.shift)
+        out = self._student(x_src, sigma_src, cond)
+        means, logw, logg = out.means, out.logweights, out.loggammas
+        T = cond['prompt_embeds'].shape[1]
+        xn = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
+        xf = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
+        semb = torch.empty(B, self.D, dtype=torch.float32, device=dev)
+        self.student.export('head_in', xn, B, N, T)
+        self.student.export('x_final', xf, B, N, T)
+        self.student.export('silu_temb', semb, B, N, T)
+
+        n_sub = max(round(segment * c.total_substeps), 1)
+        window = min(c.window_substeps * (segment / n_sub), segment)
+        raw_dst = raw_src - segment
+        # GM dropout of the roll-out policy (policies/arcflow.py:96-106)
+        n = c.num_intermediate_states
+        if draws is None:      # same draw order as the reference: dropout, student intervals, teacher intervals
+            draws = (torch.rand(B, K, device=dev, generator=rng), torch.rand(B, n, device=dev, generator=rng),
+                     torch.rand(B, n - 1, device=dev, generator=rng))
+        u_drop, u_stu, u_tea = (d.to(dev) for d in draws)
+        drop = u_drop < c.gm_dropout
+        drop &= ~drop.all(dim=1, keepdim=True)
+        if c.gm_dropout <= 0:
+            drop = None
+        span = segment - window
+        s_iv = torch.sort(u_stu * ((1 - teacher_ratio) * span), dim=-1)[0]
+        s_iv = torch.diff(s_iv, dim=-1, prepend=torch.zeros(B, 1, device=dev))
+        t_iv = torch.sort(u_tea, dim=-1)[0]
+        t_iv = torch.diff(t_iv, dim=-1, prepend=torch.zeros(B, 1, device=dev), append=torch.ones(B, 1, device=dev)) \
+            * (teacher_ratio * span)
+
+        d_means = torch.zeros(B, N, K, ch, dtype=torch.float32, device=dev)
+        d_logw = torch.zeros(B, N, K, pp, dtype=torch.float32, device=dev)
+        d_logg = torch.zeros(B, N, K - 1, pp, dtype=torch.float32, device=dev)
+        coef = c.loss_scale / (n * B * N * ch) * segment          # mean over the 4B stacked states x segment weight
+        x, raw, sigma = x_src, raw_src, sigma_src
+        one = torch.ones(B, device=dev)
+        for i in range(n):
+            raw_a = (raw - s_iv[:, i]).clamp(min=0)
+            raw_b = (raw_a - t_iv[:, i]).clamp(min=0)
+            sigma_a = warp(raw_a, c.shift)
+            x_a = ops.arcflow_step_dropout(x, means, logw, logg, sigma_src, sigma, sigma_a, drop, c.eps)
+            tgt = self._teacher_u(x_a, sigma_a, cond)
+            # predicted mean velocity of the full policy over [raw_e, raw_a] (policy_average_u_momentum)
+            raw_e = raw_b - window
+            short = (torch.round((raw_a - raw_e) * c.total_substeps) < 2).float()
+            sigma_e = warp(raw_e, c.shift)
+            inv_den = 1.0 / (sigma_a - sigma_e).clamp(min=c.eps)
+            x_e = ops.arcflow_step(x_a, means, logw, logg, sigma_src, sigma_a, sigma_e, c.eps)
+            u_mean = ops.axpby_rows(x_a, inv_den, x_e, -inv_den)
+            u_loc = ops.arcflow_velocity(means, logw, logg, sigma_src, sigma_a)
+            pred = ops.axpby_rows(u_loc, short, u_mean, one - short)
+            g = ops.mse_loss(pred, tgt, coef, self._loss_acc)
+            ops.arcflow_backward(g, means, logw, logg, sigma_src, sigma_a, sigma_e, gscale=(one - short) * inv_den,
+                                 grads=(d_means, d_logw, d_logg), eps=c.eps)
+            ops.arcflow_backward(g, means, logw, logg, sigma_src, sigma_a, sigma_a, gscale=short, velocity=True,
+                                 grads=(d_means, d_logw, d_logg), eps=c.eps)
+            sigma_b = warp(raw_b, c.shift)
+            x = ops.euler_roll(x_a, tgt, sigma_a, sigma_b)
+            raw, sigma = raw_b, sigma_b
+        x_dst = ops.arcflow_step_dropout(x, means, logw, logg, sigma_src, sigma, warp(raw_dst, c.shift), drop, c.eps)
+
+        # ---- backward: head logits -> head weights / bias, norm_out modulation -> norm_out.linear ---------------
+        gbuf = self.grads[step_id]
+        dy = ops.head_grad(d_means, d_logw, d_logg, logw, self.head_n)                 # [M, head_n] bf16
+        M = B * N
+        Mp = (M + 63) // 64 * 64
+        if Mp != M:
+            raise ValueError('batch x tokens must be a multiple of 64 for the weight-gradient GEMM')
+        dyt, xnt = ops.transpose(dy), ops.transpose(xn)                               # contraction over tokens
+        ops.linear_f32out(dyt, xnt, out=self._view(gbuf, 0).view(self.head_n, self.D), accumulate=True)
+        ops.colsum(dy, self._view(gbuf, 1))
+        dxn = ops.linear(dy, ops.transpose(self.w_head))                               # [M, D] bf16 = dY . W_head
+        dmod = ops.normout_backward(xf, dxn, torch.zeros(B, 2, self.D, dtype=torch.float32, device=dev), N)
+        dflat = dmod.view(B, 2 * self.D)
+        ops.outer_accum(dflat, semb, self._view(gbuf, 2).view(2 * self.D, self.D))
+        ops.outer_accum(dflat, torch.ones(B, 1, device=dev), self._view(gbuf, 3).view(2 * self.D, 1))
+        return x_dst, raw_dst
+
+    # ------------------------------------------------------------------ one iteration
+    def lr_at(self, it: int) -> float:
+        c = self.cfg
+        if it < c.warmup_iters:
+            k = (1 - it / c.warmup_iters) * (1 - c.warmup_ratio)
+            return c.lr * (1 - k)
+        return c.lr
+
+    def train_step(self, cond: dict, batch: int, rng: Optional[torch.Generator] = None, x_init: Optional[torch.Tensor] = None,
+                   draws=None):
+        """cond: prompt_embeds [B,T,joint] (+ pooled, negative_*), hp, wp.  Returns a dict of python floats
+        (loss, grad_norm, lr, teacher_ratio, skipped) -- one host sync per step, like the reference's float(loss)."""
+        c = self.cfg
+        N = cond['hp'] * cond['wp']
+        it = self.iteration
+        teacher_ratio = 1 - min(it, c.num_decay_iters) / c.num_decay_iters if c.num_decay_iters > 0 else 0.0
+        for gbuf in self.grads:
+            gbuf.zero_()
+        self._loss_acc.zero_()
+        x = x_init if x_init is not None else torch.randn(batch, N, self.C, device=self.device, generator=rng)
+        raw = torch.ones(batch, device=self.device)
+        base = 1.0 / (c.nfe - 1 + max(c.timestep_ratio, c.eps))
+        for step_id in range(c.nfe):
+            seg = base * max(c.timestep_ratio, c.eps) if step_id == c.nfe - 1 else base
+            x, raw = self._segment(step_id, x, raw, cond, teacher_ratio, seg, rng, None if draws is None else draws[step_id])
+            self.reducer.launch(self.grads[step_id])          # overlaps the next student step
+        inv_world = self.reducer.finish()
+        g = self.grads[0]
+        for other in self.grads[1:]:
+            g.add_(other)                                      # flat buffer sum (plumbing-sized: 22 M floats)
+        self._norm_acc.zero_()
+        ops.sumsq(g, self._norm_acc)
+        grad_norm = float(self._norm_acc.sqrt()) * inv_world   # the step's one host sync
+        loss = float(self._loss_acc)
+        lr = self.lr_at(it)
+        skipped = not (grad_norm == grad_norm and grad_norm != float('inf'))
+        if not skipped:
+            scale = inv_world
+            if it >= c.grad_clip_begin_iter and c.grad_clip > 0 and grad_norm > c.grad_clip:
+                scale *= c.grad_clip / (grad_norm + 1e-6)
+            self.opt_steps += 1
+            K, C, L = self.K, self.C, self.L
+            n2 = K * C + K * L                                 # head rows below n2: means + logweights; then loggamma
+            hw, hb = self._off[0], self._off[1]
+            groups = [(hw, hw + n2 * self.D, lr), (hw + n2 * self.D, self._off[1], lr * c.loggamma_lr_mult),
+                      (hb, hb + n2, lr), (hb + n2, self._off[2], lr * c.loggamma_lr_mult),
+                      (self._off[2], self._off[4], lr)]
+            for a, b, glr in groups:
+                ops.adamw_step(self.params[a:b], g[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], glr, self.opt_steps,
+                               betas=c.betas, weight_decay=c.weight_decay, grad_scale=scale)
+            self._sync_working_copies()
+        # Karras EMA (ema_hook.py:86-124): copy before start_iter, lerp after
+        if it < c.ema_start_iter:
+            self.ema.copy_(self.params)
+        else:
+            t = max(it + 1 - c.ema_start_iter, 1)
+            ops.ema_lerp(self.ema, self.params, min((1 - 1 / t) ** (c.ema_gamma + 1), 1.0))
+        self.iteration += 1
+        self.last_x = x
+        return dict(loss=loss, grad_norm=grad_norm, lr=lr, teacher_ratio=teacher_ratio, skipped=skipped)

@@ -183,3 +183,25 @@ def random_packed(family: str, num_double: int, num_single: int, device, heads: 
     raw = in_channels if teacher else K * in_channels + K * L + (K - 1) * L
     lin('head', (raw + 7) // 8 * 8, D)
     return p
+
+
+def init_arcflow_heads_from_teacher(sd: Dict[str, Tensor], K: int = 16, L: int = 4, noise_std: float = 0.05,
+                                    generator: Optional[torch.Generator] = None) -> Dict[str, Tensor]:
+    """Student head initialisation from the teacher's ``proj_out`` (reference
+    lakonlab/models/architecture/arcflow/arcflux.py:328-341 and :103-132): means = K tiled copies of proj_out with a
+    per-(component, channel) bias jitter shared by the p^2 sub-pixels, log-weights zero, log-gamma weight zero with
+    the log-spaced rate bias.  Returns a copy of ``sd`` with the three ``proj_out_*`` linears added."""
+    import math
+    out = dict(sd)
+    w, b = sd['proj_out.weight'], sd['proj_out.bias']
+    C, D = w.shape
+    out['proj_out_means.weight'] = w[None].expand(K, -1, -1).reshape(K * C, D).clone()
+    jitter = torch.randn(K * C // L, generator=generator) * noise_std
+    out['proj_out_means.bias'] = (b[None].expand(K, -1).reshape(K * C).float()
+                                  + jitter[:, None].expand(-1, L).flatten()).to(b.dtype)
+    out['proj_out_logweights.weight'] = torch.zeros(K * L, D, dtype=w.dtype)
+    out['proj_out_logweights.bias'] = torch.zeros(K * L, dtype=b.dtype)
+    out['proj_out_loggamma.weight'] = torch.zeros((K - 1) * L, D, dtype=w.dtype)
+    rates = torch.logspace(math.log10(0.2), math.log10(4.0), K - 1, base=10)
+    out['proj_out_loggamma.bias'] = torch.log(rates).unsqueeze(1).repeat(1, L).flatten().to(b.dtype)
+    return out

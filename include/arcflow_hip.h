@@ -76,6 +76,8 @@ int afx_destroy(afx_ctx* ctx);
  *   d<i>.{img,txt}_{qkv,out,mlp1,mlp2}.{weight,bias}   d<i>.qknorm   (rows k|v|q in *_qkv)
  *   s<i>.{fused,out}.{weight,bias}          s<i>.qknorm              (rows k|v|q|mlp in fused)
  *   head.{weight,bias}
+ *   mod_final.{weight,bias}   optional: a separately owned norm_out.linear [2D, D] that overrides the last 2D rows
+ *                             of mod.* (the distillation student trains it while the teacher keeps the frozen copy)
  */
 int afx_bind_weight(afx_ctx* ctx, const char* name, const void* dptr, int32_t dtype,
                     int32_t ndim, const int64_t* shape);
@@ -162,6 +164,10 @@ int afx_mse_loss(const float* pred, const float* target, float coef, float* grad
 /* x_out = x_a + u * (sigma_b[b] - sigma_a[b])   teacher Euler roll (arcflow.py:189-192) */
 int afx_euler_roll(const float* x_a, const float* u, const float* sigma_a, const float* sigma_b, float* out,
                    int32_t batch, int64_t per_sample, void* stream);
+/* out = alpha[b] * a + beta[b] * b, per-sample scalars: mean velocity (x_a - x_e) / (sigma_a - sigma_e) and the
+ * short/long roll-out select of policy_average_u_momentum (arcflow.py:92-110) */
+int afx_axpby_rows(const float* a, const float* alpha, const float* b, const float* beta, float* out, int32_t batch,
+                   int64_t per_sample, void* stream);
 /* out = pos + (pos - neg) * (scale - 1)   teacher CFG (gaussian_flow.py:18-26, orthogonal=False) */
 int afx_cfg_combine(const float* pos, const float* neg, float scale, float* out, int64_t n, void* stream);
 
