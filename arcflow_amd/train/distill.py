@@ -64,29 +64,38 @@ def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
 
 
 class ArcFlowDistiller:
-    def __init__(self, family: str, engine_kwargs: dict, state_dict: Dict[str, torch.Tensor], cfg: DistillConfig,
-                 device='cuda', process_group=None):
-        """state_dict: diffusers keys of the teacher (with ``proj_out``) plus the student heads ``proj_out_*``."""
+    def __init__(self, family: str, engine_kwargs: dict, state_dict: Optional[Dict[str, torch.Tensor]], cfg: DistillConfig,
+                 device='cuda', process_group=None, packed: Optional[Dict[str, torch.Tensor]] = None):
+        """state_dict: diffusers keys of the teacher (with ``proj_out``) plus the student heads ``proj_out_*``.
+        Alternatively ``packed``: an already fused weight set on the device (arcflow_amd.weights.random_packed) that
+        also carries ``teacher_head.{weight,bias}`` and ``norm_out.{weight,bias}`` -- synthetic-weight benchmarks."""
         self.cfg, self.family, self.device = cfg, family, torch.device(device)
         kw = dict(engine_kwargs)
         nd, ns = kw.pop('num_double'), kw.pop('num_single', 0)
         self.student = MMDiTEngine(family, nd, ns, device=device, **kw)
         self.teacher = MMDiTEngine(family, nd, ns, device=device, teacher_head=True, **kw)
         K, C, L = self.student.num_gaussians, self.student.in_channels, self.student.logweights_channels
-        if family == 'flux':
-            packed = pack_flux(state_dict, nd, ns, self.device, K, C, L, self.student.guidance_embeds)
+        if packed is not None:
+            packed = dict(packed)
+            th_w, th_b = packed.pop('teacher_head.weight'), packed.pop('teacher_head.bias')
+            no_w32, no_b32 = packed.pop('norm_out.weight').float(), packed.pop('norm_out.bias').float()
         else:
-            packed = pack_qwen(state_dict, nd, self.device, K, C, L)
+            if family == 'flux':
+                packed = pack_flux(state_dict, nd, ns, self.device, K, C, L, self.student.guidance_embeds)
+            else:
+                packed = pack_qwen(state_dict, nd, self.device, K, C, L)
+            th_w, th_b = pack_head(state_dict, self.device, K, C, L, teacher=True)
+            no_w32 = state_dict['norm_out.linear.weight'].to(self.device, torch.float32)
+            no_b32 = state_dict['norm_out.linear.bias'].to(self.device, torch.float32)
         # frozen trunk weights exist ONCE and are bound into both contexts (tie_untrained_submodules, utils/misc.py:116-133)
         t_packed = dict(packed)
-        t_packed['head.weight'], t_packed['head.bias'] = pack_head(state_dict, self.device, K, C, L, teacher=True)
+        t_packed['head.weight'], t_packed['head.bias'] = th_w, th_b
         self.teacher.bind_packed(t_packed)
         D = self.student.dim
         self.D, self.K, self.C, self.L = D, K, C, L
         self.head_n = packed['head.weight'].shape[0]
         # ---- trainable set, flat fp32: [head.weight | head.bias | norm_out.weight | norm_out.bias] --------------
-        no_w = state_dict['norm_out.linear.weight'].to(self.device, torch.float32)
-        no_b = state_dict['norm_out.linear.bias'].to(self.device, torch.float32)
+        no_w, no_b = no_w32, no_b32
         sizes = [self.head_n * D, self.head_n, 2 * D * D, 2 * D]
         self._off = [0]
         for s in sizes:

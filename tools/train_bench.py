@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Distillation-step throughput on one MI355X (BASELINE.json configs[3] shape per GPU: FLUX-12B architecture,
+4 samples, 1024^2 latents, 512 text tokens, random-init weights).  Trainable set of this round: heads + norm_out.
+
+    python tools/train_bench.py [--batch 4] [--iters 3] [--model flux]
+    torchrun --nproc-per-node N tools/train_bench.py ...     (data parallel, RCCL all-reduce of the trainables)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=4)
+    ap.add_argument('--iters', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--model', default='flux')
+    args = ap.parse_args()
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dev = f'cuda:{local}'
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from arcflow_amd.weights import random_packed
+    assert args.model == 'flux'
+    D = 3072
+    packed = random_packed('flux', 19, 38, dev, seed=0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    packed['teacher_head.weight'] = (torch.randn(64, D, generator=g, device=dev) * 0.02).bfloat16()
+    packed['teacher_head.bias'] = torch.zeros(64, device=dev, dtype=torch.bfloat16)
+    packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
+    packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
+    dist_ = ArcFlowDistiller('flux', dict(num_double=19, num_single=38), None, DistillConfig(), device=dev, packed=packed)
+    B = args.batch
+    cond = dict(prompt_embeds=(torch.randn(B, 512, 4096, device=dev, generator=g) * 0.1).bfloat16(),
+                pooled=(torch.randn(B, 768, device=dev, generator=g) * 0.1).bfloat16(), hp=64, wp=64)
+    rng = torch.Generator(device=dev).manual_seed(100 + rank)
+    for _ in range(args.warmup):
+        info = dist_.train_step(cond, B, rng=rng)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        info = dist_.train_step(cond, B, rng=rng)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    fwd_equiv = 2 + 8                       # student + teacher forwards per sample-iteration (no trunk backward yet)
+    if rank == 0:
+        print(json.dumps({'metric': 'distillation samples/s (heads + norm_out trainable set)', 'value': world * B / dt,
+                          's_per_iter': dt, 'batch_per_gpu': B, 'n_gpus': world, 'last': info,
+                          'forward_equivalents_per_sample': fwd_equiv,
+                          'denoiser_tflops': world * B * fwd_equiv * 74.41 / dt}))
+
+
+if __name__ == '__main__':
+    main()
