@@ -80,7 +80,8 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
-    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B) {
+    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B,
+    float* __restrict__ lse) {
   // two stages of { K tile [64][128] | V^T tile [128][64] }, 16 KiB each -> 64 KiB
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
@@ -251,6 +252,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   // ---- normalise and store: lane (q, hi) holds O[q][32*d + 8*g + 4*hi + 0..3] -------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.0f / l_tot;
+  // log2-domain log-sum-exp of the scaled scores: P = exp2(s * c - lse); consumed by the backward kernels
+  if (lse != nullptr && hi == 0 && q0 + ql < S) lse[((int64_t)b * H + h) * S_pad + q0 + ql] = m_run * c + __log2f(l_tot);
   if (q0 + ql < S) {
     bf16_t* op = o + ((int64_t)b * S + q0 + ql) * ldo + h * HD;
 #pragma unroll
@@ -267,12 +270,12 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
 
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream) {
+                            hipStream_t stream, float* lse) {
   const int S_pad = (int)attn_spad(S);
   const int nq = (S + QB - 1) / QB;
   const int heads_per_xcd = (H + 7) / 8;
   dim3 grid(8 * heads_per_xcd * nq * B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B, lse);
   return hipGetLastError();
 }
 

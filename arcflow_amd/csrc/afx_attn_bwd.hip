@@ -1,0 +1,380 @@
+// Flash-attention backward for gfx950 (head_dim 128, bf16 in/out, no mask), the gradient twin of afx_attn.hip.
+//
+// Given Q, K, V, O, dO and the forward's log2-domain row statistic L (P = exp2(s c - L)):
+//     delta_q = sum_d dO[q,d] O[q,d]
+//     dV = P^T dO        dP = dO V^T        dS = P o (dP - delta) / sqrt(d)        dQ = dS K        dK = dS^T Q
+// Two kernels, no atomics, both on v_mfma_f32_32x32x16_bf16 with the same "reduction index lives in the
+// registers of ONE lane" trick as the forward:
+//   * dQ kernel   (query-stationary, lane = query):  S^T = K Q^T, dP^T = V dO^T  -> dS^T is already the B operand
+//                 of dQ^T += K^T dS^T  (K^T tile pre-transposed with the 16-group key permutation of afx_attn.hip)
+//   * dKdV kernel (key-stationary,   lane = key):    S = Q K^T,  dP = dO V^T   -> P and dS are already the B
+//                 operands of dV^T += dO^T P and dK^T += Q^T dS (Q^T / dO^T tiles pre-transposed, queries permuted)
+// S and dP are recomputed in both kernels (7 matmuls instead of 5) in exchange for determinism and zero
+// inter-work-group traffic.  Tiles stream HBM -> LDS by LDS-DMA into 2-stage XOR-swizzled rings.
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+namespace {
+constexpr int HD = 128;
+constexpr int TB = 64;                    // tile of the streamed index (keys in dQ, queries in dKdV)
+constexpr int ROWMAJ_BYTES = TB * HD * 2; // [64][128] bf16 tile, 256-byte rows, chunk ^ (row & 15) swizzle
+constexpr int TRANS_BYTES = HD * TB * 2;  // [128][64] bf16 tile, 128-byte rows, chunk ^ ((row >> 1) & 7) swizzle
+constexpr float SCALE = 0.08838834764831845f;                 // 1/sqrt(128)
+constexpr float C_LOG2 = 0.08838834764831845f * 1.4426950408889634f;
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+// one 1 KiB piece of a row-major [64][128] tile: chunk index p -> (row, physical chunk), source swizzled
+template <int nthreads>
+AFX_DEV void dma_rowmajor(const bf16_t* base, int64_t ld, int row0, int nrows, char* dst, int tid, int wave_u) {
+  constexpr int pieces = (TB * 16) / nthreads;
+#pragma unroll
+  for (int i = 0; i < pieces; ++i) {
+    int seed = i * nthreads + tid;
+    const int r = seed >> 4, cp = seed & 15;
+    const int gr = min(row0 + r, nrows - 1);
+    const bf16_t* src = base + (int64_t)gr * ld + ((cp ^ (r & 15)) << 3);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (i * nthreads + wave_u * 64) * 16), 16, 0, 0);
+  }
+}
+// one piece of a transposed [128][64] tile out of X^T[128][S_pad]
+template <int nthreads>
+AFX_DEV void dma_trans(const bf16_t* base, int64_t S_pad, int col0, char* dst, int tid, int wave_u) {
+  constexpr int pieces = (HD * 8) / nthreads;
+#pragma unroll
+  for (int i = 0; i < pieces; ++i) {
+    int seed = i * nthreads + tid;
+    const int d = seed >> 3, vp = seed & 7;
+    const bf16_t* src = base + (int64_t)d * S_pad + col0 + ((vp ^ ((d >> 1) & 7)) << 3);
+    __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(dst + (i * nthreads + wave_u * 64) * 16), 16, 0, 0);
+  }
+}
+AFX_DEV bf16x8_t frag_rowmaj(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * 256 + ((chunk ^ (row & 15)) << 4));
+}
+AFX_DEV bf16x8_t frag_trans(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8_t*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+}  // namespace
+
+// delta[b,h,q] = sum_d dO O   (one 16-lane group per (row, head); pad rows get 0)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o, int64_t ldo,
+                                                         const bf16_t* __restrict__ dout, int64_t lddo,
+                                                         float* __restrict__ delta, int H, int S, int S_pad, int64_t total) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int c = (int)(g & 15);
+  const int64_t th = g >> 4;
+  const int h = (int)(th % H);
+  const int64_t row = th / H;               // b * S + s
+  float a[8], b[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(o + row * ldo + h * HD + c * 8), a);
+  unpack8(*reinterpret_cast<const u32x4_t*>(dout + row * lddo + h * HD + c * 8), b);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s += a[e] * b[e];
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (c == 0) {
+    const int64_t bb = row / S, ss = row % S;
+    delta[(bb * H + h) * S_pad + ss] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dQ
+constexpr int DQ_WAVES = 8;
+constexpr int DQ_THREADS = DQ_WAVES * 64;
+constexpr int DQ_STAGE = 2 * ROWMAJ_BYTES + TRANS_BYTES;      // K | V | K^T = 48 KiB
+
+__global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
+    const bf16_t* __restrict__ v, int64_t ldv, const bf16_t* __restrict__ kt, const bf16_t* __restrict__ dout,
+    int64_t lddo, const float* __restrict__ lse, const float* __restrict__ delta, bf16_t* __restrict__ dq,
+    int64_t lddq, int H, int S, int S_pad, int nq, int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int ql = lane & 31, hi = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int per_head = nq * B;
+  const int h = xcd + 8 * (slot_id / per_head);
+  if (h >= H) return;
+  const int rem = slot_id % per_head;
+  const int b = rem / nq;
+  const int q0 = (rem % nq) * (DQ_WAVES * 32) + wave * 32;
+  const bool q_ok = q0 + ql < S;
+  const int qrow = min(q0 + ql, S - 1);
+  const int ntiles = S_pad / TB;
+
+  const bf16_t* kbase = k + (int64_t)b * S * ldk + h * HD;
+  const bf16_t* vbase = v + (int64_t)b * S * ldv + h * HD;
+  const bf16_t* ktbase = kt + ((int64_t)(b * H + h) * HD) * S_pad;
+  const bf16_t* qp = q + ((int64_t)b * S + qrow) * ldq + h * HD;
+  const bf16_t* dop = dout + ((int64_t)b * S + qrow) * lddo + h * HD;
+  bf16x8_t qf[8], dof[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16 + hi * 8);
+    dof[s] = *reinterpret_cast<const bf16x8_t*>(dop + s * 16 + hi * 8);
+  }
+  const int64_t stat = ((int64_t)b * H + h) * S_pad + qrow;
+  const float Lq = q_ok ? lse[stat] : INFINITY;          // rows past S: P = 0
+  const float Dq = q_ok ? delta[stat] : 0.f;
+
+  auto stage = [&](int t, int buf) {
+    char* kd = smem + buf * DQ_STAGE;
+    dma_rowmajor<DQ_THREADS>(kbase, ldk, t * TB, S, kd, tid, wave_u);
+    dma_rowmajor<DQ_THREADS>(vbase, ldv, t * TB, S, kd + ROWMAJ_BYTES, tid, wave_u);
+    dma_trans<DQ_THREADS>(ktbase, S_pad, t * TB, kd + 2 * ROWMAJ_BYTES, tid, wave_u);
+  };
+  f32x16_t acc[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
+
+  stage(0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    asm volatile("" : "+v"(qf[s]));
+    asm volatile("" : "+v"(dof[s]));
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    const char* ks = smem + (t & 1) * DQ_STAGE;
+    const char* vs = ks + ROWMAJ_BYTES;
+    const char* kts = ks + 2 * ROWMAJ_BYTES;
+    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+    bf16x8_t dsf[4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      f32x16_t sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
+      const int krow = kb * 32 + ql;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(ks, krow, s * 2 + hi), qf[s], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(vs, krow, s * 2 + hi), dof[s], dp, 0, 0, 0);
+      }
+      float dsv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = t * TB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const float p = key < S ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - Lq) : 0.f;
+        dsv[r] = p * (dp[r] - Dq) * SCALE;
+      }
+#pragma unroll
+      for (int ksub = 0; ksub < 2; ++ksub) {
+        float tmp[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tmp[j] = dsv[ksub * 8 + j];
+        const u32x4_t w = pack8(tmp);
+        dsf[kb * 2 + ksub] = __builtin_bit_cast(bf16x8_t, w);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+        acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(kts, d * 32 + ql, g * 2 + hi), dsf[g], acc[d], 0, 0, 0);
+    __syncthreads();
+  }
+  if (q_ok) {
+    bf16_t* op = dq + ((int64_t)b * S + q0 + ql) * lddq + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf16x2(acc[d][4 * g + 0], acc[d][4 * g + 1]);
+        w[1] = pack_bf16x2(acc[d][4 * g + 2], acc[d][4 * g + 3]);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + g * 8 + hi * 4) = w;
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+constexpr int DKV_WAVES = 4;
+constexpr int DKV_THREADS = DKV_WAVES * 64;
+constexpr int DKV_STAT = 2 * TB * 4;                                       // L | delta of the 64 queries
+constexpr int DKV_STAGE = 2 * ROWMAJ_BYTES + 2 * TRANS_BYTES + DKV_STAT;   // Q | dO | Q^T | dO^T | stats
+
+__global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
+    const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
+    const bf16_t* __restrict__ v, int64_t ldv, const bf16_t* __restrict__ qt, const bf16_t* __restrict__ dout,
+    int64_t lddo, const bf16_t* __restrict__ dot, const float* __restrict__ lse, const float* __restrict__ delta,
+    bf16_t* __restrict__ dk, int64_t lddk, bf16_t* __restrict__ dv, int64_t lddv, int H, int S, int S_pad, int nk,
+    int B) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int kl = lane & 31, hi = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int per_head = nk * B;
+  const int h = xcd + 8 * (slot_id / per_head);
+  if (h >= H) return;
+  const int rem = slot_id % per_head;
+  const int b = rem / nk;
+  const int k0 = (rem % nk) * (DKV_WAVES * 32) + wave * 32;
+  const bool k_ok = k0 + kl < S;
+  const int krow = min(k0 + kl, S - 1);
+  const int ntiles = S_pad / TB;
+
+  const bf16_t* qbase = q + (int64_t)b * S * ldq + h * HD;
+  const bf16_t* dobase = dout + (int64_t)b * S * lddo + h * HD;
+  const bf16_t* qtbase = qt + ((int64_t)(b * H + h) * HD) * S_pad;
+  const bf16_t* dotbase = dot + ((int64_t)(b * H + h) * HD) * S_pad;
+  const float* lbase = lse + ((int64_t)b * H + h) * S_pad;
+  const float* dbase = delta + ((int64_t)b * H + h) * S_pad;
+  const bf16_t* kp = k + ((int64_t)b * S + krow) * ldk + h * HD;
+  const bf16_t* vp = v + ((int64_t)b * S + krow) * ldv + h * HD;
+  bf16x8_t kf[8], vf[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    kf[s] = *reinterpret_cast<const bf16x8_t*>(kp + s * 16 + hi * 8);
+    vf[s] = *reinterpret_cast<const bf16x8_t*>(vp + s * 16 + hi * 8);
+  }
+
+  auto stage = [&](int t, int buf) {
+    char* base = smem + buf * DKV_STAGE;
+    dma_rowmajor<DKV_THREADS>(qbase, ldq, t * TB, S, base, tid, wave_u);
+    dma_rowmajor<DKV_THREADS>(dobase, lddo, t * TB, S, base + ROWMAJ_BYTES, tid, wave_u);
+    dma_trans<DKV_THREADS>(qtbase, S_pad, t * TB, base + 2 * ROWMAJ_BYTES, tid, wave_u);
+    dma_trans<DKV_THREADS>(dotbase, S_pad, t * TB, base + 2 * ROWMAJ_BYTES + TRANS_BYTES, tid, wave_u);
+    char* st = base + 2 * ROWMAJ_BYTES + 2 * TRANS_BYTES;
+    if (wave_u == 0)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(lbase + t * TB + lane), (lds_void_t*)st, 4, 0, 0);
+    else if (wave_u == 1)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(dbase + t * TB + lane), (lds_void_t*)(st + TB * 4), 4, 0, 0);
+  };
+  f32x16_t dva[4], dka[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dva[d][r] = dka[d][r] = 0.f;
+
+  stage(0, 0);
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    asm volatile("" : "+v"(kf[s]));
+    asm volatile("" : "+v"(vf[s]));
+  }
+  for (int t = 0; t < ntiles; ++t) {
+    const char* qs = smem + (t & 1) * DKV_STAGE;
+    const char* dos = qs + ROWMAJ_BYTES;
+    const char* qts = qs + 2 * ROWMAJ_BYTES;
+    const char* dots = qts + TRANS_BYTES;
+    const float* lst = reinterpret_cast<const float*>(dots + TRANS_BYTES);
+    const float* dst = lst + TB;
+    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      f32x16_t sa, dp;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
+      const int qrow = qb * 32 + kl;                       // A-operand row of this lane = a query of the tile
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(qs, qrow, s * 2 + hi), kf[s], sa, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(dos, qrow, s * 2 + hi), vf[s], dp, 0, 0, 0);
+      }
+      // lane = key (column), register r = query 32 qb + (r&3) + 8 (r>>2) + 4 hi
+      float pv[16], dsv[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lst + qb * 32 + 8 * g + 4 * hi);
+        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dst + qb * 32 + 8 * g + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float p = k_ok ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - l4[e]) : 0.f;
+          pv[r] = p;
+          dsv[r] = p * (dp[r] - d4[e]) * SCALE;
+        }
+      }
+#pragma unroll
+      for (int ksub = 0; ksub < 2; ++ksub) {
+        float t0[8], t1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          t0[j] = pv[ksub * 8 + j];
+          t1[j] = dsv[ksub * 8 + j];
+        }
+        const u32x4_t w0 = pack8(t0), w1 = pack8(t1);
+        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, w0);
+        const bf16x8_t df = __builtin_bit_cast(bf16x8_t, w1);
+        const int chunk = (qb * 2 + ksub) * 2 + hi;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(dots, d * 32 + kl, chunk), pf, dva[d], 0, 0, 0);
+          dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(qts, d * 32 + kl, chunk), df, dka[d], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (k_ok) {
+    bf16_t* kp_o = dk + ((int64_t)b * S + k0 + kl) * lddk + h * HD;
+    bf16_t* vp_o = dv + ((int64_t)b * S + k0 + kl) * lddv + h * HD;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf16x2(dka[d][4 * g + 0], dka[d][4 * g + 1]);
+        w[1] = pack_bf16x2(dka[d][4 * g + 2], dka[d][4 * g + 3]);
+        *reinterpret_cast<u32x2_t*>(kp_o + d * 32 + g * 8 + hi * 4) = w;
+        w[0] = pack_bf16x2(dva[d][4 * g + 0], dva[d][4 * g + 1]);
+        w[1] = pack_bf16x2(dva[d][4 * g + 2], dva[d][4 * g + 3]);
+        *reinterpret_cast<u32x2_t*>(vp_o + d * 32 + g * 8 + hi * 4) = w;
+      }
+  }
+}
+
+int64_t attn_bwd_ws_bytes(int B, int H, int S) {
+  const int64_t S_pad = attn_spad(S);
+  return 3 * (int64_t)B * H * HD * S_pad * 2 + (int64_t)B * H * S_pad * 4;
+}
+
+hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
+                                     int64_t ldv, const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo,
+                                     const float* lse, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk,
+                                     uint16_t* dv, int64_t lddv, void* ws, int B, int H, int S, hipStream_t stream) {
+  const int S_pad = (int)attn_spad(S);
+  const int64_t tsz = (int64_t)B * H * HD * S_pad;
+  uint16_t* kt = (uint16_t*)ws;
+  uint16_t* qt = kt + tsz;
+  uint16_t* dot = qt + tsz;
+  float* delta = (float*)(dot + tsz);
+  hipError_t e;
+  if ((e = hipMemsetAsync(delta, 0, (size_t)B * H * S_pad * 4, stream)) != hipSuccess) return e;
+  if ((e = launch_v_transpose(k, ldk, kt, B, H, S, stream)) != hipSuccess) return e;
+  if ((e = launch_v_transpose(q, ldq, qt, B, H, S, stream)) != hipSuccess) return e;
+  if ((e = launch_v_transpose(dout, lddo, dot, B, H, S, stream)) != hipSuccess) return e;
+  const int64_t total = (int64_t)B * S * H * 16;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, o, ldo, dout, lddo,
+                     delta, H, S, S_pad, total);
+  static bool attr = false;
+  if (!attr) {
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 2 * DQ_STAGE)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 2 * DKV_STAGE)) != hipSuccess) return e;
+    attr = true;
+  }
+  const int hpx = (H + 7) / 8;
+  const int nq = (S + DQ_WAVES * 32 - 1) / (DQ_WAVES * 32);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(8 * hpx * nq * B), dim3(DQ_THREADS), 2 * DQ_STAGE, stream, q, ldq, k, ldk, v,
+                     ldv, kt, dout, lddo, lse, delta, dq, lddq, H, S, S_pad, nq, B);
+  const int nk = (S + DKV_WAVES * 32 - 1) / (DKV_WAVES * 32);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(8 * hpx * nk * B), dim3(DKV_THREADS), 2 * DKV_STAGE, stream, q, ldq, k, ldk,
+                     v, ldv, qt, dout, lddo, dot, lse, delta, dk, lddk, dv, lddv, H, S, S_pad, nk, B);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -571,6 +571,34 @@ int afx_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, c
   return AFX_OK;
 }
 
+int64_t afx_attention_bwd_ws_bytes(int32_t batch, int32_t heads, int32_t S) {
+  if (batch < 1 || heads < 1 || S < 1) return fail(AFX_E_INVALID, "bad attention shape");
+  return attn_bwd_ws_bytes(batch, heads, S);
+}
+
+int afx_attention_fwd_lse_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                               int64_t ldo, float* lse, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream) {
+  if (!q || !k || !v || !o || !vt_ws || !lse) return fail(AFX_E_INVALID, "null argument to afx_attention_fwd_lse_bf16");
+  if (batch < 1 || heads < 1 || S < 1 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return fail(AFX_E_INVALID, "bad attention shape / stride");
+  HIP_TRY(launch_v_transpose((const uint16_t*)v, ldv, (uint16_t*)vt_ws, batch, heads, S, (hipStream_t)stream));
+  HIP_TRY(launch_attention((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)vt_ws, (uint16_t*)o, ldo,
+                           batch, heads, S, (hipStream_t)stream, lse));
+  return AFX_OK;
+}
+
+int afx_attention_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                           int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk,
+                           int64_t lddk, void* dv, int64_t lddv, void* ws, int32_t batch, int32_t heads, int32_t S,
+                           void* stream) {
+  if (!q || !k || !v || !o || !dout || !lse || !dq || !dk || !dv || !ws) return fail(AFX_E_INVALID, "null argument to afx_attention_bwd_bf16");
+  if (batch < 1 || heads < 1 || S < 1 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || lddo % 8 || lddq % 4 || lddk % 4 || lddv % 4)
+    return fail(AFX_E_INVALID, "bad attention backward shape / stride");
+  HIP_TRY(launch_attention_backward((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv,
+                                    (const uint16_t*)o, ldo, (const uint16_t*)dout, lddo, lse, (uint16_t*)dq, lddq,
+                                    (uint16_t*)dk, lddk, (uint16_t*)dv, lddv, ws, batch, heads, S, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int afx_norm_modulate_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows, int32_t D,
                            const float* scale, const float* shift, int64_t ldmod, int32_t rows_per_batch, int32_t rms,
                            void* stream) {

@@ -38,7 +38,13 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
                               hipStream_t stream);
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream);
+                            hipStream_t stream, float* lse = nullptr);
+// backward: see afx_attn_bwd.hip.  ws layout: Kt | Qt | dOt (each B*H*128*S_pad bf16) | delta (B*H*S_pad f32)
+int64_t attn_bwd_ws_bytes(int B, int H, int S);
+hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
+                                     int64_t ldv, const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo,
+                                     const float* lse, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk,
+                                     uint16_t* dv, int64_t lddv, void* ws, int B, int H, int S, hipStream_t stream);
 inline int64_t attn_spad(int S) { return ((int64_t)S + 63) / 64 * 64; }
 
 // ---- element-wise / reductions -----------------------------------------------------------------

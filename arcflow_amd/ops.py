@@ -300,3 +300,33 @@ def cast_bf16(x, out=None):
         out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     _lib.check(lib.afx_cast_f32_bf16(_p(x), _p(out), x.numel(), _s()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# attention with gradient
+def attention_fwd_lse(q, k, v):
+    """q,k,v [B,S,H,128] bf16 -> (o [B,S,H*128] bf16, lse [B,H,S_pad] f32)."""
+    lib = _lib.load()
+    B, S, H, Dh = q.shape
+    q2, k2, v2 = (t.reshape(B * S, H * Dh) for t in (q.contiguous(), k.contiguous(), v.contiguous()))
+    o = torch.empty(B * S, H * Dh, dtype=torch.bfloat16, device=q.device)
+    S_pad = (S + 63) // 64 * 64
+    lse = torch.full((B, H, S_pad), float('inf'), dtype=torch.float32, device=q.device)
+    ws = torch.empty(lib.afx_attention_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.afx_attention_fwd_lse_bf16(_p(q2), H * Dh, _p(k2), H * Dh, _p(v2), H * Dh, _p(o), H * Dh, _p(lse), _p(ws),
+                                              B, H, S, _s()))
+    return o.reshape(B, S, H * Dh), lse
+
+
+def attention_bwd(q, k, v, o, dout, lse):
+    """-> (dq, dk, dv) each [B,S,H,128] bf16."""
+    lib = _lib.load()
+    B, S, H, Dh = q.shape
+    flat = lambda t: t.contiguous().reshape(B * S, H * Dh)   # noqa: E731
+    q2, k2, v2, o2, do2 = flat(q), flat(k), flat(v), flat(o), flat(dout)
+    dq, dk, dv = (torch.empty(B * S, H * Dh, dtype=torch.bfloat16, device=q.device) for _ in range(3))
+    ws = torch.empty(lib.afx_attention_bwd_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    ld = H * Dh
+    _lib.check(lib.afx_attention_bwd_bf16(_p(q2), ld, _p(k2), ld, _p(v2), ld, _p(o2), ld, _p(do2), ld, _p(lse), _p(dq), ld,
+                                          _p(dk), ld, _p(dv), ld, _p(ws), B, H, S, _s()))
+    return tuple(t.reshape(B, S, H, Dh) for t in (dq, dk, dv))

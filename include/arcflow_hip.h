@@ -216,6 +216,17 @@ int afx_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        int64_t ldv, void* o, int64_t ldo, void* vt_ws,
                        int32_t batch, int32_t heads, int32_t S, void* stream);
 
+/* Training twins: forward that also returns lse [B, H, roundup(S,64)] f32 (log2-domain log-sum-exp of the scaled
+ * scores; the caller pre-fills it with +inf so padded queries drop out), and the backward producing dq, dk, dv
+ * (same row/head addressing as q, k, v) from o, dout and lse.  ws: afx_attention_bwd_ws_bytes() bytes. */
+int afx_attention_fwd_lse_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
+                               int64_t ldo, float* lse, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream);
+int64_t afx_attention_bwd_ws_bytes(int32_t batch, int32_t heads, int32_t S);
+int afx_attention_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
+                           int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk,
+                           int64_t lddk, void* dv, int64_t lddv, void* ws, int32_t batch, int32_t heads, int32_t S,
+                           void* stream);
+
 /* out = LayerNorm(x, eps=1e-6, no affine) * (1 + scale[b]) + shift[b]   (AdaLN modulate), or with
  * rms != 0: out = x * rsqrt(mean(x^2) + 1e-6) * w  (scale = w as f32[D], shift ignored). */
 int afx_norm_modulate_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int32_t rows,

@@ -164,3 +164,26 @@ def test_adamw_ema_sumsq_cast(ops):
     acc = ops.sumsq(p, torch.zeros(1, device='cuda'))
     close(acc[0], (p.cpu().double() ** 2).sum().float(), rtol=1e-4, atol=1e-2)
     close(ops.cast_bf16(p).float(), p.cpu().bfloat16().float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2)])
+def test_attention_backward(ops, B, S, H):
+    g = torch.Generator().manual_seed(S + 1)
+    q, k, v, do = (torch.randn(B, S, H, 128, generator=g).bfloat16() for _ in range(4))
+    qr, kr, vr = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = torch.nn.functional.scaled_dot_product_attention(qr.transpose(1, 2), kr.transpose(1, 2), vr.transpose(1, 2)).transpose(1, 2)
+    (ref * do.float()).sum().backward()
+    o, lse = ops.attention_fwd_lse(q.cuda(), k.cuda(), v.cuda())
+    o_plain = ops.attention(q.cuda(), k.cuda(), v.cuda())
+    assert torch.equal(o, o_plain)                                  # the LSE side output does not perturb O
+    # lse is the log2-domain log-sum-exp of the scaled scores
+    s = torch.einsum('bqhd,bkhd->bhqk', q.float(), k.float()) / 128 ** 0.5
+    ref_lse = torch.logsumexp(s, dim=-1) / np.log(2.0)
+    assert torch.allclose(lse[:, :, :S].cpu(), ref_lse, atol=2e-2)
+    dq, dk, dv = ops.attention_bwd(q.cuda(), k.cuda(), v.cuda(), o.reshape(B, S, H, 128), do.cuda(), lse)
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / b.norm()).item()
+    assert rel(dv, vr.grad) < 1.5e-2, rel(dv, vr.grad)
+    assert rel(dq, qr.grad) < 2e-2, rel(dq, qr.grad)
+    assert rel(dk, kr.grad) < 2e-2, rel(dk, kr.grad)
