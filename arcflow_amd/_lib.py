@@ -20,6 +20,7 @@ EXPORTS = [
     'afx_arcflow_velocity', 'afx_linear_bf16', 'afx_attention_ws_bytes', 'afx_attention_bf16',
     'afx_norm_modulate_bf16', 'afx_qk_norm_rope_bf16', 'afx_gemv_bf16',
     'afx_attention_fwd_lse_bf16', 'afx_attention_bwd_ws_bytes', 'afx_attention_bwd_bf16',
+    'afx_ln_modulate_backward', 'afx_qk_norm_rope_oop_bf16', 'afx_gelu_bf16', 'afx_add_scale_bf16',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
     'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward',
     'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
@@ -76,6 +77,10 @@ def load() -> C.CDLL:
     lib.afx_attention_bwd_ws_bytes.argtypes = [i32, i32, i32]
     lib.afx_attention_bwd_ws_bytes.restype = i64
     lib.afx_attention_bwd_bf16.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.afx_ln_modulate_backward.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, i32, i32, vp]
+    lib.afx_qk_norm_rope_oop_bf16.argtypes = [vp, i64, vp, i64, vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]
+    lib.afx_gelu_bf16.argtypes = [vp, i64, vp, i64, vp, i64, i64, i32, vp]
+    lib.afx_add_scale_bf16.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, i64, i64, i32, vp]
     lib.afx_arcflow_step_dropout.argtypes = [vp, vp, vp, vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, vp]
     lib.afx_arcflow_backward.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, vp, f32, f32, vp, vp, vp, i32, i32, i32,
                                          i32, i32, i32, i32, vp]

@@ -520,3 +520,248 @@ int afx_cfg_combine(const float* pos, const float* neg, float scale, float* out,
 }
 
 }  // extern "C"
+
+// ====================================================================================================
+// Element-wise backward kernels of the MMDiT trunk (used by arcflow_amd/train/trunk.py)
+namespace afx {
+
+// dx = dres + LN-backward(dxn * (1 + scale[b]))   for xn = LN(x) (1 + scale) + shift, LN without affine, eps 1e-6
+//   y = (x - mu) rstd ; g = dxn (1 + scale) ; dx = rstd (g - mean(g) - y mean(g y))
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                         const bf16_t* __restrict__ dxn, int64_t ldd,
+                                                         const float* __restrict__ scale, int64_t ldmod, int rows_per_batch,
+                                                         const bf16_t* __restrict__ dres, int64_t ldr,
+                                                         bf16_t* __restrict__ dx, int64_t ldo, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = D >> 3;
+  const float* sc = scale + (int64_t)(row / rows_per_batch) * ldmod;
+  float v[8][8], gq[8][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + (int64_t)row * ldx + c * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] -= mean;
+        q += v[i][e] * v[i][e];
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+  float sg = 0.f, sgy = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float d[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(dxn + (int64_t)row * ldd + c * 8), d);
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sc + c * 8);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(sc + c * 8 + 4);
+      const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] *= rstd;                       // y
+        gq[i][e] = d[e] * (1.0f + sv[e]);      // g
+        sg += gq[i][e];
+        sgy += gq[i][e] * v[i][e];
+      }
+    }
+  }
+  const float mg = wave_sum(sg) / (float)D, mgy = wave_sum(sgy) / (float)D;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = lane + i * 64;
+    if (c < nchunk) {
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = rstd * (gq[i][e] - mg - v[i][e] * mgy);
+      if (dres != nullptr) {
+        float a[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(dres + (int64_t)row * ldr + c * 8), a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] += a[e];
+      }
+      *reinterpret_cast<u32x4_t*>(dx + (int64_t)row * ldo + c * 8) = pack8(r);
+    }
+  }
+}
+
+// Out-of-place per-head RMSNorm + RoPE (forward, keeps the pre-norm projection for the backward) and its backward:
+//   y = R(s) (x rstd w);   dz = R(s)^T dy;  xh = x rstd;  g = dz w;  dx = rstd (g - xh mean(g xh))
+__global__ __launch_bounds__(256) void qk_norm_rope_oop_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y,
+                                                               int64_t ldy, const bf16_t* __restrict__ dy, int64_t lddy,
+                                                               const float* __restrict__ w_txt, const float* __restrict__ w_img,
+                                                               const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                                               int S, int n_txt, int H, int64_t total, int backward) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int c = (int)(g & 15);
+  const int64_t th = g >> 4;
+  const int h = (int)(th % H);
+  const int64_t row = th / H;
+  const int s = (int)(row % S);
+  float v[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(x + row * ldx + h * 128 + c * 8), v);
+  float ss = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+  const float* w = (s < n_txt ? w_txt : w_img) + c * 8;
+  const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(w);
+  const f32x4_t w1 = *reinterpret_cast<const f32x4_t*>(w + 4);
+  const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
+  const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cos_t + (int64_t)s * 64 + c * 4);
+  const f32x4_t sn = *reinterpret_cast<const f32x4_t*>(sin_t + (int64_t)s * 64 + c * 4);
+  float r[8];
+  if (!backward) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float a = v[2 * i] * rstd * wv[2 * i];
+      const float b = v[2 * i + 1] * rstd * wv[2 * i + 1];
+      r[2 * i] = a * cs[i] - b * sn[i];
+      r[2 * i + 1] = a * sn[i] + b * cs[i];
+    }
+  } else {
+    float d[8], gg[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(dy + row * lddy + h * 128 + c * 8), d);
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float ze = d[2 * i] * cs[i] + d[2 * i + 1] * sn[i];
+      const float zo = -d[2 * i] * sn[i] + d[2 * i + 1] * cs[i];
+      gg[2 * i] = ze * wv[2 * i];
+      gg[2 * i + 1] = zo * wv[2 * i + 1];
+      dot += gg[2 * i] * v[2 * i] * rstd + gg[2 * i + 1] * v[2 * i + 1] * rstd;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 64);
+    dot *= (1.0f / 128.0f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = rstd * (gg[e] - v[e] * rstd * dot);
+  }
+  *reinterpret_cast<u32x4_t*>(y + row * ldy + h * 128 + c * 8) = pack8(r);
+}
+
+// h = gelu_tanh(pre)   /   dpre = dh * gelu_tanh'(pre)      (bf16, strided rows)
+__global__ __launch_bounds__(256) void gelu_kernel(const bf16_t* __restrict__ pre, int64_t ldp, const bf16_t* __restrict__ dh,
+                                                   int64_t ldh, bf16_t* __restrict__ out, int64_t ldo, int64_t rows, int cols) {
+  const int cpr = cols >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= rows * cpr) return;
+  const int64_t r = g / cpr;
+  const int c = (int)(g % cpr);
+  float x[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(pre + r * ldp + c * 8), x);
+  if (dh == nullptr) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = gelu_tanh(x[e]);
+  } else {
+    float d[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(dh + r * ldh + c * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float u = 0.7978845608028654f * (x[e] + 0.044715f * x[e] * x[e] * x[e]);
+      const float t = 1.0f - 2.0f / (__expf(2.0f * u) + 1.0f);
+      const float du = 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * x[e] * x[e]);
+      o[e] = d[e] * (0.5f * (1.0f + t) + 0.5f * x[e] * (1.0f - t * t) * du);
+    }
+  }
+  *reinterpret_cast<u32x4_t*>(out + r * ldo + c * 8) = pack8(o);
+}
+
+// out[r, c] = (a[r, c] (+ b[r, c])) * gate[batch(r), c]     gate == nullptr -> 1       (bf16 rows; residual-grad plumbing)
+__global__ __launch_bounds__(256) void addscale_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b,
+                                                       int64_t ldb, const float* __restrict__ gate, int64_t ldg,
+                                                       int rows_per_batch, bf16_t* __restrict__ out, int64_t ldo,
+                                                       int64_t rows, int cols) {
+  const int cpr = cols >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= rows * cpr) return;
+  const int64_t r = g / cpr;
+  const int c = (int)(g % cpr);
+  float x[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(a + r * lda + c * 8), x);
+  if (b != nullptr) {
+    float y[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(b + r * ldb + c * 8), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] += y[e];
+  }
+  if (gate != nullptr) {
+    const float* gp = gate + (r / rows_per_batch) * ldg + c * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] *= gp[e];
+  }
+  *reinterpret_cast<u32x4_t*>(out + r * ldo + c * 8) = pack8(x);
+}
+
+}  // namespace afx
+
+extern "C" {
+
+int afx_ln_modulate_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, const float* scale, int64_t ldmod,
+                             int32_t rows_per_batch, const void* dres, int64_t ldr, void* dx, int64_t ldo, int32_t rows,
+                             int32_t D, void* stream) {
+  if (!x || !dxn || !scale || !dx || rows < 0 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1)
+    return fail(AFX_E_INVALID, "bad argument to afx_ln_modulate_backward");
+  if (rows == 0) return AFX_OK;
+  hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (const bf16_t*)dxn, ldd, scale, ldmod, rows_per_batch, (const bf16_t*)dres, ldr, (bf16_t*)dx, ldo, rows, D);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_qk_norm_rope_oop_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const void* dy, int64_t lddy,
+                              const float* w_txt, const float* w_img, const float* rope_cos, const float* rope_sin,
+                              int32_t batch, int32_t S, int32_t n_txt, int32_t heads, int32_t backward, void* stream) {
+  if (!x || !y || !w_txt || !w_img || !rope_cos || !rope_sin || (backward && !dy))
+    return fail(AFX_E_INVALID, "null argument to afx_qk_norm_rope_oop_bf16");
+  const int64_t total = (int64_t)batch * S * heads * 16;
+  if (total <= 0) return fail(AFX_E_INVALID, "bad qk_norm_rope shape");
+  hipLaunchKernelGGL(qk_norm_rope_oop_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (const bf16_t*)dy, lddy, w_txt, w_img, rope_cos, rope_sin, S,
+                     n_txt, heads, total, backward);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_gelu_bf16(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* out, int64_t ldo, int64_t rows,
+                  int32_t cols, void* stream) {
+  if (!pre || !out || rows < 0 || cols < 8 || cols % 8) return fail(AFX_E_INVALID, "bad argument to afx_gelu_bf16");
+  const int64_t n = rows * (cols >> 3);
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(gelu_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)pre, ldp,
+                     (const bf16_t*)dh, ldh, (bf16_t*)out, ldo, rows, cols);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_add_scale_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* gate, int64_t ldg,
+                       int32_t rows_per_batch, void* out, int64_t ldo, int64_t rows, int32_t cols, void* stream) {
+  if (!a || !out || rows < 0 || cols < 8 || cols % 8 || (gate && rows_per_batch < 1))
+    return fail(AFX_E_INVALID, "bad argument to afx_add_scale_bf16");
+  const int64_t n = rows * (cols >> 3);
+  if (n == 0) return AFX_OK;
+  hipLaunchKernelGGL(addscale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                     (const bf16_t*)b, ldb, gate, ldg, rows_per_batch > 0 ? rows_per_batch : 1, (bf16_t*)out, ldo, rows, cols);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+}  // extern "C"

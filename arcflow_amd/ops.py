@@ -330,3 +330,62 @@ def attention_bwd(q, k, v, o, dout, lse):
     _lib.check(lib.afx_attention_bwd_bf16(_p(q2), ld, _p(k2), ld, _p(v2), ld, _p(o2), ld, _p(do2), ld, _p(lse), _p(dq), ld,
                                           _p(dk), ld, _p(dv), ld, _p(ws), B, H, S, _s()))
     return tuple(t.reshape(B, S, H, Dh) for t in (dq, dk, dv))
+
+
+# ---------------------------------------------------------------------------------------------------
+# element-wise trunk backward
+def ln_modulate_backward(x, dxn, scale, rows_per_batch: int = 0, dres=None, out=None):
+    """dx = dres + LN^T(dxn * (1 + scale[b])); x, dxn [R,D] bf16 (row-strided views allowed), scale [B,D] f32."""
+    lib = _lib.load()
+    R, D = x.shape
+    if out is None:
+        out = torch.empty(R, D, dtype=torch.bfloat16, device=x.device)
+    scale = _cuda(scale, torch.float32)
+    if scale.dim() == 1:
+        scale = scale[None]
+    _lib.check(lib.afx_ln_modulate_backward(_p(x), x.stride(0), _p(dxn), dxn.stride(0), _p(scale), scale.stride(0),
+                                            rows_per_batch if rows_per_batch > 0 else max(R, 1), _p(dres),
+                                            0 if dres is None else dres.stride(0), _p(out), out.stride(0), R, D, _s()))
+    return out
+
+
+def qk_norm_rope(x, w_txt, w_img, cos, sin, n_txt: int, out=None, dy=None):
+    """Out-of-place per-head RMSNorm + RoPE on x [B,S,H*128 view with row stride]; with dy: the backward (dx)."""
+    lib = _lib.load()
+    B, S, HD = x.shape
+    H = HD // 128
+    x2 = x.reshape(B * S, HD) if x.is_contiguous() else x.view(B * S, HD)
+    if out is None:
+        out = torch.empty(B * S, HD, dtype=torch.bfloat16, device=x.device)
+    dy2 = None if dy is None else dy.view(B * S, HD)
+    _lib.check(lib.afx_qk_norm_rope_oop_bf16(_p(x2), x2.stride(0), _p(out), out.stride(0), _p(dy2),
+                                             0 if dy2 is None else dy2.stride(0), _p(_cuda(w_txt, torch.float32)),
+                                             _p(_cuda(w_img, torch.float32)), _p(cos), _p(sin), B, S, n_txt, H,
+                                             int(dy is not None), _s()))
+    return out.view(B, S, HD)
+
+
+def gelu(pre, dh=None, out=None):
+    """h = gelu_tanh(pre) or, with dh, dpre = dh * gelu'(pre); [R,C] bf16 row-strided views."""
+    lib = _lib.load()
+    R, Cc = pre.shape
+    if out is None:
+        out = torch.empty(R, Cc, dtype=torch.bfloat16, device=pre.device)
+    _lib.check(lib.afx_gelu_bf16(_p(pre), pre.stride(0), _p(dh), 0 if dh is None else dh.stride(0), _p(out), out.stride(0), R, Cc, _s()))
+    return out
+
+
+def add_scale(a, b=None, gate=None, rows_per_batch: int = 0, out=None):
+    """out = (a (+ b)) * gate[batch]; a, b [R,C] bf16 row-strided, gate [B,C] f32."""
+    lib = _lib.load()
+    R, Cc = a.shape
+    if out is None:
+        out = torch.empty(R, Cc, dtype=torch.bfloat16, device=a.device)
+    if gate is not None:
+        gate = _cuda(gate, torch.float32)
+        if gate.dim() == 1:
+            gate = gate[None]
+    _lib.check(lib.afx_add_scale_bf16(_p(a), a.stride(0), _p(b), 0 if b is None else b.stride(0), _p(gate),
+                                      0 if gate is None else gate.stride(0), rows_per_batch if rows_per_batch > 0 else max(R, 1),
+                                      _p(out), out.stride(0), R, Cc, _s()))
+    return out

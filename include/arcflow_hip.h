@@ -189,6 +189,20 @@ int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t 
 int afx_mmdit_export(afx_ctx* ctx, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt,
                      void* stream);
 
+/* Element-wise backward kernels of the trunk (gradient checkpointed block recompute + backward):
+ * dx = dres + LN^T(dxn (1+scale));  out-of-place RMSNorm+RoPE forward (backward = 0) / backward (dy -> dx, written
+ * to y);  GELU(tanh) forward (dh == NULL) / backward;  out = (a (+ b)) * gate[batch] residual-gradient plumbing. */
+int afx_ln_modulate_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, const float* scale, int64_t ldmod,
+                             int32_t rows_per_batch, const void* dres, int64_t ldr, void* dx, int64_t ldo, int32_t rows,
+                             int32_t D, void* stream);
+int afx_qk_norm_rope_oop_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, const void* dy, int64_t lddy,
+                              const float* w_txt, const float* w_img, const float* rope_cos, const float* rope_sin,
+                              int32_t batch, int32_t S, int32_t n_txt, int32_t heads, int32_t backward, void* stream);
+int afx_gelu_bf16(const void* pre, int64_t ldp, const void* dh, int64_t ldh, void* out, int64_t ldo, int64_t rows,
+                  int32_t cols, void* stream);
+int afx_add_scale_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, const float* gate, int64_t ldg,
+                       int32_t rows_per_batch, void* out, int64_t ldo, int64_t rows, int32_t cols, void* stream);
+
 /* Optimiser step of lakonlab/models/base.py:76-103 + ema_hook.py:86-124 on flat fp32 buffers:
  * global grad-norm (afx_sumsq accumulates sum of squares), AdamW with decoupled decay (grad_scale folds
  * 1/world and the clip factor; step >= 1 for bias correction), Karras EMA  ema = net + (ema - net) * beta. */

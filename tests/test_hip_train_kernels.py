@@ -187,3 +187,49 @@ def test_attention_backward(ops, B, S, H):
     assert rel(dv, vr.grad) < 1.5e-2, rel(dv, vr.grad)
     assert rel(dq, qr.grad) < 2e-2, rel(dq, qr.grad)
     assert rel(dk, kr.grad) < 2e-2, rel(dk, kr.grad)
+
+
+def test_elementwise_backward_kernels(ops):
+    from oracle import dit_ref as D
+    g = torch.Generator().manual_seed(9)
+    B, S, Dm = 2, 37, 512
+    x = (torch.randn(B * S, Dm, generator=g) * 1.5 + 0.2).bfloat16()
+    dxn = torch.randn(B * S, Dm, generator=g).bfloat16()
+    dres = torch.randn(B * S, Dm, generator=g).bfloat16()
+    sc = torch.randn(B, Dm, generator=g)
+    xr = x.float().clone().requires_grad_(True)
+    xn = torch.nn.functional.layer_norm(xr, (Dm,), eps=1e-6).reshape(B, S, Dm) * (1 + sc[:, None])
+    (xn * dxn.float().reshape(B, S, Dm)).sum().backward()
+    out = ops.ln_modulate_backward(x.cuda(), dxn.cuda(), sc.cuda(), S, dres=dres.cuda())
+    ref = xr.grad + dres.float()
+    assert ((out.float().cpu() - ref).norm() / ref.norm()).item() < 6e-3
+    # RMSNorm + RoPE out-of-place forward == in-place kernel, backward vs autograd
+    hp, wp, T, H = 4, 5, 6, 2
+    S2 = T + hp * wp
+    q = torch.randn(B, S2, H * 128, generator=g).bfloat16()
+    dy = torch.randn(B, S2, H * 128, generator=g).bfloat16()
+    wt, wi = 1 + 0.1 * torch.randn(128, generator=g), 1 + 0.1 * torch.randn(128, generator=g)
+    cos, sin = D.flux_rope_tables(hp, wp, T)
+    y = ops.qk_norm_rope(q.cuda(), wt.cuda(), wi.cuda(), cos.cuda(), sin.cuda(), T)
+    y_ip = ops.qk_norm_rope_(q.cuda().reshape(B, S2, H, 128).clone(), wt.cuda(), wi.cuda(), cos.cuda(), sin.cuda(), T)
+    assert torch.equal(y.reshape(B, S2, H, 128), y_ip)
+    qr = q.float().clone().requires_grad_(True)
+    q4 = qr.reshape(B, S2, H, 128)
+    yr = torch.cat([D.apply_rope(D.rms_norm(q4[:, :T], wt), cos[:T], sin[:T]),
+                    D.apply_rope(D.rms_norm(q4[:, T:], wi), cos[T:], sin[T:])], dim=1)
+    (yr * dy.float().reshape(B, S2, H, 128)).sum().backward()
+    dq = ops.qk_norm_rope(q.cuda(), wt.cuda(), wi.cuda(), cos.cuda(), sin.cuda(), T, dy=dy.cuda())
+    assert ((dq.float().cpu() - qr.grad).norm() / qr.grad.norm()).item() < 6e-3
+    # GELU forward / backward, add_scale
+    pre = (torch.randn(50, 256, generator=g) * 2).bfloat16()
+    dh = torch.randn(50, 256, generator=g).bfloat16()
+    pr = pre.float().clone().requires_grad_(True)
+    hr = torch.nn.functional.gelu(pr, approximate='tanh')
+    (hr * dh.float()).sum().backward()
+    assert ((ops.gelu(pre.cuda()).float().cpu() - hr.detach()).abs().max().item()) < 2e-2
+    dpre = ops.gelu(pre.cuda(), dh=dh.cuda())
+    assert ((dpre.float().cpu() - pr.grad).norm() / pr.grad.norm()).item() < 6e-3
+    gate = torch.randn(2, 256, generator=g)
+    out = ops.add_scale(pre.cuda(), dh.cuda(), gate.cuda(), rows_per_batch=25)
+    ref = (pre.float() + dh.float()) * gate.repeat_interleave(25, 0)
+    assert ((out.float().cpu() - ref).norm() / ref.norm()).item() < 6e-3
