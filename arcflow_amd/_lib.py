@@ -16,7 +16,7 @@ AFX_DT_F32 = 2
 
 EXPORTS = [
     'afx_last_error', 'afx_version', 'afx_create', 'afx_destroy', 'afx_bind_weight', 'afx_finalize',
-    'afx_workspace_bytes', 'afx_set_workspace', 'afx_mmdit_forward', 'afx_profile_enable', 'afx_profile_read', 'afx_arcflow_step',
+    'afx_workspace_bytes', 'afx_set_workspace', 'afx_mmdit_forward', 'afx_profile_enable', 'afx_profile_read', 'afx_set_checkpoint_buffer', 'afx_arcflow_step',
     'afx_arcflow_velocity', 'afx_linear_bf16', 'afx_attention_ws_bytes', 'afx_attention_bf16',
     'afx_norm_modulate_bf16', 'afx_qk_norm_rope_bf16', 'afx_gemv_bf16',
     'afx_attention_fwd_lse_bf16', 'afx_attention_bwd_ws_bytes', 'afx_attention_bwd_bf16',
@@ -62,6 +62,7 @@ def load() -> C.CDLL:
     lib.afx_workspace_bytes.restype = i64
     lib.afx_set_workspace.argtypes = [vp, vp, i64]
     lib.afx_mmdit_forward.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]
+    lib.afx_set_checkpoint_buffer.argtypes = [vp, vp]
     lib.afx_profile_enable.argtypes = [vp, i32]
     lib.afx_profile_read.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double)]
     lib.afx_arcflow_step.argtypes = [vp, vp, vp, vp, i32, f32, f32, f32, vp, f32, vp, i32, i32, i32, i32, i32, vp]

@@ -56,6 +56,7 @@ struct afx_ctx {
   int D = 0;
   int64_t n_mod = 0;       // rows of the stacked modulation linear
   int head_n = 0;          // padded head width
+  uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
   // optional per-launch-class timing (HIP events on the forward's stream)
   bool prof_on = false;
   struct ProfRec { hipEvent_t a, b; int klass; double flops; };
@@ -372,6 +373,7 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   for (int i = 0; i < d.num_double; ++i) {
     const std::string p = "d" + std::to_string(i) + ".";
     const float* qkn = W32(c, p + "qknorm");   // [img_q, img_k, txt_q, txt_k][128]
+    if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     if ((rc = stream_norm(i, 0, 1))) return rc;
     if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "qkv", QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
     HIP_TRY(launch_qk_norm_rope(QKV, 3 * D, qkn + 3 * 128, qkn + 1 * 128, rope_cos, rope_sin, B, S, T, H, st));            // k
@@ -388,6 +390,8 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   for (int i = 0; i < d.num_single; ++i) {
     const std::string p = "s" + std::to_string(i) + ".";
     const float* qkn = W32(c, p + "qknorm");   // [q, k][128]
+    if (c->ckpt)
+      HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)(d.num_double + i) * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
     GemmBatch gb{};
     gb.nprob = 1;
@@ -432,6 +436,12 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   if (d.head_mode == 0)
     HIP_TRY(launch_head_split(ws.head, c->head_n, (uint16_t*)means, (uint16_t*)logw, (uint16_t*)logg, (int64_t)B * N,
                               d.num_gaussians, d.in_channels, d.logweights_channels, st));
+  return AFX_OK;
+}
+
+int afx_set_checkpoint_buffer(afx_ctx* ctx, void* dptr) {
+  if (!ctx) return fail(AFX_E_INVALID, "null ctx");
+  ctx->ckpt = (uint16_t*)dptr;     // nullptr switches checkpointing off
   return AFX_OK;
 }
 
@@ -513,6 +523,8 @@ int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int
                              (size_t)n_img * D * 2, hipMemcpyDeviceToDevice, st));
   } else if (w == "silu_temb") {   // [B, D] f32
     HIP_TRY(hipMemcpyAsync(dst, ws.semb, (size_t)batch * D * 4, hipMemcpyDeviceToDevice, st));
+  } else if (w == "mod_all") {     // [B, n_mod] f32: every AdaLN modulation vector of the network
+    HIP_TRY(hipMemcpyAsync(dst, ws.mod, (size_t)batch * c->n_mod * 4, hipMemcpyDeviceToDevice, st));
   } else if (w == "mod_final") {   // [B, 2D] f32: (scale | shift) of norm_out
     for (int b = 0; b < batch; ++b)
       HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)b * 2 * D * 4, ws.mod + (int64_t)b * c->n_mod + ml.fin(0), (size_t)2 * D * 4,

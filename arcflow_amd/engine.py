@@ -129,6 +129,15 @@ class MMDiTEngine:
         _lib.check(self.lib.afx_mmdit_export(self._ctx, what.encode(), _ptr(dst), B, N, T, _stream()))
         return dst
 
+    def set_checkpoint_buffer(self, buf: Optional[torch.Tensor]) -> None:
+        """[num_blocks, B*S, D] bf16 tensor that receives every block's input on the next forwards (None = off)."""
+        self._ckpt = buf
+        _lib.check(self.lib.afx_set_checkpoint_buffer(self._ctx, _ptr(buf)))
+
+    @property
+    def n_mod(self) -> int:
+        return (self.num_double * 12 + self.num_single * 3 + 2) * self.dim
+
     # ------------------------------------------------------------------ instrumentation
     def profile(self, on: bool) -> None:
         _lib.check(self.lib.afx_profile_enable(self._ctx, int(on)))

@@ -63,12 +63,13 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor
 
 
 def norm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: Optional[torch.Tensor], rows_per_batch: int = 0,
-                  rms: bool = False) -> torch.Tensor:
+                  rms: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [R,D] bf16; AdaLN: scale/shift [B,D] f32 (row r uses batch r // rows_per_batch);
     rms=True: x * rsqrt(mean x^2 + 1e-6) * scale[D]."""
     lib = _lib.load()
     R, D = x.shape
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty(R, D, dtype=torch.bfloat16, device=x.device)
     scale = _cuda(scale, torch.float32)
     shift = None if shift is None else _cuda(shift, torch.float32)
     ldm = 0 if rms or scale.dim() == 1 else scale.stride(0)
@@ -249,11 +250,13 @@ def linear_f32out(a, w, out=None, accumulate: bool = False):
     return out
 
 
-def transpose(x):
+def transpose(x, pad_to: int = 1):
+    """[R,C] bf16 (row-strided view allowed) -> [C, roundup(R, pad_to)], zero padded."""
     lib = _lib.load()
     R, Cc = x.shape
-    y = torch.empty(Cc, R, dtype=torch.bfloat16, device=x.device)
-    _lib.check(lib.afx_transpose_bf16(_p(x), x.stride(0), _p(y), R, R, Cc, _s()))
+    Rp = (R + pad_to - 1) // pad_to * pad_to
+    y = (torch.zeros if Rp != R else torch.empty)(Cc, Rp, dtype=torch.bfloat16, device=x.device)
+    _lib.check(lib.afx_transpose_bf16(_p(x), x.stride(0), _p(y), Rp, R, Cc, _s()))
     return y
 
 
@@ -389,3 +392,22 @@ def add_scale(a, b=None, gate=None, rows_per_batch: int = 0, out=None):
                                       0 if gate is None else gate.stride(0), rows_per_batch if rows_per_batch > 0 else max(R, 1),
                                       _p(out), out.stride(0), R, Cc, _s()))
     return out
+
+
+def attention_fwd_lse_2d(q, k, v, o, B: int, S: int, H: int):
+    """Strided form: q, k, v, o are [B*S, H*128] views (row stride = their stride(0)); returns lse [B,H,S_pad]."""
+    lib = _lib.load()
+    S_pad = (S + 63) // 64 * 64
+    lse = torch.full((B, H, S_pad), float('inf'), dtype=torch.float32, device=q.device)
+    ws = torch.empty(lib.afx_attention_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.afx_attention_fwd_lse_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                              _p(lse), _p(ws), B, H, S, _s()))
+    return lse
+
+
+def attention_bwd_2d(q, k, v, o, dout, lse, dq, dk, dv, B: int, S: int, H: int):
+    lib = _lib.load()
+    ws = torch.empty(lib.afx_attention_bwd_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.afx_attention_bwd_bf16(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(o), o.stride(0),
+                                          _p(dout), dout.stride(0), _p(lse), _p(dq), dq.stride(0), _p(dk), dk.stride(0),
+                                          _p(dv), dv.stride(0), _p(ws), B, H, S, _s()))

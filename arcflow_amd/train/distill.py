@@ -29,6 +29,7 @@ from .. import ops
 from ..engine import MMDiTEngine
 from ..weights import pack_flux, pack_head, pack_qwen
 from .reducer import GradReducer
+from .trunk import LoraTrunk
 
 
 @dataclass
@@ -56,6 +57,7 @@ class DistillConfig:
     grad_clip_begin_iter: int = 100
     ema_gamma: float = 7.0
     ema_start_iter: int = 100
+    lora_rank: int = 0                    # 0: train heads + norm_out only; 256 in the reference configs
 
 
 def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
@@ -100,7 +102,8 @@ class ArcFlowDistiller:
         self._off = [0]
         for s in sizes:
             self._off.append(self._off[-1] + s)
-        n = self._off[-1]
+        n_lora = LoraTrunk.num_params(family, nd, ns, D, cfg.lora_rank) if cfg.lora_rank > 0 else 0
+        n = self._off[-1] + n_lora
         self.params = torch.empty(n, dtype=torch.float32, device=self.device)
         self._view(self.params, 0).copy_(packed['head.weight'].float().flatten())
         self._view(self.params, 1).copy_(packed['head.bias'].float())
@@ -117,7 +120,13 @@ class ArcFlowDistiller:
         self.b_no = torch.empty(2 * D, dtype=torch.bfloat16, device=self.device)
         packed['mod_final.weight'], packed['mod_final.bias'] = self.w_no, self.b_no
         self._sync_working_copies()
+        self.trunk = None
+        if cfg.lora_rank > 0:      # adapted weights get private merged copies inside `packed` (teacher keeps the frozen ones)
+            self.trunk = LoraTrunk(self.student, packed, cfg.lora_rank, self.params, self._off[4],
+                                   generator=torch.Generator(device=self.device).manual_seed(1234))
+            self.ema[self._off[4]:].copy_(self.params[self._off[4]:])
         self.student.bind_packed(packed)
+        self._ckpt = None
         self.reducer = GradReducer(process_group)
         self.iteration = 0
         self.opt_steps = 0
@@ -177,15 +186,26 @@ class ArcFlowDistiller:
         dev = self.device
         K, pp = self.K, self.L
         sigma_src = warp(raw_src, c.shift)
-        out = self._student(x_src, sigma_src, cond)
-        means, logw, logg = out.means, out.logweights, out.loggammas
         T = cond['prompt_embeds'].shape[1]
+        if self.trunk is not None:
+            nb = self.student.num_double + self.student.num_single
+            if self._ckpt is None or self._ckpt.shape[1] != B * (T + N):
+                self._ckpt = torch.empty(nb, B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
+            self.student.set_checkpoint_buffer(self._ckpt)
+        out = self._student(x_src, sigma_src, cond)
+        if self.trunk is not None:
+            self.student.set_checkpoint_buffer(None)      # the teacher-free forwards below must not overwrite it
+        means, logw, logg = out.means, out.logweights, out.loggammas
         xn = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
         xf = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
         semb = torch.empty(B, self.D, dtype=torch.float32, device=dev)
         self.student.export('head_in', xn, B, N, T)
         self.student.export('x_final', xf, B, N, T)
         self.student.export('silu_temb', semb, B, N, T)
+        mod_all = None
+        if self.trunk is not None:
+            mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
+            self.student.export('mod_all', mod_all, B, N, T)
 
         n_sub = max(round(segment * c.total_substeps), 1)
         window = min(c.window_substeps * (segment / n_sub), segment)
@@ -253,6 +273,10 @@ class ArcFlowDistiller:
         dflat = dmod.view(B, 2 * self.D)
         ops.outer_accum(dflat, semb, self._view(gbuf, 2).view(2 * self.D, self.D))
         ops.outer_accum(dflat, torch.ones(B, 1, device=dev), self._view(gbuf, 3).view(2 * self.D, 1))
+        if self.trunk is not None:                          # LoRA adapters: per-sample recompute + backward of every block
+            for b in range(B):
+                self.trunk.backward_sample(self._ckpt, b, mod_all, xf[b * N:(b + 1) * N], dxn[b * N:(b + 1) * N], T, N,
+                                           cond['hp'], cond['wp'], gbuf)
         return x_dst, raw_dst
 
     # ------------------------------------------------------------------ one iteration
@@ -301,11 +325,13 @@ class ArcFlowDistiller:
             hw, hb = self._off[0], self._off[1]
             groups = [(hw, hw + n2 * self.D, lr), (hw + n2 * self.D, self._off[1], lr * c.loggamma_lr_mult),
                       (hb, hb + n2, lr), (hb + n2, self._off[2], lr * c.loggamma_lr_mult),
-                      (self._off[2], self._off[4], lr)]
+                      (self._off[2], self.params.numel(), lr)]
             for a, b, glr in groups:
                 ops.adamw_step(self.params[a:b], g[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], glr, self.opt_steps,
                                betas=c.betas, weight_decay=c.weight_decay, grad_scale=scale)
             self._sync_working_copies()
+            if self.trunk is not None:
+                self.trunk.refresh()
         # Karras EMA (ema_hook.py:86-124): copy before start_iter, lerp after
         if it < c.ema_start_iter:
             self.ema.copy_(self.params)

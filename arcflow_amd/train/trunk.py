@@ -1,0 +1,270 @@
+"""Gradient path through the MMDiT trunk for the rank-r LoRA adapters (reference: peft LoRA on the MLP linears,
+lakonlab/models/architecture/arcflow/arcflux.py:294-302 with the target lists of configs/flux/arcflux_2nfe_k16.py:40-50
+and configs/qwen/arcqwen_2nfe_k16.py:47-58; gradient checkpointing of every block arcflux.py:181-189).
+
+Design for MI355X:
+  * The student FORWARD is the inference engine on merged weights W' = W + B A (one fp32-accumulated GEMM per adapted
+    linear after every optimizer step) -- no side GEMMs on the hot path; the engine stores each block's input
+    (checkpoint) while it runs.
+  * BACKWARD walks the blocks in reverse; each block is recomputed from its checkpoint with the same HIP kernels
+    (bit-identical to the forward) keeping the intermediates, then differentiated by hand:
+    dgrad GEMMs on pre-transposed weights, flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
+  * LoRA gradients per adapted linear  y = x W'^T:   t = x A^T,  dT = dy B,  dB += dy^T t,  dA += dT^T x
+    (rank-r skinny GEMMs on the MFMA kernel, fp32 accumulate-into output).
+Scope notes: LoRA dropout (0.05 in the reference config) is not applied (merged-weight forward); the
+timestep-embedder LoRA pair (2.4 M of ~650 M trainables) is not trained yet -- it needs the modulation gradients
+of every block.  Both are listed in DESIGN.md.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .. import _lib, ops
+from ..engine import MMDiTEngine
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class LoraSpec:
+    """One adapted linear: where its weight lives in the packed set and where its A / B live in the flat buffers."""
+
+    def __init__(self, name: str, packed_key: str, row0: int, out_f: int, in_f: int, off_a: int, off_b: int):
+        self.name, self.packed_key, self.row0, self.out_f, self.in_f = name, packed_key, row0, out_f, in_f
+        self.off_a, self.off_b = off_a, off_b
+
+
+def lora_targets(family: str, num_double: int, num_single: int, D: int) -> List[Tuple[str, str, int, int, int]]:
+    """(peft module name, packed weight key, first row inside that packed weight, out, in) of every adapted linear."""
+    t = []
+    for i in range(num_double):
+        for s, ff in (('img', 'ff' if family == 'flux' else 'img_mlp'), ('txt', 'ff_context' if family == 'flux' else 'txt_mlp')):
+            if family == 'qwen' and s == 'txt' and i == num_double - 1:
+                continue                                   # txt_mlp of the last Qwen block is not adapted (range(59))
+            t.append((f'transformer_blocks.{i}.{ff}.net.0.proj', f'd{i}.{s}_mlp1', 0, 4 * D, D))
+            t.append((f'transformer_blocks.{i}.{ff}.net.2', f'd{i}.{s}_mlp2', 0, D, 4 * D))
+    for i in range(num_single):
+        t.append((f'single_transformer_blocks.{i}.proj_mlp', f's{i}.fused', 3 * D, 4 * D, D))
+        t.append((f'single_transformer_blocks.{i}.proj_out', f's{i}.out', 0, D, 5 * D))
+    return t
+
+
+class LoraTrunk:
+    def __init__(self, student: MMDiTEngine, packed: Dict[str, torch.Tensor], rank: int, params: torch.Tensor,
+                 base_offset: int, generator: Optional[torch.Generator] = None):
+        """packed: the student's fused weight dict (frozen tensors shared with the teacher).  Adapted weights are
+        replaced IN THIS DICT by private merged copies.  params: the distiller's flat fp32 parameter buffer; the LoRA
+        A/B matrices are laid out from ``base_offset`` on (use ``LoraTrunk.num_params`` to size it)."""
+        self.eng, self.packed, self.r = student, packed, rank
+        self.family, self.D, self.H = student.family, student.dim, student.heads
+        self.nd, self.ns = student.num_double, student.num_single
+        self.dev = student.device
+        D = self.D
+        self.specs: List[LoraSpec] = []
+        off = base_offset
+        for name, key, row0, out_f, in_f in lora_targets(self.family, self.nd, self.ns, D):
+            self.specs.append(LoraSpec(name, key, row0, out_f, in_f, off, off + rank * in_f))
+            off += rank * in_f + out_f * rank
+        self.end_offset = off
+        self.params = params
+        self.by_key: Dict[str, List[LoraSpec]] = {}
+        for sp in self.specs:
+            self.by_key.setdefault(sp.packed_key, []).append(sp)
+        # frozen originals of the adapted weights + private merged copies bound to the student
+        self.base: Dict[str, torch.Tensor] = {}
+        for key in self.by_key:
+            self.base[key] = packed[key + '.weight']
+            packed[key + '.weight'] = packed[key + '.weight'].clone()
+        # peft init_lora_weights='gaussian': A ~ N(0, 1/r), B = 0
+        for sp in self.specs:
+            a = torch.randn(rank, sp.in_f, generator=generator, device=self.dev if generator is None or generator.device.type == 'cuda' else 'cpu') / rank
+            self.A(sp).copy_(a.to(self.dev))
+            self.B(sp).zero_()
+        self.wt: Dict[str, torch.Tensor] = {}        # transposed weights for the dgrad GEMMs
+        self.a16: Dict[str, torch.Tensor] = {}
+        self.bt16: Dict[str, torch.Tensor] = {}
+        self._ones: Dict[int, torch.Tensor] = {}
+        self._build_frozen_transposes()
+        self.refresh()
+
+    @staticmethod
+    def num_params(family: str, nd: int, ns: int, D: int, rank: int) -> int:
+        return sum(rank * i + o * rank for _, _, _, o, i in lora_targets(family, nd, ns, D))
+
+    def A(self, sp: LoraSpec, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        f = self.params if flat is None else flat
+        return f[sp.off_a:sp.off_a + self.r * sp.in_f].view(self.r, sp.in_f)
+
+    def B(self, sp: LoraSpec, flat: Optional[torch.Tensor] = None) -> torch.Tensor:
+        f = self.params if flat is None else flat
+        return f[sp.off_b:sp.off_b + sp.out_f * self.r].view(sp.out_f, self.r)
+
+    # ------------------------------------------------------------------ weights
+    def _build_frozen_transposes(self):
+        for i in range(self.nd):
+            for s in ('img', 'txt'):
+                for nm in ('qkv', 'out', 'mlp1', 'mlp2'):
+                    k = f'd{i}.{s}_{nm}'
+                    if k not in self.by_key:                     # adapted weights are (re)transposed in refresh()
+                        self.wt[k] = ops.transpose(self.packed[k + '.weight'])
+
+    def refresh(self):
+        """Re-merge W' = W + B A, refresh the transposed copies and the bf16 working copies (after an optimizer step)."""
+        for key, sps in self.by_key.items():
+            w = self.packed[key + '.weight']
+            if sps[0].row0 > 0:                                  # fused single-block weight: frozen k|v|q rows in front
+                w[:sps[0].row0].copy_(self.base[key][:sps[0].row0])
+            for sp in sps:
+                a16 = ops.cast_bf16(self.A(sp))
+                b16 = ops.cast_bf16(self.B(sp))
+                self.a16[sp.name] = a16
+                self.bt16[sp.name] = ops.transpose(b16)          # [r, out]
+                at = ops.transpose(a16)                          # [in, r]
+                ones = self._ones.setdefault(sp.in_f, torch.ones(1, sp.in_f, dtype=torch.float32, device=self.dev))
+                rows = slice(sp.row0, sp.row0 + sp.out_f)
+                ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=self.base[key][rows], rows_per_batch=sp.out_f,
+                           out=w[rows])                          # W' = W + B A  (fp32 accumulate, one rounding)
+            self.wt[key] = ops.transpose(w)
+
+    def merged_state(self) -> Dict[str, torch.Tensor]:
+        return {sp.name: self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f] for sp in self.specs}
+
+    # ------------------------------------------------------------------ LoRA gradients of one linear
+    def _lora_grad(self, sp: LoraSpec, x: torch.Tensor, dy: torch.Tensor, grads: torch.Tensor):
+        """x [M, in], dy [M, out] bf16 (row-strided views).  dA += (dy B)^T x ;  dB += dy^T (x A^T)."""
+        t = ops.linear(x, self.a16[sp.name])                     # [M, r]
+        dT = ops.linear(dy, self.bt16[sp.name])                  # [M, r]
+        xt, dyt = ops.transpose(x, 64), ops.transpose(dy, 64)    # contraction over the M tokens
+        tt, dTt = ops.transpose(t, 64), ops.transpose(dT, 64)
+        ops.linear_f32out(dyt, tt, out=self.B(sp, grads), accumulate=True)
+        ops.linear_f32out(dTt, xt, out=self.A(sp, grads), accumulate=True)
+
+    # ------------------------------------------------------------------ helpers on strided 2-D views
+    def _rope(self, x, y, w_txt, w_img, cos, sin, S, T, dy=None):
+        lib = self.eng.lib
+        _lib.check(lib.afx_qk_norm_rope_oop_bf16(_p(x), x.stride(0), _p(y), y.stride(0), _p(dy), 0 if dy is None else dy.stride(0),
+                                                 _p(w_txt), _p(w_img), _p(cos), _p(sin), 1, S, T, self.H, int(dy is not None), _s()))
+
+    def _streams(self, T: int, S: int):
+        return (('img', slice(T, S), 0), ('txt', slice(0, T), 1))
+
+    # ------------------------------------------------------------------ block recompute + backward (one sample)
+    def _double_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: torch.Tensor, grads) -> torch.Tensor:
+        """X [S, D] block input, mod [n_mod] f32 of this sample, dXo [S, D] grad of the block output -> grad of X."""
+        D, S = self.D, X.shape[0]
+        dev = self.dev
+        pk, p = self.packed, f'd{i}.'
+        m0 = i * 12 * D
+        mv = {('img', c): mod[m0 + c * D:m0 + (c + 1) * D] for c in range(6)}
+        mv.update({('txt', c): mod[m0 + (6 + c) * D:m0 + (7 + c) * D] for c in range(6)})
+        qkn = pk[p + 'qknorm']                                   # [img_q, img_k, txt_q, txt_k]
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        Xn1 = torch.empty(S, D, **bf)
+        QKVp = torch.empty(S, 3 * D, **bf)                       # pre-norm k | v | q
+        for s, rows, _ in self._streams(T, S):
+            ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
+            ops.linear(Xn1[rows], pk[p + s + '_qkv.weight'], pk[p + s + '_qkv.bias'], out=QKVp[rows])
+        Kp, V, Qp = QKVp[:, :D], QKVp[:, D:2 * D], QKVp[:, 2 * D:]
+        K, Q, O = torch.empty(S, D, **bf), torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        self._rope(Kp, K, qkn[3], qkn[1], cos, sin, S, T)
+        self._rope(Qp, Q, qkn[2], qkn[0], cos, sin, S, T)
+        lse = ops.attention_fwd_lse_2d(Q, K, V, O, 1, S, self.H)
+        X1, Xn2 = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        Pre, Hh = torch.empty(S, 4 * D, **bf), torch.empty(S, 4 * D, **bf)
+        for s, rows, _ in self._streams(T, S):
+            ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], epilogue='gate_res', gate=mv[(s, 2)],
+                       residual=X[rows], out=X1[rows])
+            ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
+            ops.linear(Xn2[rows], pk[p + s + '_mlp1.weight'], pk[p + s + '_mlp1.bias'], out=Pre[rows])
+            ops.gelu(Pre[rows], out=Hh[rows])
+        # ---- backward ----
+        dX1 = torch.empty(S, D, **bf)
+        dO = torch.empty(S, D, **bf)
+        for s, rows, _ in self._streams(T, S):
+            dY2 = ops.add_scale(dXo[rows], gate=mv[(s, 5)])
+            sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
+            if sp2 is not None:
+                self._lora_grad(sp2, Hh[rows], dY2, grads)
+            dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
+            dPre = ops.gelu(Pre[rows], dh=dH)
+            if sp1 is not None:
+                self._lora_grad(sp1, Xn2[rows], dPre, grads)
+            dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
+            ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
+            dYo = ops.add_scale(dX1[rows], gate=mv[(s, 2)])
+            ops.linear(dYo, self.wt[p + s + '_out'], out=dO[rows])
+        dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        dQKVp = torch.empty(S, 3 * D, **bf)
+        ops.attention_bwd_2d(Q, K, V, O, dO, lse, dQ, dK, dQKVp[:, D:2 * D], 1, S, self.H)
+        self._rope(Kp, dQKVp[:, :D], qkn[3], qkn[1], cos, sin, S, T, dy=dK)
+        self._rope(Qp, dQKVp[:, 2 * D:], qkn[2], qkn[0], cos, sin, S, T, dy=dQ)
+        dX = torch.empty(S, D, **bf)
+        for s, rows, _ in self._streams(T, S):
+            dXn1 = ops.linear(dQKVp[rows], self.wt[p + s + '_qkv'])
+            ops.ln_modulate_backward(X[rows], dXn1, mv[(s, 1)], dres=dX1[rows], out=dX[rows])
+        return dX
+
+    def _single_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: torch.Tensor, grads) -> torch.Tensor:
+        D, S = self.D, X.shape[0]
+        dev = self.dev
+        pk, p = self.packed, f's{i}.'
+        m0 = self.nd * 12 * D + i * 3 * D
+        sh, sc, gt = mod[m0:m0 + D], mod[m0 + D:m0 + 2 * D], mod[m0 + 2 * D:m0 + 3 * D]
+        qkn = pk[p + 'qknorm']                                   # [q, k]
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        Xn = ops.norm_modulate(X, sc, sh)
+        Fp = ops.linear(Xn, pk[p + 'fused.weight'], pk[p + 'fused.bias'])          # [S, 7D] pre-activation k|v|q|mlp
+        Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
+        K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        G = torch.empty(S, 5 * D, **bf)                          # [O | gelu(mlp)] = proj_out operand
+        self._rope(Kp, K, qkn[1], qkn[1], cos, sin, S, T)
+        self._rope(Qp, Q, qkn[0], qkn[0], cos, sin, S, T)
+        lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
+        ops.gelu(Mp, out=G[:, D:])
+        # ---- backward ----
+        dY = ops.add_scale(dXo, gate=gt)
+        sp_out, sp_mlp = self._spec(p + 'out'), self._spec(p + 'fused')
+        if sp_out is not None:
+            self._lora_grad(sp_out, G, dY, grads)
+        dG = ops.linear(dY, self.wt[p + 'out'])                  # [S, 5D]
+        dFp = torch.empty(S, 7 * D, **bf)
+        ops.gelu(Mp, dh=dG[:, D:], out=dFp[:, 3 * D:])
+        if sp_mlp is not None:
+            self._lora_grad(sp_mlp, Xn, dFp[:, 3 * D:], grads)
+        dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        ops.attention_bwd_2d(Q, K, V, G[:, :D], dG[:, :D], lse, dQ, dK, dFp[:, D:2 * D], 1, S, self.H)
+        self._rope(Kp, dFp[:, :D], qkn[1], qkn[1], cos, sin, S, T, dy=dK)
+        self._rope(Qp, dFp[:, 2 * D:3 * D], qkn[0], qkn[0], cos, sin, S, T, dy=dQ)
+        dXn = ops.linear(dFp, self.wt[p + 'fused'])
+        return ops.ln_modulate_backward(X, dXn, sc, dres=dXo)
+
+    def _spec(self, key: str) -> Optional[LoraSpec]:
+        sps = self.by_key.get(key)
+        return sps[0] if sps else None
+
+    # ------------------------------------------------------------------ whole-trunk backward of one sample
+    def backward_sample(self, ckpt: torch.Tensor, b: int, mod_all: torch.Tensor, x_final_img: torch.Tensor,
+                        dxn_img: torch.Tensor, T: int, N: int, hp: int, wp: int, grads: torch.Tensor) -> None:
+        """ckpt [nblocks, B*S, D] block inputs of the last student forward; mod_all [B, n_mod]; x_final_img [N, D] the
+        image tokens entering norm_out; dxn_img [N, D] the gradient at the velocity head's input.  Accumulates the
+        LoRA gradients of sample b into ``grads``."""
+        D, S = self.D, T + N
+        mod = mod_all[b]
+        cos, sin = self.eng.rope_tables(hp, wp, T)
+        fin = (self.nd * 12 + self.ns * 3) * D
+        dX = torch.zeros(S, D, dtype=torch.bfloat16, device=self.dev)
+        ops.ln_modulate_backward(x_final_img, dxn_img, mod[fin:fin + D], out=dX[T:])     # norm_out: scale first
+        for i in reversed(range(self.ns)):
+            X = ckpt[self.nd + i, b * S:(b + 1) * S]
+            dX = self._single_block(i, X, mod, cos, sin, T, dX, grads)
+        for i in reversed(range(self.nd)):
+            X = ckpt[i, b * S:(b + 1) * S]
+            dX = self._double_block(i, X, mod, cos, sin, T, dX, grads)

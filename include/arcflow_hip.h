@@ -108,6 +108,11 @@ int afx_mmdit_forward(afx_ctx* ctx, const void* x, const void* ctx_emb, const vo
                       int32_t batch, int32_t n_img, int32_t n_txt,
                       void* means, void* logw, void* logg, void* stream);
 
+/* Gradient checkpointing (arcflux.py:181-189,315-316 checkpoint every block): when a buffer of
+ * (num_double + num_single) x [B*(T+N), D] bf16 is set, afx_mmdit_forward stores every block's input token matrix
+ * there; the training trunk recomputes one block at a time from it.  NULL switches it off. */
+int afx_set_checkpoint_buffer(afx_ctx* ctx, void* dptr);
+
 /* Optional instrumentation for bench.py's roofline line: when enabled, afx_mmdit_forward records a HIP
  * event pair on its stream around every GEMM launch (klass 0) and attention launch (klass 1).
  * afx_profile_read waits for the recorded events and returns the summed duration, the number of
@@ -185,7 +190,8 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
 /* dW_accum[J,Kd] += sum_b dmod[b,J] x[b,Kd]   (norm_out.linear weight gradient, B <= 8) */
 int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t B, int32_t J, int32_t Kd, void* stream);
 /* Copy an activation of the LAST afx_mmdit_forward out of the workspace: "head_in" [B*N,D] bf16,
- * "x_final" [B*N,D] bf16, "silu_temb" [B,D] f32, "mod_final" [B,2D] f32 (scale|shift of norm_out). */
+ * "x_final" [B*N,D] bf16, "silu_temb" [B,D] f32, "mod_final" [B,2D] f32 (scale|shift of norm_out),
+ * "mod_all" [B, n_mod] f32 (every modulation vector: per double block img 6D | txt 6D, per single block 3D, final 2D). */
 int afx_mmdit_export(afx_ctx* ctx, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt,
                      void* stream);
 

@@ -140,3 +140,81 @@ def test_grad_reducer_gloo_world2(tmp_path):
     assert r0['mx'] == 2.0 and r1['mx'] == 2.0
     red_single = __import__('arcflow_amd.train.reducer', fromlist=['GradReducer']).GradReducer()
     assert red_single.world == 1 and red_single.finish() == 1.0
+
+
+@pytest.mark.gpu
+def test_lora_trunk_backward_matches_cpu_autograd():
+    """LoRA adapter gradients through the whole trunk (block recompute, flash-attention backward, dgrad GEMMs,
+    LN / RoPE / GELU backward) against autograd through the fp32 oracle with W' = W + B A."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from arcflow_amd.train.trunk import lora_targets
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg, w = _setup()
+    B, hp, wp, T, r = 2, 8, 8, 64, 64
+    N = hp * wp
+    g = torch.Generator().manual_seed(5)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, N, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r)
+    dist = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+    tr = dist.trunk
+    # non-zero B so that dA is exercised; keep a host copy of A, B for the oracle
+    AB = {}
+    for sp in tr.specs:
+        tr.B(sp).copy_((torch.randn(sp.out_f, r, generator=g) * 0.02).cuda())
+        AB[sp.name] = (tr.A(sp).cpu().clone(), tr.B(sp).cpu().clone())
+    tr.refresh()
+    dist.iteration = 1
+    cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+    info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+    torch.cuda.synchronize()
+    gsum = dist.grads[0]
+
+    # ---- oracle -------------------------------------------------------------------------------------------------
+    wt = {k: v.float() for k, v in w.items()}
+    leaves = {}
+    ws = dict(wt)
+    rnd = lambda t: t + (t.bfloat16().float() - t).detach()   # noqa: E731
+    for sp in tr.specs:
+        a = AB[sp.name][0].bfloat16().float().requires_grad_(True)       # the kernels consume bf16 working copies
+        b = AB[sp.name][1].bfloat16().float().requires_grad_(True)
+        leaves[sp.name] = (a, b)
+        ws[sp.name + '.weight'] = rnd(wt[sp.name + '.weight'] + b @ a)
+    gd = torch.full((B,), 3.5)
+
+    def teacher(x_lat, t):
+        with torch.no_grad():
+            u = D.flux_teacher_forward(wt, cfg, R.pack_latents(x_lat).bfloat16().float(), pe.float(), pooled.float(), t, gd, hp, wp)
+            return R.unpack_latents(u.bfloat16().float(), hp, wp)
+    x, raw = x0.clone(), torch.ones(B)
+    total = 0
+    for step in range(2):
+        m, lw, lg = D.flux_forward(ws, cfg, x.bfloat16().float(), pe.float(), pooled.float(), R.shift_sigma(raw), gd, hp, wp)
+        ml, lwl, lgl = R.unpack_mixture(rnd(m), rnd(lw), rnd(lg), hp, wp)
+        u_drop, u_stu, u_tea = draws[step]
+        mask = R.gm_dropout_mask(u_drop.reshape(B, 16, 1, 1, 1), 0.1)
+        loss, x_dst, raw = R.segment_distill(teacher, R.unpack_latents(x, hp, wp), ml, lwl, lgl, raw, 0.75, 0.5, u_stu, u_tea, drop_mask=mask)
+        total = total + loss * 0.5
+        x = R.pack_latents(x_dst.detach())
+    total.backward()
+    assert abs(info['loss'] - total.item()) < 3e-2 * abs(total.item()) + 1e-4, (info['loss'], total.item())
+
+    def rel_l2(a, b):
+        return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+    worst = 0.0
+    for sp in tr.specs:
+        ga, gb = tr.A(sp, gsum).cpu(), tr.B(sp, gsum).cpu()
+        ra, rb = leaves[sp.name][0].grad, leaves[sp.name][1].grad
+        ea, eb = rel_l2(ga, ra), rel_l2(gb, rb)
+        worst = max(worst, ea, eb)
+        assert ea < 8e-2 and eb < 8e-2, (sp.name, ea, eb)
+    assert len(tr.specs) == len(lora_targets('flux', 1, 1, 256)) == 6
+    # the step changed the adapters and re-merged the student's weights
+    sp = tr.specs[0]
+    assert (tr.A(sp).cpu() - AB[sp.name][0]).abs().max().item() > 0
+    merged = tr.merged_state()[sp.name].float().cpu()
+    ref = (w[sp.name + '.weight'].float() + tr.B(sp).cpu().bfloat16().float() @ tr.A(sp).cpu().bfloat16().float())
+    assert rel_l2(merged, ref) < 4e-3
