@@ -218,3 +218,78 @@ def test_lora_trunk_backward_matches_cpu_autograd():
     merged = tr.merged_state()[sp.name].float().cpu()
     ref = (w[sp.name + '.weight'].float() + tr.B(sp).cpu().bfloat16().float() @ tr.A(sp).cpu().bfloat16().float())
     assert rel_l2(merged, ref) < 4e-3
+
+
+@pytest.mark.gpu
+def test_qwen_distill_step_with_true_cfg_teacher():
+    """Qwen-Image family: 2 double blocks, LoRA on img_mlp (all) + txt_mlp (all but the last block), teacher with
+    true classifier-free guidance (negative prompt, scale 4: configs/qwen/arcqwen_2nfe_k16.py:100) vs CPU autograd."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from arcflow_amd.weights import init_arcflow_heads_from_teacher
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg = D.QwenCfg(num_layers=2, heads=2, joint_dim=192)
+    w = D.make_qwen_weights(cfg, seed=11)
+    g = torch.Generator().manual_seed(12)
+    w['proj_out.weight'] = (torch.randn(64, 256, generator=g) * 0.05).bfloat16()
+    w['proj_out.bias'] = (torch.randn(64, generator=g) * 0.02).bfloat16()
+    B, hp, wp, T, r = 1, 8, 8, 64, 64
+    N = hp * wp
+    pe = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+    ne = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, N, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r,
+                       teacher_guidance_scale=4.0)
+    dist = ArcFlowDistiller('qwen', dict(num_double=2, heads=2, joint_dim=192), w, dc)
+    tr = dist.trunk
+    assert len(tr.specs) == 6                       # 2 x img_mlp pairs + 1 x txt_mlp pair
+    AB = {}
+    for sp in tr.specs:
+        tr.B(sp).copy_((torch.randn(sp.out_f, r, generator=g) * 0.02).cuda())
+        AB[sp.name] = (tr.A(sp).cpu().clone(), tr.B(sp).cpu().clone())
+    tr.refresh()
+    dist.iteration = 2
+    cond = dict(prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), hp=hp, wp=wp)
+    info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+    gsum = dist.grads[0]
+    wt = {k: v.float() for k, v in w.items()}
+    ws = dict(wt)
+    rnd = lambda t: t + (t.bfloat16().float() - t).detach()   # noqa: E731
+    leaves = {}
+    for sp in tr.specs:
+        a = AB[sp.name][0].bfloat16().float().requires_grad_(True)
+        b = AB[sp.name][1].bfloat16().float().requires_grad_(True)
+        leaves[sp.name] = (a, b)
+        ws[sp.name + '.weight'] = rnd(wt[sp.name + '.weight'] + b @ a)
+
+    def qwen_teacher_u(ctx, x_tok, t):
+        # plain Qwen-Image forward: same trunk, single proj_out head (diffusers/qwen.py:107-139)
+        saved = {k: wt[k] for k in ('proj_out_means.weight', 'proj_out_means.bias')}
+        wv = dict(wt)
+        wv['proj_out_means.weight'] = torch.cat([wt['proj_out.weight']] + [torch.zeros(64, 256)] * 15)
+        wv['proj_out_means.bias'] = torch.cat([wt['proj_out.bias']] + [torch.zeros(64)] * 15)
+        m, _, _ = D.qwen_forward(wv, cfg, x_tok, ctx, t, hp, wp)
+        return m[:, :, 0]
+
+    def teacher(x_lat, t):
+        with torch.no_grad():
+            xt = R.pack_latents(x_lat).bfloat16().float()
+            pos = qwen_teacher_u(pe.float(), xt, t).bfloat16().float()
+            neg = qwen_teacher_u(ne.float(), xt, t).bfloat16().float()
+            return R.unpack_latents(pos + R.cfg_bias(pos, neg, 4.0), hp, wp)
+    x, raw, total = x0.clone(), torch.ones(B), 0
+    for step in range(2):
+        m, lw, lg = D.qwen_forward(ws, cfg, x.bfloat16().float(), pe.float(), R.shift_sigma(raw), hp, wp)
+        ml, lwl, lgl = R.unpack_mixture(rnd(m), rnd(lw), rnd(lg), hp, wp)
+        u_drop, u_stu, u_tea = draws[step]
+        mask = R.gm_dropout_mask(u_drop.reshape(B, 16, 1, 1, 1), 0.1)
+        loss, x_dst, raw = R.segment_distill(teacher, R.unpack_latents(x, hp, wp), ml, lwl, lgl, raw, 0.5, 0.5, u_stu, u_tea, drop_mask=mask)
+        total = total + loss * 0.5
+        x = R.pack_latents(x_dst.detach())
+    total.backward()
+    assert abs(info['loss'] - total.item()) < 3e-2 * abs(total.item()) + 1e-4, (info['loss'], total.item())
+    for sp in tr.specs:
+        for got, ref in ((tr.A(sp, gsum).cpu(), leaves[sp.name][0].grad), (tr.B(sp, gsum).cpu(), leaves[sp.name][1].grad)):
+            e = ((got - ref).norm() / ref.norm().clamp(min=1e-12)).item()
+            assert e < 8e-2, (sp.name, e)

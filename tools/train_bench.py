@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--model', default='flux')
+    ap.add_argument('--lora-rank', type=int, default=256)
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -41,7 +42,7 @@ def main():
     packed['teacher_head.bias'] = torch.zeros(64, device=dev, dtype=torch.bfloat16)
     packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
     packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
-    dist_ = ArcFlowDistiller('flux', dict(num_double=19, num_single=38), None, DistillConfig(), device=dev, packed=packed)
+    dist_ = ArcFlowDistiller('flux', dict(num_double=19, num_single=38), None, DistillConfig(lora_rank=args.lora_rank), device=dev, packed=packed)
     B = args.batch
     cond = dict(prompt_embeds=(torch.randn(B, 512, 4096, device=dev, generator=g) * 0.1).bfloat16(),
                 pooled=(torch.randn(B, 768, device=dev, generator=g) * 0.1).bfloat16(), hp=64, wp=64)
@@ -54,11 +55,13 @@ def main():
         info = dist_.train_step(cond, B, rng=rng)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
-    fwd_equiv = 2 + 8                       # student + teacher forwards per sample-iteration (no trunk backward yet)
+    # student fwd 2 + teacher fwd 8 (+ per-block recompute 2 + backward ~4 with the LoRA trunk): SURVEY 3.3 counts 16
+    fwd_equiv = 16 if args.lora_rank > 0 else 10
     if rank == 0:
-        print(json.dumps({'metric': 'distillation samples/s (heads + norm_out trainable set)', 'value': world * B / dt,
+        print(json.dumps({'metric': 'distillation samples/s (' + ('LoRA r=%d + ' % args.lora_rank if args.lora_rank else '') + 'heads + norm_out trainable)', 'value': world * B / dt,
                           's_per_iter': dt, 'batch_per_gpu': B, 'n_gpus': world, 'last': info,
-                          'forward_equivalents_per_sample': fwd_equiv,
+                          'forward_equivalents_per_sample': fwd_equiv, 'trainable_params': int(dist_.params.numel()),
+                          'max_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
                           'denoiser_tflops': world * B * fwd_equiv * 74.41 / dt}))
 
 
