@@ -73,15 +73,25 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
           for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
         }
       } else if (P.epi == EPI_GATE_RES) {
-        const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
-        const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
-        const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
+        float g[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // gate == nullptr: plain residual add
+        if (P.gate != nullptr) {
+          const float* gp = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg + gcol;
+          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(gp);
+          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(gp + 4);
+          g[0] = g0[0]; g[1] = g0[1]; g[2] = g0[2]; g[3] = g0[3]; g[4] = g1[0]; g[5] = g1[1]; g[6] = g1[2]; g[7] = g1[3];
+        }
         const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol);
         float rr[8];
         unpack8(rw, rr);
-        const float g[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
+      }
+      if (P.conv_wp > 0) {        // convolution on the padded grid: keep the 1-pixel border zero for the next layer
+        const int yy = grow / P.conv_wp, xx = grow - yy * P.conv_wp;
+        if (yy == 0 || yy == P.conv_hp - 1 || xx == 0 || xx == P.conv_wp - 1) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        }
       }
       if (P.out_f32 == 0) {
         *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol) = pack8(v);
@@ -218,7 +228,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // phase r; WAR: see above.  Loads for tiles past K are clamped to the last tile (keeps the count uniform).
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
 
-AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int kbyte, char* slot, int wave) {
+AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int64_t kbyte, char* slot, int wave) {
   const char* s0 = reinterpret_cast<const char*>(p0) + kbyte;
   const char* s1 = reinterpret_cast<const char*>(p1) + kbyte;
   __builtin_amdgcn_global_load_lds((gbl_void_t*)s0, (lds_void_t*)(slot + (wave * 64) * 16), 16, 0, 0);
@@ -272,7 +282,17 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   }
   // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
   auto slot = [&](int t, int h) -> char* { return smem + (((t & 1) << 2) + h) * HALF_BYTES; };
-  auto kb = [&](int t) -> int { return (t < nk ? t : nk - 1) * (BK * 2); };
+  auto kb = [&](int t) -> int64_t { return (int64_t)(t < nk ? t : nk - 1) * (BK * 2); };
+  // implicit 3x3 convolution on a zero-bordered NHWC grid (conv_cin_tiles > 0): K-tile t = (tap, 64-channel chunk);
+  // its A rows are the SAME flat pixel rows shifted by (dy * row_pitch + dx) -- no im2col, the tap is a row offset.
+  const int ct = P.conv_cin_tiles;
+  auto ka = [&](int t) -> int64_t {
+    t = t < nk ? t : nk - 1;
+    if (ct == 0) return (int64_t)t * (BK * 2);
+    const int tap = t / ct, cc = t - tap * ct;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    return ((int64_t)(dy * P.conv_wp + dx) * P.lda + cc * BK) * 2;
+  };
 
   f32x4_t acc[8][4];
 #pragma unroll
@@ -282,11 +302,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
 
   // ---- prologue = the staging of virtual phases -6..-1 -------------------------------------
   stage_half(src[2][0], src[2][1], kb(0), slot(0, 2), wave);   // Y0(0)
-  stage_half(src[0][0], src[0][1], kb(0), slot(0, 0), wave);   // X0(0)
+  stage_half(src[0][0], src[0][1], ka(0), slot(0, 0), wave);   // X0(0)
   stage_half(src[3][0], src[3][1], kb(0), slot(0, 3), wave);   // Y1(0)
-  stage_half(src[1][0], src[1][1], kb(0), slot(0, 1), wave);   // X1(0)
+  stage_half(src[1][0], src[1][1], ka(0), slot(0, 1), wave);   // X1(0)
   stage_half(src[2][0], src[2][1], kb(1), slot(1, 2), wave);   // Y0(1)
-  stage_half(src[0][0], src[0][1], kb(1), slot(1, 0), wave);   // X0(1)
+  stage_half(src[0][0], src[0][1], ka(1), slot(1, 0), wave);   // X0(1)
   AFX_WAIT_VM8();                       // Y0(0), X0(0) landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();         // ... and everybody else's
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
@@ -336,7 +356,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int j = 0; j < 2; ++j) b1[kk][j] = lds_frag(y1, brow + j * 16, kk * 4 + fq);
-    stage_half(src[1][0], src[1][1], kb(t + 1), slot(t + 1, 1), wave);   // X1(t+1)
+    stage_half(src[1][0], src[1][1], ka(t + 1), slot(t + 1, 1), wave);   // X1(t+1)
     AFX_WAIT_VM8();
     AFX_PHASE_TAIL(0, 1, b1)
     // ---- phase 2: quadrant (mh1, nh1) -----------------------------------------------------
@@ -347,7 +367,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
     stage_half(src[2][0], src[2][1], kb(t + 2), slot(t, 2), wave);       // Y0(t+2)
     AFX_PHASE_TAIL(1, 1, b1)
     // ---- phase 3: quadrant (mh1, nh0), operands already in registers --------------------------
-    stage_half(src[0][0], src[0][1], kb(t + 2), slot(t, 0), wave);       // X0(t+2)
+    stage_half(src[0][0], src[0][1], ka(t + 2), slot(t, 0), wave);       // X0(t+2)
     AFX_WAIT_VM8();
     AFX_PHASE_TAIL(1, 0, b0)
   }
@@ -722,11 +742,14 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (r != hipSuccess) return r;
   }
   batch.group_m = group_m;
-  if (impl == 1)
+  int use = impl;
+  for (int i = 0; i < batch.nprob; ++i)
+    if (batch.p[i].conv_cin_tiles > 0) use = 2;      // the implicit-conv addressing lives in the v2 kernel
+  if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
-  else if (impl == 2)
+  else if (use == 2)
     hipLaunchKernelGGL(gemm_bf16_kernel_v2, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
-  else if (impl == 3)
+  else if (use == 3)
     hipLaunchKernelGGL(gemm_bf16_kernel_v3, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else
     hipLaunchKernelGGL(gemm_bf16_kernel_v4, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);

@@ -20,6 +20,7 @@ struct GemmProblem {
   int32_t M, N, K;
   int32_t epi, gelu_col0, rows_per_batch;
   int32_t out_f32;      // 0: C is bf16; 1: C is float (ldc in floats); 2: C (float) += result
+  int32_t conv_cin_tiles, conv_wp, conv_hp;   // > 0: implicit 3x3 conv on a padded [conv_hp][conv_wp] NHWC grid, K = 9 * 64 * conv_cin_tiles
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 

@@ -1,0 +1,266 @@
+// VAE decoder kernels (FLUX AutoencoderKL decoder: the step right after the denoising loop,
+// reference lakonlab/pipelines/arcflux_pipeline.py:531-534; diffusers-owned architecture).
+//
+// Layout: every activation is NHWC bf16 on a ZERO-BORDERED grid [H+2][W+2][C] (flat row = pixel, C contiguous).
+// A 3x3 convolution is then an implicit GEMM on the MFMA kernel of afx_gemm.hip with NO im2col: K-tile
+// (tap, 64-channel chunk) reads the same pixel rows shifted by dy*(W+2)+dx (see GemmProblem::conv_*), the
+// epilogue re-zeroes the border, so each layer's output is directly the next layer's padded input.
+// The kernels here are the HBM-bound glue: GroupNorm(32) statistics + apply(+SiLU), nearest 2x upsample,
+// interior gather / scatter for the single-head mid-block attention, fp32 row softmax, latent / image layout.
+#include <algorithm>
+
+#include "afx_api_util.h"
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// ---- GroupNorm statistics: stats[b][g] = {sum, sum of squares} in fp64 (border rows are zero and do not count) ----
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, int64_t rows, int C, int groups,
+                                                       double* __restrict__ stats, int rows_per_block) {
+  __shared__ float part[64][2];
+  const int cpr = C >> 3;                       // 16-byte chunks per row
+  const int gs = C / groups;                    // channels per group (>= 4)
+  if (threadIdx.x < 64) part[threadIdx.x][0] = part[threadIdx.x][1] = 0.f;
+  __syncthreads();
+  const int c = threadIdx.x % cpr;
+  const int rl = threadIdx.x / cpr, rstep = 256 / cpr;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  for (int64_t r = r0 + rl; r < r1; r += rstep) {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s0 += v[e]; q0 += v[e] * v[e];
+      s1 += v[4 + e]; q1 += v[4 + e] * v[4 + e];
+    }
+  }
+  const int g0 = (c * 8) / gs, g1 = (c * 8 + 4) / gs;
+  atomicAdd(&part[g0][0], s0); atomicAdd(&part[g0][1], q0);
+  atomicAdd(&part[g1][0], s1); atomicAdd(&part[g1][1], q1);
+  __syncthreads();
+  if (threadIdx.x < groups) {
+    atomicAdd(stats + threadIdx.x * 2, (double)part[threadIdx.x][0]);
+    atomicAdd(stats + threadIdx.x * 2 + 1, (double)part[threadIdx.x][1]);
+  }
+}
+
+// y = act((x - mean_g) rstd_g gamma_c + beta_c), border pixels forced to 0.  act: 0 none, 1 SiLU.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int C,
+                                                       int groups, const double* __restrict__ stats, double count,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                       int act, int hp, int wp) {
+  const int cpr = C >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= rows * cpr) return;
+  const int64_t r = g / cpr;
+  const int c = (int)(g % cpr);
+  const int yy = (int)((r % ((int64_t)hp * wp)) / wp), xx = (int)(r % wp);
+  float o[8];
+  if (yy == 0 || yy == hp - 1 || xx == 0 || xx == wp - 1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+  } else {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
+    const int gs = C / groups;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ch = c * 8 + e;
+      const int gi = ch / gs;
+      const double mean = stats[gi * 2] / count;
+      const double var = stats[gi * 2 + 1] / count - mean * mean;
+      const float rstd = rsqrtf((float)var + eps);
+      float t = (v[e] - (float)mean) * rstd * gamma[ch] + beta[ch];
+      o[e] = act ? silu(t) : t;
+    }
+  }
+  *reinterpret_cast<u32x4_t*>(y + r * C + c * 8) = pack8(o);
+}
+
+// nearest 2x upsample between zero-bordered NHWC grids: out[(2h+a+1), (2w+b+1)] = in[h+1, w+1]
+__global__ __launch_bounds__(256) void upsample2x_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int H, int W, int C) {
+  const int cpr = C >> 3;
+  const int Ho = 2 * H + 2, Wo = 2 * W + 2;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)Ho * Wo * cpr) return;
+  const int c = (int)(g % cpr);
+  const int64_t p = g / cpr;
+  const int yo = (int)(p / Wo), xo = (int)(p % Wo);
+  u32x4_t v = (u32x4_t){0u, 0u, 0u, 0u};
+  if (yo >= 1 && yo <= 2 * H && xo >= 1 && xo <= 2 * W) {
+    const int yi = (yo - 1) / 2 + 1, xi = (xo - 1) / 2 + 1;
+    v = *reinterpret_cast<const u32x4_t*>(x + ((int64_t)yi * (W + 2) + xi) * C + c * 8);
+  }
+  *reinterpret_cast<u32x4_t*>(y + p * C + c * 8) = v;
+}
+
+// interior <-> compact: dir 0: compact[h*W+w] = padded[(h+1),(w+1)];  dir 1: padded interior = compact (+ res interior)
+__global__ __launch_bounds__(256) void interior_kernel(bf16_t* __restrict__ padded, bf16_t* __restrict__ compact,
+                                                       const bf16_t* __restrict__ res, int H, int W, int C, int dir) {
+  const int cpr = C >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)H * W * cpr) return;
+  const int c = (int)(g % cpr);
+  const int64_t p = g / cpr;
+  const int h = (int)(p / W), w = (int)(p % W);
+  const int64_t pp = ((int64_t)(h + 1) * (W + 2) + (w + 1)) * C + c * 8;
+  if (dir == 0) {
+    *reinterpret_cast<u32x4_t*>(compact + p * C + c * 8) = *reinterpret_cast<const u32x4_t*>(padded + pp);
+  } else {
+    float a[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(compact + p * C + c * 8), a);
+    if (res != nullptr) {
+      float b[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(res + pp), b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[e] += b[e];
+    }
+    *reinterpret_cast<u32x4_t*>(padded + pp) = pack8(a);
+  }
+}
+
+// P[r, :] = softmax(scale * S[r, :])   fp32 in, bf16 out; one block per row
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int64_t lds_, bf16_t* __restrict__ p,
+                                                           int64_t ldp, int cols, float scale) {
+  __shared__ float red[4];
+  const float* sr = s + (int64_t)blockIdx.x * lds_;
+  bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < cols; i += 256) mx = fmaxf(mx, sr[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < cols; i += 256) sum += __expf((sr[i] - mx) * scale);
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  for (int i = threadIdx.x; i < cols; i += 256) pr[i] = f32_to_bf16(__expf((sr[i] - mx) * scale) * inv);
+}
+
+// packed latent tokens [N = hp*wp, 64] f32 (channel c*4 + ph*2 + pw) -> zero-bordered NHWC [2hp+2][2wp+2][Cpad] bf16,
+// value = lat / scaling + shift  (arcflux_pipeline.py:531-532), channels >= 16 zero.
+__global__ __launch_bounds__(256) void latent_to_nhwc_kernel(const float* __restrict__ tok, bf16_t* __restrict__ y, int hp, int wp,
+                                                             int Cpad, float inv_scale, float shift) {
+  const int H = 2 * hp, W = 2 * wp;
+  const int64_t total = (int64_t)(H + 2) * (W + 2) * Cpad;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int c = (int)(g % Cpad);
+  const int64_t p = g / Cpad;
+  const int yy = (int)(p / (W + 2)), xx = (int)(p % (W + 2));
+  float v = 0.f;
+  if (c < 16 && yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+    const int h = yy - 1, w = xx - 1;
+    v = tok[((int64_t)(h >> 1) * wp + (w >> 1)) * 64 + c * 4 + (h & 1) * 2 + (w & 1)] * inv_scale + shift;
+  }
+  y[g] = f32_to_bf16(v);
+}
+
+// zero-bordered NHWC [H+2][W+2][C] bf16 -> image [3][H][W] f32
+__global__ __launch_bounds__(256) void nhwc_to_image_kernel(const bf16_t* __restrict__ x, float* __restrict__ img, int H, int W, int C) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)3 * H * W) return;
+  const int ch = (int)(g / ((int64_t)H * W));
+  const int64_t p = g % ((int64_t)H * W);
+  const int h = (int)(p / W), w = (int)(p % W);
+  img[g] = bf16_to_f32(x[((int64_t)(h + 1) * (W + 2) + (w + 1)) * C + ch]);
+}
+
+}  // namespace afx
+
+using namespace afx;
+
+static inline unsigned vblocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
+                     int32_t Cout, const void* res, void* stream) {
+  // x, y, res: zero-bordered NHWC grids [(H+2)*(W+2), C]; x must have >= (W+3) readable rows before and after
+  // (guard band of the shifted taps).  w: [Cout][3][3][Cin] bf16 (tap-major K).  Cin % 64 == 0, Cout % 8 == 0.
+  if (!x || !w || !y || H < 1 || W < 1 || Cin < 64 || Cin % 64 || Cout < 8 || Cout % 8)
+    return fail(AFX_E_INVALID, "afx_conv3x3_bf16: need Cin %% 64 == 0, Cout %% 8 == 0");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)x; p.lda = Cin; p.W = (const uint16_t*)w; p.ldw = 9 * (int64_t)Cin; p.bias = (const uint16_t*)bias;
+  p.C = (uint16_t*)y; p.ldc = Cout; p.M = (H + 2) * (W + 2); p.N = Cout; p.K = 9 * Cin;
+  p.rows_per_batch = 1 << 30;
+  p.conv_cin_tiles = Cin / 64; p.conv_wp = W + 2; p.conv_hp = H + 2;
+  if (res != nullptr) {          // y = res + conv(x): residual epilogue with a unit gate
+    p.epi = EPI_GATE_RES; p.gate = nullptr; p.ldg = 0; p.res = (const uint16_t*)res; p.ldr = Cout;
+  }
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
+                       const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
+  if (!x || !y || !stats_ws || !gamma || !beta || C % 8 || groups < 1 || groups > 64 || C % groups || (C / groups) % 4)
+    return fail(AFX_E_INVALID, "bad argument to afx_groupnorm_nhwc");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)(H + 2) * (W + 2);
+  HIP_TRY(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * groups, st));
+  const int rpb = 128;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, (const bf16_t*)x, rows, C,
+                     groups, stats_ws, rpb);
+  const double count = (double)H * W * (C / groups);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(vblocks(rows * (C >> 3))), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, C,
+                     groups, stats_ws, count, gamma, beta, eps, act, H + 2, W + 2);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_upsample2x_nhwc(const void* x, void* y, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !y || C % 8) return fail(AFX_E_INVALID, "bad argument to afx_upsample2x_nhwc");
+  hipLaunchKernelGGL(upsample2x_kernel, dim3(vblocks((int64_t)(2 * H + 2) * (2 * W + 2) * (C >> 3))), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, H, W, C);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_interior_nhwc(void* padded, void* compact, const void* res_padded, int32_t H, int32_t W, int32_t C, int32_t scatter,
+                      void* stream) {
+  if (!padded || !compact || C % 8) return fail(AFX_E_INVALID, "bad argument to afx_interior_nhwc");
+  hipLaunchKernelGGL(interior_kernel, dim3(vblocks((int64_t)H * W * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)padded, (bf16_t*)compact, (const bf16_t*)res_padded, H, W, C, scatter);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_softmax_rows_f32(const float* s, int64_t lds_, void* p, int64_t ldp, int32_t rows, int32_t cols, float scale,
+                         void* stream) {
+  if (!s || !p || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_softmax_rows_f32");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds_, (bf16_t*)p, ldp, cols, scale);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_latent_to_nhwc(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, float scaling_factor,
+                       float shift_factor, void* stream) {
+  if (!tokens || !y || Cpad < 16 || Cpad % 8) return fail(AFX_E_INVALID, "bad argument to afx_latent_to_nhwc");
+  const int64_t total = (int64_t)(2 * hp + 2) * (2 * wp + 2) * Cpad;
+  hipLaunchKernelGGL(latent_to_nhwc_kernel, dim3(vblocks(total)), dim3(256), 0, (hipStream_t)stream, tokens, (bf16_t*)y, hp, wp,
+                     Cpad, 1.0f / scaling_factor, shift_factor);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_nhwc_to_image(const void* x, float* img, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !img || C < 3) return fail(AFX_E_INVALID, "bad argument to afx_nhwc_to_image");
+  hipLaunchKernelGGL(nhwc_to_image_kernel, dim3(vblocks((int64_t)3 * H * W)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, img, H, W, C);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+}  // extern "C"

@@ -193,6 +193,12 @@ class ArcFluxPipeline(_PipelineBase):
             sched_cfg = json.load(open(sp))
         pipe = cls(scheduler=FlowMatchEulerDiscreteScheduler.from_config(sched_cfg))
         pipe._transformer_config, pipe._base_state_dict = cfg, sd
+        if os.path.isdir(os.path.join(root, 'vae')):          # AutoencoderKL decoder on the HIP engine
+            from ..vae import AutoencoderKLDecoder
+            vcfg, vsd = load_transformer_dir(os.path.join(root, 'vae'))
+            pipe.vae = AutoencoderKLDecoder(vsd, tuple(vcfg.get('block_out_channels', (128, 256, 512, 512))),
+                                            vcfg.get('norm_num_groups', 32), vcfg.get('layers_per_block', 2),
+                                            vcfg.get('scaling_factor', 0.3611), vcfg.get('shift_factor', 0.1159))
         if 'proj_out.weight' in sd:          # plain FLUX: usable as the teacher until an adapter is loaded
             pipe.transformer = pipe._build_engine(teacher_head=True)
             pipe.transformer.load_state_dict(sd)
@@ -284,10 +290,14 @@ class ArcFluxPipeline(_PipelineBase):
             image = latents
         else:
             if self.vae is None:
-                raise RuntimeError("no VAE decoder attached (SURVEY 8f f1): use output_type='latent'")
-            lat = self._unpack(latents, hp, wp)
-            lat = lat / self.vae.config.scaling_factor + self.vae.config.shift_factor
-            image = self.vae.decode(lat.to(next(self.vae.parameters()).dtype), return_dict=False)[0]
+                raise RuntimeError("no VAE decoder attached: use output_type='latent' or set pipe.vae")
+            from ..vae import AutoencoderKLDecoder
+            if isinstance(self.vae, AutoencoderKLDecoder):      # HIP decoder: un-scaling + unpack fused into its first kernel
+                image = self.vae.decode_packed(latents, hp, wp)
+            else:                                               # any module with the diffusers AutoencoderKL interface
+                lat = self._unpack(latents, hp, wp)
+                lat = lat / self.vae.config.scaling_factor + self.vae.config.shift_factor
+                image = self.vae.decode(lat.to(next(self.vae.parameters()).dtype), return_dict=False)[0]
             image = self._postprocess(image, output_type)
         self.maybe_free_model_hooks()
         if not return_dict:

@@ -1,0 +1,143 @@
+"""AutoencoderKL decoder on the MI355X engine: the ``vae.decode`` step that follows the ArcFlow loop
+(reference lakonlab/pipelines/arcflux_pipeline.py:531-534, wrapper lakonlab/models/architecture/diffusers/pretrained.py:22-149).
+
+MI355X-first layout: NHWC bf16 activations on zero-bordered grids; every 3x3 convolution is an implicit GEMM on the
+8-phase MFMA kernel (tap = row shift, no im2col, residual add fused in the epilogue); GroupNorm(32)+SiLU, nearest
+upsample, softmax and the layout conversions are single-pass streaming kernels; the mid-block attention (one head,
+dim 512, 16 384 tokens at 1024^2) is two MFMA GEMMs around an fp32 row softmax.  Weights are re-laid once at load:
+conv [Cout,Cin,3,3] -> [Cout][tap][Cin] (K-contiguous), to_q|to_k|to_v stacked.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Sequence
+
+import torch
+
+from . import _lib, ops
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Grid:
+    """Zero-bordered NHWC activation [(H+2)*(W+2), C] with guard rows on both sides (the shifted taps of the implicit
+    GEMM read up to W+3 rows outside the grid; what they produce lands on border rows, which the epilogue zeroes)."""
+
+    def __init__(self, H: int, W: int, Cn: int, device):
+        self.H, self.W, self.C = H, W, Cn
+        self.guard = W + 3
+        rows = (H + 2) * (W + 2)
+        self.buf = torch.zeros(rows + 2 * self.guard, Cn, dtype=torch.bfloat16, device=device)
+        self.t = self.buf[self.guard:self.guard + rows]
+
+
+class AutoencoderKLDecoder:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], block_out_channels: Sequence[int] = (128, 256, 512, 512),
+                 norm_num_groups: int = 32, layers_per_block: int = 2, scaling_factor: float = 0.3611,
+                 shift_factor: float = 0.1159, device='cuda'):
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.groups, self.lpb = norm_num_groups, layers_per_block
+        self.rev = list(reversed(block_out_channels))
+        self.scaling_factor, self.shift_factor = scaling_factor, shift_factor
+        self.config = type('cfg', (), dict(scaling_factor=scaling_factor, shift_factor=shift_factor))()
+        self.w: Dict[str, torch.Tensor] = {}
+        sd = state_dict
+        for k in [k for k in sd if k.startswith('decoder.') and k.endswith('.weight')]:
+            name = k[:-len('.weight')]
+            wt, b = sd[k], sd.get(name + '.bias')
+            if wt.dim() == 4 and wt.shape[-1] == 3:                       # 3x3 conv -> [Cout][tap][Cin], K-contiguous
+                co, ci = wt.shape[:2]
+                cip, cop = max(64, (ci + 63) // 64 * 64), (co + 7) // 8 * 8
+                wp = torch.zeros(cop, 9, cip, dtype=torch.bfloat16)
+                wp[:co, :, :ci] = wt.permute(0, 2, 3, 1).reshape(co, 9, ci).to(torch.bfloat16)
+                bp = torch.zeros(cop, dtype=torch.bfloat16)
+                bp[:co] = b.to(torch.bfloat16)
+                self.w[name + '.weight'], self.w[name + '.bias'] = wp.reshape(cop, 9 * cip).to(self.dev), bp.to(self.dev)
+            elif wt.dim() == 4:                                           # 1x1 conv_shortcut -> linear
+                self.w[name + '.weight'] = wt.reshape(wt.shape[0], wt.shape[1]).to(self.dev, torch.bfloat16).contiguous()
+                self.w[name + '.bias'] = b.to(self.dev, torch.bfloat16)
+            elif wt.dim() == 2:
+                self.w[name + '.weight'] = wt.to(self.dev, torch.bfloat16).contiguous()
+                self.w[name + '.bias'] = b.to(self.dev, torch.bfloat16)
+            else:                                                         # GroupNorm affine
+                self.w[name + '.weight'] = wt.to(self.dev, torch.float32)
+                self.w[name + '.bias'] = b.to(self.dev, torch.float32)
+        a = 'decoder.mid_block.attentions.0.'
+        self.w[a + 'qkv.weight'] = torch.cat([self.w[a + n + '.weight'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
+        self.w[a + 'qkv.bias'] = torch.cat([self.w[a + n + '.bias'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
+        self._stats = torch.zeros(128, dtype=torch.float64, device=self.dev)
+
+    # ------------------------------------------------------------------ primitives on grids
+    def _conv(self, name: str, x: _Grid, cout: int, res: _Grid = None) -> _Grid:
+        w, b = self.w[name + '.weight'], self.w[name + '.bias']
+        y = _Grid(x.H, x.W, w.shape[0], self.dev)
+        _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, w.shape[0],
+                                             None if res is None else _p(res.t), _s()))
+        return y
+
+    def _gn(self, name: str, x: _Grid, act: bool) -> _Grid:
+        y = _Grid(x.H, x.W, x.C, self.dev)
+        _lib.check(self.lib.afx_groupnorm_nhwc(_p(x.t), _p(y.t), _p(self._stats), x.H, x.W, x.C, self.groups,
+                                               _p(self.w[name + '.weight']), _p(self.w[name + '.bias']), 1e-6, int(act), _s()))
+        return y
+
+    def _resnet(self, p: str, x: _Grid) -> _Grid:
+        h = self._conv(p + 'conv1', self._gn(p + 'norm1', x, True), 0)
+        skip = x
+        if p + 'conv_shortcut.weight' in self.w:
+            skip = _Grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0], self.dev)
+            ops.linear(x.t, self.w[p + 'conv_shortcut.weight'], self.w[p + 'conv_shortcut.bias'], out=skip.t)
+        return self._conv(p + 'conv2', self._gn(p + 'norm2', h, True), 0, res=skip)
+
+    def _attention(self, p: str, x: _Grid) -> _Grid:
+        H, W, Cn = x.H, x.W, x.C
+        N = H * W
+        xn = self._gn(p + 'group_norm', x, False)
+        Np = (N + 63) // 64 * 64                 # token count padded for the GEMM contraction; pad keys get P = 0
+        xc = torch.zeros(Np, Cn, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.afx_interior_nhwc(_p(xn.t), _p(xc), None, H, W, Cn, 0, _s()))
+        qkv = ops.linear(xc, self.w[p + 'qkv.weight'], self.w[p + 'qkv.bias'])                    # [Np, 3C]
+        q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]
+        s = ops.linear_f32out(q, k)                                                              # [Np, Np] fp32 logits
+        pm = torch.zeros(Np, Np, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.afx_softmax_rows_f32(_p(s), s.stride(0), _p(pm), Np, N, N, Cn ** -0.5, _s()))
+        o = ops.linear(pm, ops.transpose(v))                                                     # [N, C] = P V
+        oc = ops.linear(o, self.w[p + 'to_out.0.weight'], self.w[p + 'to_out.0.bias'])
+        y = _Grid(H, W, Cn, self.dev)
+        _lib.check(self.lib.afx_interior_nhwc(_p(y.t), _p(oc), _p(x.t), H, W, Cn, 1, _s()))
+        return y
+
+    # ------------------------------------------------------------------ decode
+    @torch.no_grad()
+    def decode_tokens(self, tokens: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+        """tokens: packed latents [hp*wp, 64] fp32 (the loop's output for ONE image) -> image [3, 16hp, 16wp] fp32."""
+        x = _Grid(2 * hp, 2 * wp, 64, self.dev)
+        _lib.check(self.lib.afx_latent_to_nhwc(_p(tokens.to(self.dev, torch.float32).contiguous()), _p(x.t), hp, wp, 64,
+                                               self.scaling_factor, self.shift_factor, _s()))
+        x = self._conv('decoder.conv_in', x, 0)
+        x = self._resnet('decoder.mid_block.resnets.0.', x)
+        x = self._attention('decoder.mid_block.attentions.0.', x)
+        x = self._resnet('decoder.mid_block.resnets.1.', x)
+        n = len(self.rev)
+        for i in range(n):
+            for j in range(self.lpb + 1):
+                x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
+            if i < n - 1:
+                up = _Grid(2 * x.H, 2 * x.W, x.C, self.dev)
+                _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
+                x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.conv', up, 0)
+        x = self._conv('decoder.conv_out', self._gn('decoder.conv_norm_out', x, True), 0)
+        img = torch.empty(3, x.H, x.W, dtype=torch.float32, device=self.dev)
+        _lib.check(self.lib.afx_nhwc_to_image(_p(x.t), _p(img), x.H, x.W, x.C, _s()))
+        return img
+
+    def decode_packed(self, latents: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+        """[B, hp*wp, 64] packed latents -> [B, 3, 16hp, 16wp]."""
+        return torch.stack([self.decode_tokens(latents[b], hp, wp) for b in range(latents.shape[0])])

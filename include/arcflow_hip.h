@@ -218,6 +218,28 @@ int afx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int afx_ema_lerp(float* ema, const float* net, float beta, int64_t n, void* stream);
 int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 
+/* ---- VAE decoder (AutoencoderKL, the step after the loop: arcflux_pipeline.py:531-534) ---------------------------
+ * Activations are NHWC bf16 on ZERO-BORDERED grids [(H+2)*(W+2), C]; a 3x3 convolution is an implicit GEMM on the MFMA
+ * kernel (K-tile = (tap, 64-channel chunk) = the same pixel rows shifted by dy*(W+2)+dx, no im2col), the epilogue
+ * re-zeroes the border.  x must be readable (W+3) rows before and after the grid.  w: [Cout][3][3][Cin] bf16. */
+int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
+                     int32_t Cout, const void* res, void* stream);
+/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: 2*groups doubles of scratch; act 1 = SiLU */
+int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
+                       const float* gamma, const float* beta, float eps, int32_t act, void* stream);
+int afx_upsample2x_nhwc(const void* x, void* y, int32_t H, int32_t W, int32_t C, void* stream);
+/* scatter == 0: compact[H*W, C] = interior(padded);  != 0: interior(padded) = compact (+ interior(res_padded)) */
+int afx_interior_nhwc(void* padded, void* compact, const void* res_padded, int32_t H, int32_t W, int32_t C, int32_t scatter,
+                      void* stream);
+/* P = softmax(scale * S) row-wise, S fp32 [rows, cols], P bf16 (mid-block single-head attention, head dim 512) */
+int afx_softmax_rows_f32(const float* s, int64_t lds_, void* p, int64_t ldp, int32_t rows, int32_t cols, float scale,
+                         void* stream);
+/* packed latent tokens [hp*wp, 64] f32 -> padded NHWC [(2hp+2)*(2wp+2), Cpad] bf16 of lat/scaling + shift; and back to
+ * an image [3, H, W] f32 from the first 3 channels of a padded NHWC grid */
+int afx_latent_to_nhwc(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, float scaling_factor,
+                       float shift_factor, void* stream);
+int afx_nhwc_to_image(const void* x, float* img, int32_t H, int32_t W, int32_t C, void* stream);
+
 /* ---- building-block kernels (exported for the per-kernel parity tests and micro benches) -- */
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias)   bf16 in/out, fp32 accumulate (nn.Linear semantics).

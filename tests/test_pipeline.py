@@ -99,7 +99,7 @@ def test_flux_pipeline_two_nfe_vs_oracle(tmp_path):
     pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, output_type='latent',
          callback_on_step_end=lambda p, i, t, kw: (seen.append(i), kw)[1])
     assert seen == [0, 1, 2, 3]
-    with pytest.raises(RuntimeError, match='VAE'):
+    with pytest.raises(RuntimeError, match='VAE decoder'):
         pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, num_inference_steps=2)
 
 
