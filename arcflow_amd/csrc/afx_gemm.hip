@@ -1,6 +1,11 @@
 // Grouped bf16 GEMM for gfx950:  C = epi(A . W^T + bias),  A [M,K] and W [N,K] both K-contiguous
 // (the nn.Linear layout), fp32 accumulation on v_mfma_f32_16x16x32_bf16.
 //
+// Two kernels share the tile geometry (the 8-phase v2 is the product path; the plain 2-stage kernel stays as the
+// simple reference for A/B runs, AFX_GEMM_IMPL=1).  Variants that were measured and dropped: the v2 schedule on
+// v_mfma_f32_32x32x16_bf16 (-12 %: the 2-deep accumulator chains stall), 2 phases of 32 MFMAs per K-tile (+3 % on
+// cache-resident operands but -7 % in the real forward, where the halved DMA lead time meets HBM latency), LDS reads
+// levelled 8/4/8/4 over the phases (0 %).
 // Structure (wave64, 8 waves = 2(M) x 4(N), 256x256x64 tile, one work-group per CU):
 //   * HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane): no VGPR round trip.  The DMA
 //     writes LDS lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE
@@ -404,313 +409,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   }
 }
 
-// v4: same half-tile / stagger idea with TWO phases of 32 MFMAs per K-tile (half the barriers):
-//   phase 0: rows mh0 x 64 cols, reads X0 + Y_{wc>>1};  stages X0, Y0, Y1 of tile t+1;  vmcnt(6)
-//   phase 1: rows mh1 (W fragments kept in registers), reads X1;  stages X1 of tile t+1;  vmcnt(2)
-// Y0 / Y1 are the W rows of wave columns {0,1} / {2,3}.  Lead time of a half tile = one phase pair.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v4(const GemmBatch batch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
-  const GemmProblem& P = batch.p[pi];
-  wg -= P.tile_start;
-  const int GM_ = batch.group_m;
-  const int per_group = GM_ * P.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GM_;
-  const int gsz = min(P.tiles_m - first_m, GM_);
-  const int in_grp = wg - grp * per_group;
-  const int tm = first_m + in_grp % gsz;
-  const int tn = in_grp / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = P.K / BK;
-
-  // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
-  const bf16_t* src[4][2];     // [X0, X1, Y0, Y1][chunk i]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = i * GEMM_THREADS + tid;
-    const int lr = p >> 3;                              // local row of the half tile
-    const int c = (p & 7) ^ ((lr >> 1) & 7);            // logical 16-byte chunk stored at physical p & 7
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
-      ar = ar < P.M ? ar : P.M - 1;
-      src[h][i] = P.A + (int64_t)ar * P.lda + c * 8;
-      int br = n0 + h * 128 + lr;
-      br = br < P.N ? br : P.N - 1;
-      src[2 + h][i] = P.W + (int64_t)br * P.ldw + c * 8;
-    }
-  }
-  // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
-  auto slot = [&](int t, int h) -> char* { return smem + (((t & 1) << 2) + h) * HALF_BYTES; };
-  auto kb = [&](int t) -> int { return (t < nk ? t : nk - 1) * (BK * 2); };
-
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  // ---- prologue = the staging of virtual phases -2, -1 -----------------------------------------
-  stage_half(src[0][0], src[0][1], kb(0), slot(0, 0), wave);   // X0(0)
-  stage_half(src[2][0], src[2][1], kb(0), slot(0, 2), wave);   // Y0(0)
-  stage_half(src[3][0], src[3][1], kb(0), slot(0, 3), wave);   // Y1(0)
-  stage_half(src[1][0], src[1][1], kb(0), slot(0, 1), wave);   // X1(0)
-  asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
-
-  const int frow = lane & 15, fq = lane >> 4;
-  const int arow = wr * 64 + frow;                 // + i*16   (rows of X_mh)
-  const int brow = (wc & 1) * 64 + frow;           // + j*16   (rows of Y_{wc>>1})
-  const int yh = 2 + (wc >> 1);
-  bf16x8_t af[2][4], bfr[2][4];                    // [kk][tile]
-
-#define AFX_MFMA_HALF(MH)                                                                           \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                  \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
-    acc[(MH) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                 \
-        af[kk][i], bfr[kk][j], acc[(MH) * 4 + i][j], 0, 0, 0);
-
-#define AFX_PHASE_TAIL4(MH)                                                                         \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_barrier();                                                                     \
-  AFX_WAIT_LGKM0();                                                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_setprio(1);                                                                    \
-  AFX_MFMA_HALF(MH)                                                                                 \
-  __builtin_amdgcn_s_setprio(0);                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_barrier();                                                                     \
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int t = 0; t < nk; ++t) {
-    const char* x0 = slot(t, 0);
-    const char* x1 = slot(t, 1);
-    const char* yy = slot(t, yh);
-    // ---- phase 0: rows mh0 x all 64 columns: reads X0 + Y, stages X0,Y0,Y1 of tile t+1 ------------
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bfr[kk][j] = lds_frag(yy, brow + j * 16, kk * 4 + fq);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[kk][i] = lds_frag(x0, arow + i * 16, kk * 4 + fq);
-    }
-    stage_half(src[0][0], src[0][1], kb(t + 1), slot(t + 1, 0), wave);
-    stage_half(src[2][0], src[2][1], kb(t + 1), slot(t + 1, 2), wave);
-    stage_half(src[3][0], src[3][1], kb(t + 1), slot(t + 1, 3), wave);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // X1(t) landed
-    AFX_PHASE_TAIL4(0)
-    // ---- phase 1: rows mh1, W fragments stay in registers: reads X1, stages X1 of tile t+1 ----------
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[kk][i] = lds_frag(x1, arow + i * 16, kk * 4 + fq);
-    stage_half(src[1][0], src[1][1], kb(t + 1), slot(t + 1, 1), wave);
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");     // X0, Y0, Y1 of tile t+1 landed
-    AFX_PHASE_TAIL4(1)
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail DMAs must land before LDS is reused
-  if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
-  __syncthreads();
-
-  // ---- epilogue (identical to v1) -------------------------------------------------------------
-  float* patch = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-  const int wm = wr, wn = wc;
-  const int er = lane >> 3;
-  const int ec = (lane & 7) * 8;
-  const int gcol = n0 + wn * 64 + ec;
-  const bool col_ok = gcol < P.N;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-  if (P.bias != nullptr && col_ok) {
-    const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol);
-    unpack8(bw, bias);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
-    __syncthreads();
-    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
-  }
-}
-
-// v3: the v2 schedule on v_mfma_f32_32x32x16_bf16 (8 MFMAs of 32 cycles per phase instead of 16 x 16:
-// half the issue slots, higher matrix-pipe ceiling); fragment rows are 32-row groups of the same half tiles.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v3(const GemmBatch batch) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave >> 2, wc = wave & 3;
-
-  int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
-  const GemmProblem& P = batch.p[pi];
-  wg -= P.tile_start;
-  const int GM_ = batch.group_m;
-  const int per_group = GM_ * P.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GM_;
-  const int gsz = min(P.tiles_m - first_m, GM_);
-  const int in_grp = wg - grp * per_group;
-  const int tm = first_m + in_grp % gsz;
-  const int tn = in_grp / gsz;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = P.K / BK;
-
-  // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
-  const bf16_t* src[4][2];     // [X0, X1, Y0, Y1][chunk i]
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int p = i * GEMM_THREADS + tid;
-    const int lr = p >> 3;                              // local row of the half tile
-    const int c = (p & 7) ^ ((lr >> 1) & 7);            // logical 16-byte chunk stored at physical p & 7
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int ar = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
-      ar = ar < P.M ? ar : P.M - 1;
-      src[h][i] = P.A + (int64_t)ar * P.lda + c * 8;
-      int br = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
-      br = br < P.N ? br : P.N - 1;
-      src[2 + h][i] = P.W + (int64_t)br * P.ldw + c * 8;
-    }
-  }
-  // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
-  auto slot = [&](int t, int h) -> char* { return smem + (((t & 1) << 2) + h) * HALF_BYTES; };
-  auto kb = [&](int t) -> int { return (t < nk ? t : nk - 1) * (BK * 2); };
-
-  f32x16_t acc[4][2];     // [32-row tile of the wave's 128 rows][32-col tile of its 64 cols]
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue = the staging of virtual phases -6..-1 -------------------------------------
-  stage_half(src[2][0], src[2][1], kb(0), slot(0, 2), wave);   // Y0(0)
-  stage_half(src[0][0], src[0][1], kb(0), slot(0, 0), wave);   // X0(0)
-  stage_half(src[3][0], src[3][1], kb(0), slot(0, 3), wave);   // Y1(0)
-  stage_half(src[1][0], src[1][1], kb(0), slot(0, 1), wave);   // X1(0)
-  stage_half(src[2][0], src[2][1], kb(1), slot(1, 2), wave);   // Y0(1)
-  stage_half(src[0][0], src[0][1], kb(1), slot(1, 0), wave);   // X0(1)
-  AFX_WAIT_VM8();                       // Y0(0), X0(0) landed (this wave's pieces)
-  __builtin_amdgcn_s_barrier();         // ... and everybody else's
-  if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
-
-  const int frow = lane & 31, fq = lane >> 5;
-  const int arow = wr * 64 + frow;      // + i*32
-  const int brow = wc * 32 + frow;
-  bf16x8_t af[4][2], b0[4], b1[4];      // [k-step of 16][32-row tile]
-
-#undef AFX_MFMA_QUAD
-#define AFX_MFMA_QUAD(MH, NH, BF)                                                                   \
-  _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                  \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-    acc[(MH) * 2 + i][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(                                \
-        af[ks][i], BF[ks], acc[(MH) * 2 + i][NH], 0, 0, 0);
-
-#undef AFX_PHASE_TAIL
-#define AFX_PHASE_TAIL(MH, NH, BF)                                                                  \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_barrier();                                                                     \
-  AFX_WAIT_LGKM0();                                                                                 \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_setprio(1);                                                                    \
-  AFX_MFMA_QUAD(MH, NH, BF)                                                                         \
-  __builtin_amdgcn_s_setprio(0);                                                                    \
-  __builtin_amdgcn_sched_barrier(0);                                                                \
-  __builtin_amdgcn_s_barrier();                                                                     \
-  __builtin_amdgcn_sched_barrier(0);
-
-  for (int t = 0; t < nk; ++t) {
-    const char* x0 = slot(t, 0);
-    const char* x1 = slot(t, 1);
-    const char* y0 = slot(t, 2);
-    const char* y1 = slot(t, 3);
-    // ---- phase 0: quadrant (mh0, nh0) -----------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      b0[ks] = lds_frag(y0, brow, ks * 2 + fq);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[ks][i] = lds_frag(x0, arow + i * 32, ks * 2 + fq);
-    }
-    stage_half(src[3][0], src[3][1], kb(t + 1), slot(t + 1, 3), wave);   // Y1(t+1)
-    AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(0, 0, b0)
-    // ---- phase 1: quadrant (mh0, nh1) -----------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = lds_frag(y1, brow, ks * 2 + fq);
-    stage_half(src[1][0], src[1][1], kb(t + 1), slot(t + 1, 1), wave);   // X1(t+1)
-    AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(0, 1, b1)
-    // ---- phase 2: quadrant (mh1, nh1) -----------------------------------------------------
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) af[ks][i] = lds_frag(x1, arow + i * 32, ks * 2 + fq);
-    stage_half(src[2][0], src[2][1], kb(t + 2), slot(t, 2), wave);       // Y0(t+2)
-    AFX_PHASE_TAIL(1, 1, b1)
-    // ---- phase 3: quadrant (mh1, nh0), operands already in registers --------------------------
-    stage_half(src[0][0], src[0][1], kb(t + 2), slot(t, 0), wave);       // X0(t+2)
-    AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(1, 0, b0)
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail DMAs must land before LDS is reused
-  if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
-  __syncthreads();
-
-  // ---- epilogue (identical to v1) -------------------------------------------------------------
-  float* patch = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-  const int wm = wr, wn = wc;
-  const int er = lane >> 3;
-  const int ec = (lane & 7) * 8;
-  const int gcol = n0 + wn * 64 + ec;
-  const bool col_ok = gcol < P.N;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-  if (P.bias != nullptr && col_ok) {
-    const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol);
-    unpack8(bw, bias);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          patch[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fq) * EPI_LD + j * 32 + frow] = acc[h * 2 + i][j][r];
-    __syncthreads();
-    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
-  }
-}
-
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < batch.nprob; ++i) {
@@ -726,18 +424,12 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   static int group_m = GROUP_M;
   if (impl < 0) {
     if (const char* g = getenv("AFX_GEMM_GROUP_M")) group_m = atoi(g) > 0 ? atoi(g) : GROUP_M;
-    const char* e = getenv("AFX_GEMM_IMPL");
-    impl = (e && e[0] >= '1' && e[0] <= '4') ? (e[0] - '0') : 2;   // v2: best on HBM-streamed weights (bench.py A/B)
+    const char* e = getenv("AFX_GEMM_IMPL");           // 1: simple 2-stage kernel (reference / A-B), default: 8-phase v2
+    impl = (e && e[0] == '1') ? 1 : 2;
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
     r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel_v2),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel_v4),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel_v3),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
   }
@@ -747,12 +439,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (batch.p[i].conv_cin_tiles > 0) use = 2;      // the implicit-conv addressing lives in the v2 kernel
   if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
-  else if (use == 2)
-    hipLaunchKernelGGL(gemm_bf16_kernel_v2, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
-  else if (use == 3)
-    hipLaunchKernelGGL(gemm_bf16_kernel_v3, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else
-    hipLaunchKernelGGL(gemm_bf16_kernel_v4, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+    hipLaunchKernelGGL(gemm_bf16_kernel_v2, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   return hipGetLastError();
 }
 
