@@ -5,7 +5,10 @@
 // simple reference for A/B runs, AFX_GEMM_IMPL=1).  Variants that were measured and dropped: the v2 schedule on
 // v_mfma_f32_32x32x16_bf16 (-12 %: the 2-deep accumulator chains stall), 2 phases of 32 MFMAs per K-tile (+3 % on
 // cache-resident operands but -7 % in the real forward, where the halved DMA lead time meets HBM latency), LDS reads
-// levelled 8/4/8/4 over the phases (0 %).
+// levelled 8/4/8/4 over the phases (0 %), one barrier per K-tile with every wave interleaving its own ds_reads / DMA with
+// its MFMAs (-21 %: the vmcnt(0) in front of the barrier drains the DMA queue).
+// Cycle budget of one 256x256 tile, K = 3072 (tools/gemm_trace.hip, s_memtime): prologue 3.2 k, main loop 118 k
+// (2464 per K-tile; 2048 = 128 MFMAs x 16 cycles is the floor), epilogue 7.9 k.
 // Structure (wave64, 8 waves = 2(M) x 4(N), 256x256x64 tile, one work-group per CU):
 //   * HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 16 B/lane): no VGPR round trip.  The DMA
 //     writes LDS lane-linearly, so the bank-conflict swizzle is applied to the per-lane SOURCE
@@ -13,8 +16,9 @@
 //     lives at chunk c ^ ((r >> 1) & 7) of its 128-byte LDS row -> every 16-lane ds_read_b128
 //     group hits 16 distinct 16-byte slots of the 256-byte bank row.
 //   * two LDS stages (2 x 64 KiB): tile t+1 streams in while tile t feeds 64 MFMAs per wave.
-//   * epilogue: accumulators are transposed through LDS (per-wave 64x64 fp32 patches) so that
-//     bias / GELU / gate*x+residual run on row-contiguous data and C is stored 16 B per lane.
+//   * epilogue: the 8-phase kernel accumulates C^T (operands swapped) and pairs lanes with v_permlane16_swap, so bias /
+//     GELU / gate*x+residual and the C store are 16 B per lane straight from registers (12.1 k -> 7.9 k cycles against
+//     the LDS transpose the simple kernel still uses).
 //   * several problems (image + text stream, or per-sample slices) share one launch; the 1-D
 //     grid is remapped so every XCD owns a contiguous run of tiles (private-L2 reuse of A/W panels).
 #include <cstdlib>
@@ -114,6 +118,86 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
   }
 }
 
+// LDS-free epilogue of the 8-phase kernel.  Its MFMAs are issued with the operands swapped (W fragment as "A"), so the
+// accumulator tile is C^T: lane (frow, fq) of acc[ii][jj] holds C[row ii*16 + frow][cols jj*16 + fq*4 .. +3].  One
+// v_permlane16_swap per register between the column tiles jj, jj+1 pairs the 16-lane groups fq, fq^1: afterwards an even-fq
+// lane owns 8 consecutive columns of tile jj, an odd-fq lane 8 of tile jj+1 -> every bias / gate / residual access and the
+// store are 16 bytes per lane (64 contiguous bytes per row and instruction), no LDS round trip, no barrier.
+AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq) {
+  int gcol[2];
+  bool col_ok[2];
+  float bias[2][8];
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    gcol[jp] = col_base + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;
+    col_ok[jp] = gcol[jp] < P.N;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
+    if (P.bias != nullptr && col_ok[jp]) {
+      const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol[jp]);
+      unpack8(bw, bias[jp]);
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < 8; ++ii) {
+    const int grow = row_base + ii * 16 + frow;
+    const bool row_ok = grow < P.M;
+    bool border = false;
+    if (P.conv_wp > 0) {        // convolution on the padded grid: keep the 1-pixel border zero for the next layer
+      const int yy = grow / P.conv_wp, xx = grow - yy * P.conv_wp;
+      border = yy == 0 || yy == P.conv_hp - 1 || xx == 0 || xx == P.conv_wp - 1;
+    }
+    const float* grow_gate = nullptr;
+    if (P.epi == EPI_GATE_RES && P.gate != nullptr && row_ok) grow_gate = P.gate + (int64_t)(grow / P.rows_per_batch) * P.ldg;
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * jp][e]), __float_as_uint(acc[ii][2 * jp + 1][e]), false, false);
+        v[e] = __uint_as_float(sw[0]);
+        v[4 + e] = __uint_as_float(sw[1]);
+      }
+      if (!row_ok || !col_ok[jp]) continue;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[jp][e];
+      if (P.epi == EPI_GELU) {
+        if (gcol[jp] >= P.gelu_col0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+        }
+      } else if (P.epi == EPI_GATE_RES) {
+        float g[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};      // gate == nullptr: plain residual add
+        if (grow_gate != nullptr) {
+          const f32x4_t g0 = *reinterpret_cast<const f32x4_t*>(grow_gate + gcol[jp]);
+          const f32x4_t g1 = *reinterpret_cast<const f32x4_t*>(grow_gate + gcol[jp] + 4);
+          g[0] = g0[0]; g[1] = g0[1]; g[2] = g0[2]; g[3] = g0[3]; g[4] = g1[0]; g[5] = g1[1]; g[6] = g1[2]; g[7] = g1[3];
+        }
+        const u32x4_t rw = *reinterpret_cast<const u32x4_t*>(P.res + (int64_t)grow * P.ldr + gcol[jp]);
+        float rr[8];
+        unpack8(rw, rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rr[e] + g[e] * v[e];
+      }
+      if (border) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      }
+      if (P.out_f32 == 0) {
+        *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol[jp]) = pack8(v);
+      } else {
+        float* cp = reinterpret_cast<float*>(P.C) + (int64_t)grow * P.ldc + gcol[jp];
+        f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        if (P.out_f32 == 2) {
+          o0 += *reinterpret_cast<const f32x4_t*>(cp);
+          o1 += *reinterpret_cast<const f32x4_t*>(cp + 4);
+        }
+        *reinterpret_cast<f32x4_t*>(cp) = o0;
+        *reinterpret_cast<f32x4_t*>(cp + 4) = o1;
+      }
+    }
+  }
+}
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -233,6 +317,21 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
 // phase r; WAR: see above.  Loads for tiles past K are clamped to the last tile (keeps the count uniform).
 constexpr int HALF_BYTES = 128 * BK * 2;     // 16 KiB
 
+// Cycle stamps for tools/gemm_trace.hip (compiled only with -DAFX_GEMM_TRACE): s_memtime at fixed points of ONE
+// K-iteration, kept in SGPRs and dumped after the loop.  Empty in the product build.
+#ifdef AFX_GEMM_TRACE
+__device__ unsigned int g_gemm_trace[2][8][32];
+#if AFX_GEMM_TRACE == 1
+#define AFX_TR(i) if (t == trace_t) { tr[i] = (unsigned)__builtin_readcyclecounter(); }
+#else
+#define AFX_TR(i)
+#endif
+#define AFX_TRC(i) tr[i] = (unsigned)__builtin_readcyclecounter();
+#else
+#define AFX_TR(i)
+#define AFX_TRC(i)
+#endif
+
 AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int64_t kbyte, char* slot, int wave) {
   const char* s0 = reinterpret_cast<const char*>(p0) + kbyte;
   const char* s1 = reinterpret_cast<const char*>(p1) + kbyte;
@@ -267,6 +366,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   const int tn = in_grp / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
   const int nk = P.K / BK;
+#ifdef AFX_GEMM_TRACE
+  unsigned tr[24];
+  const int trace_t = nk / 2;
+  AFX_TRC(17)
+#endif
 
   // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
   const bf16_t* src[4][2];     // [X0, X1, Y0, Y1][chunk i]
@@ -326,21 +430,27 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
     acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-        af[kk][i], BF[kk][j], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);
+        BF[kk][j], af[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);
 
-#define AFX_PHASE_TAIL(MH, NH, BF)                                                                  \
+#define AFX_PHASE_TAIL(MH, NH, BF, TI)                                                              \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_barrier();                                                                     \
+  AFX_TR(TI)                                                                                        \
   AFX_WAIT_LGKM0();                                                                                 \
+  AFX_TR(TI + 1)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
   __builtin_amdgcn_s_setprio(1);                                                                    \
   AFX_MFMA_QUAD(MH, NH, BF)                                                                         \
   __builtin_amdgcn_s_setprio(0);                                                                    \
   __builtin_amdgcn_sched_barrier(0);                                                                \
+  AFX_TR(TI + 2)                                                                                    \
   __builtin_amdgcn_s_barrier();                                                                     \
+  AFX_TR(TI + 3)                                                                                    \
   __builtin_amdgcn_sched_barrier(0);
 
+  AFX_TRC(18)
   for (int t = 0; t < nk; ++t) {
+    AFX_TR(16)
     const char* x0 = slot(t, 0);
     const char* x1 = slot(t, 1);
     const char* y0 = slot(t, 2);
@@ -355,7 +465,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
     }
     stage_half(src[3][0], src[3][1], kb(t + 1), slot(t + 1, 3), wave);   // Y1(t+1)
     AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(0, 0, b0)
+    AFX_PHASE_TAIL(0, 0, b0, 0)
     // ---- phase 1: quadrant (mh0, nh1) -----------------------------------------------------
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
@@ -363,50 +473,32 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
       for (int j = 0; j < 2; ++j) b1[kk][j] = lds_frag(y1, brow + j * 16, kk * 4 + fq);
     stage_half(src[1][0], src[1][1], ka(t + 1), slot(t + 1, 1), wave);   // X1(t+1)
     AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(0, 1, b1)
+    AFX_PHASE_TAIL(0, 1, b1, 4)
     // ---- phase 2: quadrant (mh1, nh1) -----------------------------------------------------
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[kk][i] = lds_frag(x1, arow + i * 16, kk * 4 + fq);
     stage_half(src[2][0], src[2][1], kb(t + 2), slot(t, 2), wave);       // Y0(t+2)
-    AFX_PHASE_TAIL(1, 1, b1)
+    AFX_PHASE_TAIL(1, 1, b1, 8)
     // ---- phase 3: quadrant (mh1, nh0), operands already in registers --------------------------
     stage_half(src[0][0], src[0][1], ka(t + 2), slot(t, 0), wave);       // X0(t+2)
     AFX_WAIT_VM8();
-    AFX_PHASE_TAIL(1, 0, b0)
+    AFX_PHASE_TAIL(1, 0, b0, 12)
   }
+  AFX_TRC(19)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // clamped tail DMAs must land before LDS is reused
   if (wr == 0) __builtin_amdgcn_s_barrier();         // undo the stagger
   __syncthreads();
+  AFX_TRC(20)
 
-  // ---- epilogue (identical to v1) -------------------------------------------------------------
-  float* patch = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-  const int wm = wr, wn = wc;
-  const int er = lane >> 3;
-  const int ec = (lane & 7) * 8;
-  const int gcol = n0 + wn * 64 + ec;
-  const bool col_ok = gcol < P.N;
-  float bias[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-  if (P.bias != nullptr && col_ok) {
-    const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol);
-    unpack8(bw, bias);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          patch[(i * 16 + fq * 4 + r) * EPI_LD + j * 16 + frow] = acc[h * 4 + i][j][r];
-    __syncthreads();
-    epi_store_rows(P, patch, m0 + wm * 128 + h * 64, gcol, col_ok, er, ec, bias);
-  }
+  // ---- epilogue: straight from the (transposed) accumulators ------------------------------------
+  epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq);
+#ifdef AFX_GEMM_TRACE
+  AFX_TRC(21)
+  if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0)
+    for (int i = 0; i < 22; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave][i] = tr[i];
+#endif
 }
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
@@ -435,8 +527,9 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   }
   batch.group_m = group_m;
   int use = impl;
-  for (int i = 0; i < batch.nprob; ++i)
-    if (batch.p[i].conv_cin_tiles > 0) use = 2;      // the implicit-conv addressing lives in the v2 kernel
+  bool conv = false;
+  for (int i = 0; i < batch.nprob; ++i) conv = conv || batch.p[i].conv_cin_tiles > 0;
+  if (conv) use = 2;                                 // the implicit-conv addressing lives in the 8-phase kernel
   if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else
