@@ -36,14 +36,16 @@ int main(int argc, char** argv) {
     printf("block %d: per phase [load+vmcnt+bar1 | lgkm | mfma issue | bar2]\n", blk ? 300 : 0);
     for (int wv = 0; wv < 8; ++wv) {
       unsigned* t = tr[blk][wv];
-      printf(" w%d:", wv);
       unsigned prev = t[16];
+      if (AFX_GEMM_TRACE != 1) goto coarse;
+      printf(" w%d:", wv);
       for (int q = 0; q < 4; ++q) {
         printf("  %4u %4u %4u %4u |", t[q * 4] - prev, t[q * 4 + 1] - t[q * 4], t[q * 4 + 2] - t[q * 4 + 1], t[q * 4 + 3] - t[q * 4 + 2]);
         prev = t[q * 4 + 3];
       }
       printf("  iter %u\n", t[15] - t[16]);
-      printf("      kernel: prologue %u  loop %u (%u / K-tile)  drain %u  epilogue %u  total %u\n", t[18] - t[17], t[19] - t[18],
+    coarse:
+      printf("      w%d kernel: prologue %u  loop %u (%u / K-tile)  drain %u  epilogue %u  total %u\n", wv, t[18] - t[17], t[19] - t[18],
              (t[19] - t[18]) / (K / 64), t[20] - t[19], t[21] - t[20], t[21] - t[17]);
     }
   }
