@@ -1,0 +1,136 @@
+"""Checkpoint / adapter interchange (arcflow_amd/train/checkpoint.py): key layout of the reference's iter_N.pth and
+adapter directory on CPU; save -> resume and export -> load_arcflow_adapter round trips on the GPU."""
+import json
+import os
+
+import pytest
+import torch
+
+from arcflow_amd.train import checkpoint as CK
+from arcflow_amd.train.trunk import lora_targets
+
+
+def _layout(family='flux', nd=2, ns=3, D=64, K=16, C=64, L=4, rank=8):
+    n_head = K * C + K * L + (K - 1) * L
+    head_n = (n_head + 127) // 128 * 128
+    off = [0]
+    for s in (head_n * D, head_n, 2 * D * D, 2 * D):
+        off.append(off[-1] + s)
+    lora, o = [], off[-1]
+    for name, _key, _row0, out_f, in_f in lora_targets(family, nd, ns, D):
+        lora.append((name, out_f, in_f, o, o + rank * in_f))
+        o += rank * in_f + out_f * rank
+    return CK.TrainableLayout(K, C, L, D, head_n, off, rank, lora), o
+
+
+def test_state_dict_names_follow_the_reference_layout():
+    lay, n = _layout()
+    flat = torch.arange(n, dtype=torch.float32)
+    sd = CK.flat_to_state(flat, lay, peft_names=True)
+    # heads + norm_out: the freeze_exclude list of configs/flux/arcflux_2nfe_k16.py:20-25
+    assert sd['proj_out_means.weight'].shape == (1024, 64) and sd['proj_out_logweights.bias'].shape == (64,)
+    assert sd['proj_out_loggamma.weight'].shape == (60, 64) and sd['norm_out.linear.weight'].shape == (128, 64)
+    # LoRA: peft names of the lora_target_modules of the same config (:40-48), adapter name 'default'
+    for k in ('transformer_blocks.1.ff.net.0.proj.lora_A.default.weight', 'transformer_blocks.0.ff_context.net.2.lora_B.default.weight',
+              'single_transformer_blocks.2.proj_mlp.lora_A.default.weight', 'single_transformer_blocks.0.proj_out.lora_B.default.weight'):
+        assert k in sd, k
+    assert sd['single_transformer_blocks.0.proj_out.lora_A.default.weight'].shape == (8, 5 * 64)
+    assert sd['transformer_blocks.0.ff.net.2.lora_B.default.weight'].shape == (64, 8)
+    # every element of the flat buffer except the head padding rows is owned by exactly one tensor
+    covered = sum(v.numel() for v in sd.values())
+    pad = (lay.head_n - 1148) * (lay.D + 1)
+    assert covered + pad == n
+    # and the inverse mapping restores it (accepting both the peft and the exported spelling)
+    back = torch.zeros(n)
+    assert CK.state_to_flat({k: v.half() for k, v in sd.items()}, back, lay) == []
+    exported = CK.export_adapter_state({CK.EMA_PREFIX + k: v for k, v in sd.items()}, ema=True)
+    assert 'transformer_blocks.1.ff.net.0.proj.lora_A.weight' in exported and not any('default' in k for k in exported)
+    back2 = torch.zeros(n)
+    extra = CK.state_to_flat(dict(exported, **{'time_text_embed.timestep_embedder.linear_1.lora_A.weight': torch.zeros(8, 256)}), back2, lay)
+    assert extra == ['time_text_embed.timestep_embedder.linear_1.lora_A.weight']
+    mask = torch.ones(n, dtype=torch.bool)
+    hw = mask[:lay.offsets[1]].view(lay.head_n, lay.D)
+    hw[1148:] = False
+    mask[lay.offsets[1] + 1148:lay.offsets[2]] = False
+    assert torch.equal(back2[mask], flat[mask])
+    with pytest.raises(KeyError):
+        CK.state_to_flat({'proj_out_means.weight': sd['proj_out_means.weight']}, back, lay)
+    with pytest.raises(ValueError):
+        CK.state_to_flat(dict(sd, **{'proj_out_means.bias': torch.zeros(3)}), back, lay)
+
+
+def test_qwen_layout_skips_last_txt_mlp():
+    lay, _ = _layout('qwen', nd=3, ns=0)
+    names = [l[0] for l in lay.lora]
+    assert 'transformer_blocks.2.img_mlp.net.2' in names and 'transformer_blocks.1.txt_mlp.net.0.proj' in names
+    assert not any(n.startswith('transformer_blocks.2.txt_mlp') for n in names)     # arcqwen_2nfe_k16.py:52-56 range(59)
+
+
+def _tiny_distiller(lora_rank=64):
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from tests.test_distill import _setup
+    cfg, w = _setup()
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=0, ema_start_iter=0, lora_rank=lora_rank)
+    return ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc), w
+
+
+def _cond(B=2, hp=8, wp=8, T=12, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16().cuda()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16().cuda()
+    return dict(prompt_embeds=pe, pooled=pooled, hp=hp, wp=wp)
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_is_exact(tmp_path):
+    a, _ = _tiny_distiller()
+    rng = torch.Generator(device='cuda').manual_seed(5)
+    for _ in range(2):
+        a.train_step(_cond(), 2, rng=rng)
+    path = CK.save_checkpoint(a, str(tmp_path), fp16=False)
+    assert os.path.basename(path) == 'iter_2.pth' and os.path.islink(tmp_path / 'latest.pth')
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    assert ck['meta']['iter'] == 2 and any(k.startswith('diffusion_ema.denoising.') for k in ck['state_dict'])
+    b, _ = _tiny_distiller()
+    meta = CK.load_checkpoint(b, str(tmp_path / 'latest.pth'))
+    assert meta['iter'] == 2 and b.iteration == 2 and b.opt_steps == a.opt_steps
+    lay = CK.layout_of(a)
+    sa, sb = CK.flat_to_state(a.params, lay), CK.flat_to_state(b.params, lay)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    assert torch.equal(CK.flat_to_state(a.ema, lay)['norm_out.linear.weight'], CK.flat_to_state(b.ema, lay)['norm_out.linear.weight'])
+    # the next step of the resumed run equals the next step of the original one
+    ra, rb = (torch.Generator(device='cuda').manual_seed(9) for _ in range(2))
+    ia, ib = a.train_step(_cond(seed=4), 2, rng=ra), b.train_step(_cond(seed=4), 2, rng=rb)
+    assert abs(float(ia['loss']) - float(ib['loss'])) <= 1e-6 * max(1.0, abs(float(ia['loss'])))
+    for k, v in CK.flat_to_state(a.params, lay).items():
+        assert torch.allclose(v, CK.flat_to_state(b.params, lay)[k], rtol=0, atol=1e-7), k
+
+
+@pytest.mark.gpu
+def test_exported_adapter_loads_into_the_pipeline(tmp_path):
+    from arcflow_amd.pipelines import ArcFluxPipeline
+    d, w = _tiny_distiller()
+    rng = torch.Generator(device='cuda').manual_seed(5)
+    for _ in range(2):
+        d.train_step(_cond(), 2, rng=rng)
+    out = CK.export_adapter(d, str(tmp_path / 'adapter'), ema=False, policy_kwargs=dict(denoising_mean_mode='U'))
+    cfg = json.load(open(os.path.join(out, 'config.json')))
+    assert cfg['_class_name'] == 'ArcFluxTransformer2DModel' and cfg['num_gaussians'] == 16 and cfg['logweights_channels'] == 4
+    base = {k: v for k, v in w.items() if not k.startswith('proj_out_')}
+    tcfg = dict(num_layers=1, num_single_layers=1, num_attention_heads=2, attention_head_dim=128, joint_attention_dim=128,
+                pooled_projection_dim=64, in_channels=64, guidance_embeds=True)
+    pipe = ArcFluxPipeline.from_state_dict(tcfg, base, student=False)
+    assert pipe.load_arcflow_adapter(out) == 'transformer_arcflow'
+    assert pipe.policy_config == {'denoising_mean_mode': 'U', 'type': 'ArcFlow'}
+    # the adapted student of the pipeline (LoRA folded at load) == the distiller's live student (LoRA merged per step)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(1, 64, 64, generator=g).bfloat16().cuda()
+    c = _cond(B=1)
+    t = torch.tensor([0.7], device='cuda')
+    gd = torch.full((1,), 3.5, device='cuda')
+    o1 = d.student.forward(x, t, c['prompt_embeds'], c['pooled'], gd, 8, 8)
+    o2 = pipe.transformer.forward(x, t, c['prompt_embeds'], c['pooled'], gd, 8, 8)
+    for k in ('means', 'logweights', 'loggammas'):
+        a, b = o1[k].float(), o2[k].float()
+        assert (a - b).norm() <= 2e-2 * a.norm() + 1e-3, k
