@@ -318,6 +318,46 @@ def main():
              u_teacher=u_tea, loss=loss, x_dst=x_dst, raw_dst=raw_dst,
              u_pred=captured['u_t_pred'], u_tgt=captured['u_t'], timesteps=captured['timesteps'])
 
+    golden_sampler()
+
+
+def golden_sampler():
+    """G8: rank-strided / bucketed / resumable sampler (lakonlab/datasets/samplers/distributed_sampler.py:19-158).
+    The class needs only torch + numpy; mmgen's ``sync_random_seed`` (an all-rank broadcast) is stubbed."""
+    src = open(os.path.join(REF, 'datasets/samplers/distributed_sampler.py')).read()
+    tree = ast.parse(src)
+    body = [n for n in tree.body if not (isinstance(n, ast.ImportFrom) and n.module and n.module.startswith('mmgen'))]
+    ns = {'sync_random_seed': lambda s: 0 if s is None else s}
+    exec(compile(ast.Module(body=body, type_ignores=[]), 'ref_sampler', 'exec'), ns)
+    Ref = ns['DistributedSampler']
+
+    class DS:
+        def __init__(self, n, buckets=None):
+            self.n = n
+            if buckets is not None:
+                self.bucket_ids = buckets
+
+        def __len__(self):
+            return self.n
+
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    b37 = torch.randint(0, 3, (37,), generator=g).tolist()
+    b64 = [0] * 20 + [1] * 31 + [2] * 13
+    cases = [(23, None, 2, 4, True, 7, 0, 0), (23, None, 2, 4, True, 7, 1, 2), (40, None, 8, 2, False, 0, 0, 1),
+             (64, b64, 2, 4, True, 3, 0, 0), (64, b64, 4, 2, True, 3, 2, 3), (37, b37, 2, 2, False, 0, 0, 0),
+             (64, b64, 8, 4, True, 11, 0, 0)]
+    for ci, (n, buckets, world, spg, shuffle, seed, epoch, it) in enumerate(cases):
+        for rank in range(world):
+            s = Ref(DS(n, buckets), num_replicas=world, rank=rank, shuffle=shuffle, samples_per_gpu=spg, seed=seed)
+            s.set_epoch(epoch)
+            s.set_iter(it)
+            out[f'c{ci}_r{rank}'] = np.array(list(iter(s)), dtype=np.int64)
+        out[f'c{ci}_meta'] = np.array([n, world, spg, int(shuffle), seed, epoch, it, -1 if buckets is None else 1], dtype=np.int64)
+        if buckets is not None:
+            out[f'c{ci}_buckets'] = np.array(buckets, dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, 'g8_sampler.npz'), **out)
+
 
 if __name__ == '__main__':
     main()

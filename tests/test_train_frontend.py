@@ -1,0 +1,164 @@
+"""Training front-end: sampler vs the reference class (golden g8), config reader, prompt cache."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from arcflow_amd.train import config as CFG
+from arcflow_amd.train import data as DATA
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden', 'g8_sampler.npz')
+
+
+class _DS:
+    def __init__(self, n, buckets=None):
+        self.n = n
+        if buckets is not None:
+            self.bucket_ids = buckets
+
+    def __len__(self):
+        return self.n
+
+
+def test_sampler_matches_reference_golden():
+    g = np.load(GOLD)
+    n_cases = len([k for k in g.files if k.endswith('_meta')])
+    assert n_cases == 7
+    for ci in range(n_cases):
+        n, world, spg, shuffle, seed, epoch, it, has_b = g[f'c{ci}_meta'].tolist()
+        buckets = g[f'c{ci}_buckets'].tolist() if has_b == 1 else None
+        seen = []
+        for rank in range(world):
+            s = DATA.DistributedSampler(_DS(n, buckets), world, rank, shuffle=bool(shuffle), samples_per_gpu=spg, seed=seed)
+            s.set_epoch(epoch)
+            s.set_iter(it)
+            got = np.array(list(iter(s)), dtype=np.int64)
+            assert np.array_equal(got, g[f'c{ci}_r{rank}']), (ci, rank)
+            seen.append(got)
+            if buckets is not None:          # every per-GPU batch comes from one bucket
+                for b in got.reshape(-1, spg):
+                    assert len({buckets[i] for i in b}) == 1
+        assert len(list(iter(s))) == s.num_samples      # the skip applies once (resume), then full epochs
+
+
+def test_sampler_rejects_tiny_datasets():
+    with pytest.raises(ValueError):
+        DATA.DistributedSampler(_DS(3), 2, 0, samples_per_gpu=4)
+    with pytest.raises(ValueError):
+        DATA.DistributedSampler(_DS(8, [0] * 7 + [1]), 2, 0, samples_per_gpu=2)
+
+
+def test_config_reader_merges_bases_and_maps_to_distill_config(tmp_path):
+    (tmp_path / '_base.py').write_text(
+        "train_cfg = dict(diffusion_grad_clip=50.0, diffusion_grad_clip_begin_iter=100)\n"
+        "optimizer = {'diffusion': dict(type='AdamW8bit', lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0,\n"
+        "    paramwise_cfg=dict(custom_keys={'proj_out_loggamma': dict(lr_mult=0.1)}))}\n"
+        "lr_config = dict(policy='fixed', warmup='linear', warmup_iters=100, warmup_ratio=0.001)\n"
+        "runner = dict(type='R', ckpt_trainable_only=True, ckpt_fp16=True, ckpt_fp16_ema=True)\n"
+        "model = dict(diffusion=dict(denoising=dict(freeze_exclude_autocast_dtype='bfloat16')))\n")
+    (tmp_path / 'exp.py').write_text(
+        "_base_ = ['./_base.py']\nk = 16\nname = f'exp_k{k}'\n"
+        "model = dict(type='LatentDiffusionTextImage', diffusion=dict(type='ArcFlowImitationDataFree', policy_type='ArcFlow',\n"
+        "  denoising=dict(type='ArcFluxTransformer2DModel', num_gaussians=k, logweights_channels=4, in_channels=64, num_layers=19,\n"
+        "    num_single_layers=38, attention_head_dim=128, num_attention_heads=24, joint_attention_dim=4096,\n"
+        "    pooled_projection_dim=768, guidance_embeds=True, use_lora=True, lora_dropout=0.05, lora_rank=256),\n"
+        "  flow_loss=dict(type='DiffusionMSELoss', rescale_cfg=dict(scale=30.0)),\n"
+        "  timestep_sampler=dict(type='ContinuousTimeStepSampler', shift=3.2)))\n"
+        "train_cfg = dict(num_decay_iters=2000, window_substeps=3, gm_dropout=0.1, num_intermediate_states=4,\n"
+        "  distilled_guidance_scale=3.5, nfe=2, timestep_ratio=1.0, total_substeps=128)\n"
+        "data = dict(train_dataloader=dict(samples_per_gpu=4))\n"
+        "checkpoint_config = dict(interval=500, out_dir='checkpoints/')\ntotal_iters = 10000\n"
+        "custom_hooks = [dict(type='ExponentialMovingAverageHookMod', start_iter=100, momentum_cfg=dict(gamma=7.0))]\n"
+        "resume_from = f'checkpoints/{name}/latest.pth'\n")
+    cfg = CFG.load_config(str(tmp_path / 'exp.py'))
+    assert cfg['model']['diffusion']['denoising']['freeze_exclude_autocast_dtype'] == 'bfloat16'      # from the base
+    assert cfg['train_cfg']['diffusion_grad_clip'] == 50.0 and cfg['train_cfg']['nfe'] == 2           # dicts merge
+    fam, eng, dc, run = CFG.distill_setup(cfg)
+    assert fam == 'flux' and eng['num_double'] == 19 and eng['num_single'] == 38 and eng['joint_dim'] == 4096
+    assert (dc.lr, dc.betas, dc.loggamma_lr_mult, dc.warmup_iters, dc.warmup_ratio) == (1e-4, (0.9, 0.95), 0.1, 100, 0.001)
+    assert (dc.grad_clip, dc.grad_clip_begin_iter, dc.loss_scale, dc.shift, dc.lora_rank) == (50.0, 100, 30.0, 3.2, 256)
+    assert (dc.ema_gamma, dc.ema_start_iter, dc.gm_dropout, dc.num_decay_iters) == (7.0, 100, 0.1, 2000)
+    assert run['samples_per_gpu'] == 4 and run['ckpt_fp16'] and run['ckpt_dir'] == 'checkpoints/exp_k16'
+    assert run['resume_from'] == 'checkpoints/exp_k16/latest.pth' and run['lora_dropout'] == 0.05
+    cfg2 = CFG.apply_options(cfg, {'train_cfg.nfe': 4, 'total_iters': 10})
+    assert cfg2['train_cfg']['nfe'] == 4 and cfg2['train_cfg']['gm_dropout'] == 0.1 and cfg2['total_iters'] == 10
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference tree not present')
+def test_reference_configs_load():
+    for path, fam, nd, tgs, decay in (('/root/reference/configs/flux/arcflux_2nfe_k16.py', 'flux', 19, 1.0, 2000),
+                                       ('/root/reference/configs/qwen/arcqwen_2nfe_k16.py', 'qwen', 60, 4.0, 1000)):
+        f, eng, dc, run = CFG.distill_setup(CFG.load_config(path))
+        assert (f, eng['num_double'], dc.teacher_guidance_scale, dc.num_decay_iters) == (fam, nd, tgs, decay)
+        assert dc.lora_rank == 256 and dc.lr == 1e-4 and dc.grad_clip == 50.0 and dc.loss_scale == 30.0 and dc.nfe == 2
+
+
+def test_prompt_cache_items_and_collate(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    for i, (T, size) in enumerate([(5, (16, 8, 8)), (7, (16, 8, 8)), (4, (16, 4, 12))]):
+        e, p = torch.randn(T, 32, generator=g).half(), torch.randn(16, generator=g).half()
+        if i == 1:      # legacy spelling (image_prompts.py:86-91)
+            item = dict(prompt=f'p{i}', prompt_embeds=e, prompt_embeds_scale=2.0, pooled_prompt_embeds=p, latent_size=size)
+        else:
+            item = dict(prompt=f'p{i}', prompt_embed_kwargs=dict(encoder_hidden_states=e, encoder_hidden_states_scale=2.0,
+                                                                  pooled_projections=p), latent_size=size)
+        with open(tmp_path / f'{i:04d}.pkl', 'wb') as f:
+            pickle.dump(item, f)
+    ds = DATA.PromptEmbedCache(str(tmp_path), pad_seq_len=6, bucketize=True)
+    assert len(ds) == 3 and ds.bucket_ids == [1, 1, 0]
+    a, b = ds[0], ds[1]
+    assert a['prompt_embed_kwargs']['encoder_hidden_states'].shape == (6, 32) and a['name'] == 'p0'
+    assert torch.all(a['prompt_embed_kwargs']['encoder_hidden_states'][5] == 0)                 # zero padding
+    assert b['prompt_embed_kwargs']['encoder_hidden_states'].shape == (6, 32)                   # truncation
+    raw = pickle.load(open(tmp_path / '0000.pkl', 'rb'))
+    assert torch.allclose(a['prompt_embed_kwargs']['encoder_hidden_states'][:5], raw['prompt_embed_kwargs']['encoder_hidden_states'].float() * 2.0)
+    cond = DATA.collate([a, b], device='cpu')
+    assert cond['prompt_embeds'].shape == (2, 6, 32) and cond['pooled'].shape == (2, 16) and (cond['hp'], cond['wp']) == (4, 4)
+    with pytest.raises(ValueError):
+        DATA.collate([a, ds[2]], device='cpu')
+
+
+_TINY_CFG = """
+name = 'tiny'
+model = dict(diffusion=dict(type='ArcFlowImitationDataFree', policy_type='ArcFlow', policy_kwargs=dict(),
+    denoising=dict(type='ArcFluxTransformer2DModel', num_gaussians=16, logweights_channels=4, in_channels=64, num_layers=1,
+        num_single_layers=1, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64,
+        guidance_embeds=True, use_lora=True, lora_rank=64, lora_dropout=0.0),
+    flow_loss=dict(type='DiffusionMSELoss', rescale_cfg=dict(scale=30.0)), timestep_sampler=dict(shift=3.2)))
+train_cfg = dict(num_decay_iters=4, window_substeps=3, gm_dropout=0.1, num_intermediate_states=4, nfe=2, timestep_ratio=1.0,
+                 total_substeps=128, diffusion_grad_clip=50.0, diffusion_grad_clip_begin_iter=1)
+optimizer = {'diffusion': dict(type='AdamW8bit', lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)}
+lr_config = dict(warmup_iters=2, warmup_ratio=0.001)
+runner = dict(ckpt_fp16=True, ckpt_fp16_ema=True)
+data = dict(train_dataloader=dict(samples_per_gpu=2))
+checkpoint_config = dict(interval=2, out_dir='checkpoints/')
+total_iters = 4
+custom_hooks = [dict(type='ExponentialMovingAverageHookMod', start_iter=1, momentum_cfg=dict(gamma=7.0))]
+"""
+
+
+@pytest.mark.gpu
+def test_train_cli_runs_saves_and_resumes(tmp_path):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfgp = tmp_path / 'tiny.py'
+    cfgp.write_text(_TINY_CFG)
+    base = [sys.executable, os.path.join(root, 'tools', 'train.py'), str(cfgp), '--synthetic', '--work-dir', str(tmp_path / 'w'),
+            '--latent-tokens', '8', '8', '--diff_seed']
+    r = subprocess.run(base + ['--iters', '3'], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    logs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert [l['iter'] for l in logs] == [1, 2, 3] and all(l['loss'] == l['loss'] for l in logs)
+    ck = tmp_path / 'w' / 'checkpoints'
+    assert (ck / 'iter_2.pth').exists() and (ck / 'iter_3.pth').exists() and os.readlink(ck / 'latest.pth') == 'iter_3.pth'
+    sd = torch.load(ck / 'iter_3.pth', map_location='cpu', weights_only=False)['state_dict']
+    assert sd['diffusion.denoising.proj_out_means.weight'].dtype == torch.float16          # ckpt_fp16
+    r2 = subprocess.run(base + ['--resume-from', str(ck / 'latest.pth'), '--export', str(tmp_path / 'adapter')], capture_output=True, text=True, timeout=600)
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    logs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith('{')]
+    assert [l['iter'] for l in logs2] == [4] and 'resumed from' in r2.stdout
+    assert (tmp_path / 'adapter' / 'config.json').exists() and (tmp_path / 'adapter' / 'diffusion_pytorch_model.safetensors').exists()
