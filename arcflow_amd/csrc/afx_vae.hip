@@ -164,6 +164,68 @@ __global__ __launch_bounds__(256) void latent_to_nhwc_kernel(const float* __rest
   y[g] = f32_to_bf16(v);
 }
 
+// Same unpack with a per-pixel affine map on the 16 latent channels: v = A . lat + b (A row-major [16][16]).  The Qwen-Image
+// pipeline's per-channel un-normalisation (lat * std + mean, arcqwen_pipeline.py:470-479) and the VAE's 1x1x1
+// post_quant_conv are both of this form, so their product is applied here; border and channels >= 16 stay zero.
+__global__ __launch_bounds__(256) void latent_to_nhwc_affine_kernel(const float* __restrict__ tok, bf16_t* __restrict__ y, int hp,
+                                                                    int wp, int Cpad, const float* __restrict__ A,
+                                                                    const float* __restrict__ b) {
+  const int H = 2 * hp, W = 2 * wp;
+  const int64_t total = (int64_t)(H + 2) * (W + 2) * Cpad;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  const int c = (int)(g % Cpad);
+  const int64_t p = g / Cpad;
+  const int yy = (int)(p / (W + 2)), xx = (int)(p % (W + 2));
+  float v = 0.f;
+  if (c < 16 && yy >= 1 && yy <= H && xx >= 1 && xx <= W) {
+    const int h = yy - 1, w = xx - 1;
+    const float* t = tok + ((int64_t)(h >> 1) * wp + (w >> 1)) * 64 + (h & 1) * 2 + (w & 1);
+    v = b[c];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v += A[c * 16 + k] * t[k * 4];
+  }
+  y[g] = f32_to_bf16(v);
+}
+
+// Per-pixel RMS norm over the channels of an NHWC row (QwenImageRMS_norm: F.normalize(x, dim=C) * sqrt(C) * gamma), optional
+// SiLU.  One wave per row; Creal channels carry data, channels up to Cpad are zero padding (gamma is zero there).
+__global__ __launch_bounds__(256) void rmsnorm_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int Cpad,
+                                                           int Creal, const float* __restrict__ gamma, int act) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + row * Cpad;
+  bf16_t* yr = y + row * Cpad;
+  float v[8][8];
+  float ss = 0.f;
+  const int nch = Cpad / 8;                     // 16-byte chunks per row (<= 512 channels)
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = i * 64 + lane;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+    }
+  }
+  ss = wave_sum(ss);
+  const float inv = sqrtf((float)Creal) / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int ch = i * 64 + lane;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = v[i][e] * inv * gamma[ch * 8 + e];
+        o[e] = act ? silu(t) : t;
+      }
+      *reinterpret_cast<u32x4_t*>(yr + ch * 8) = pack8(o);
+    }
+  }
+}
+
 // zero-bordered NHWC [H+2][W+2][C] bf16 -> image [3][H][W] f32
 __global__ __launch_bounds__(256) void nhwc_to_image_kernel(const bf16_t* __restrict__ x, float* __restrict__ img, int H, int W, int C) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -251,6 +313,26 @@ int afx_latent_to_nhwc(const float* tokens, void* y, int32_t hp, int32_t wp, int
   const int64_t total = (int64_t)(2 * hp + 2) * (2 * wp + 2) * Cpad;
   hipLaunchKernelGGL(latent_to_nhwc_kernel, dim3(vblocks(total)), dim3(256), 0, (hipStream_t)stream, tokens, (bf16_t*)y, hp, wp,
                      Cpad, 1.0f / scaling_factor, shift_factor);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_latent_to_nhwc_affine(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, const float* A, const float* b,
+                              void* stream) {
+  if (!tokens || !y || !A || !b || Cpad < 16 || Cpad % 8) return fail(AFX_E_INVALID, "bad argument to afx_latent_to_nhwc_affine");
+  const int64_t total = (int64_t)(2 * hp + 2) * (2 * wp + 2) * Cpad;
+  hipLaunchKernelGGL(latent_to_nhwc_affine_kernel, dim3(vblocks(total)), dim3(256), 0, (hipStream_t)stream, tokens, (bf16_t*)y, hp,
+                     wp, Cpad, A, b);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_rmsnorm_nhwc(const void* x, void* y, int64_t rows, int32_t Cpad, int32_t Creal, const float* gamma, int32_t act,
+                     void* stream) {
+  if (!x || !y || !gamma || rows < 1 || Cpad % 8 || Cpad > 4096 || Creal < 1 || Creal > Cpad)
+    return fail(AFX_E_INVALID, "afx_rmsnorm_nhwc: need Cpad % 8 == 0, Cpad <= 4096, 1 <= Creal <= Cpad");
+  hipLaunchKernelGGL(rmsnorm_nhwc_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, rows, Cpad, Creal, gamma, act);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

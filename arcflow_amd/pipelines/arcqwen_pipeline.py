@@ -49,6 +49,12 @@ class ArcQwenImagePipeline(_PipelineBase):
             sched_cfg = json.load(open(sp))
         pipe = cls(scheduler=FlowMatchEulerDiscreteScheduler.from_config(sched_cfg))
         pipe._transformer_config, pipe._base_state_dict = cfg, sd
+        if os.path.isdir(os.path.join(root, 'vae')):          # AutoencoderKLQwenImage decoder on the HIP engine
+            from ..vae import AutoencoderKLQwenImageDecoder
+            vcfg, vsd = load_transformer_dir(os.path.join(root, 'vae'))
+            pipe.vae = AutoencoderKLQwenImageDecoder(vsd, vcfg['latents_mean'], vcfg['latents_std'],
+                                                     tuple(vcfg.get('dim_mult', (1, 2, 4, 4))), vcfg.get('num_res_blocks', 2),
+                                                     vcfg.get('z_dim', 16))
         if 'proj_out.weight' in sd:
             pipe.transformer = pipe._build_engine(teacher_head=True)
             pipe.transformer.load_state_dict(sd)
@@ -102,7 +108,11 @@ class ArcQwenImagePipeline(_PipelineBase):
             image = latents
         else:
             if self.vae is None:
-                raise RuntimeError("no VAE decoder attached (SURVEY 8f f1): use output_type='latent'")
+                raise RuntimeError("no VAE decoder attached: use output_type='latent' or set pipe.vae")
+            from ..vae import AutoencoderKLQwenImageDecoder
+            if isinstance(self.vae, AutoencoderKLQwenImageDecoder):   # HIP decoder: un-normalisation + unpack fused into its first kernel
+                image = self._postprocess(self.vae.decode_packed(latents, hp, wp), output_type)
+                return (image,) if not return_dict else QwenImagePipelineOutput(images=image)
             lat = self._unpack(latents, hp, wp)[:, :, None]
             mean = torch.tensor(self.vae.config.latents_mean, device=device).view(1, -1, 1, 1, 1)
             std = torch.tensor(self.vae.config.latents_std, device=device).view(1, -1, 1, 1, 1)

@@ -37,6 +37,27 @@ class _Grid:
         self.t = self.buf[self.guard:self.guard + rows]
 
 
+def _single_head_attention(lib, xn: _Grid, x: _Grid, w_qkv, b_qkv, w_out, b_out, scale: float) -> _Grid:
+    """x + proj(softmax(q k^T * scale) v) over the H*W pixels of a grid (xn = normalised x): two MFMA GEMMs around an fp32
+    row softmax.  The token count is padded to a multiple of 64 for the GEMM contraction; padded keys get P = 0."""
+    H, W, Cn = x.H, x.W, x.C
+    N = H * W
+    dev = x.t.device
+    Np = (N + 63) // 64 * 64
+    xc = torch.zeros(Np, Cn, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.afx_interior_nhwc(_p(xn.t), _p(xc), None, H, W, Cn, 0, _s()))
+    qkv = ops.linear(xc, w_qkv, b_qkv)                                                       # [Np, 3C]
+    q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]
+    s = ops.linear_f32out(q, k)                                                              # [Np, Np] fp32 logits
+    pm = torch.zeros(Np, Np, dtype=torch.bfloat16, device=dev)
+    _lib.check(lib.afx_softmax_rows_f32(_p(s), s.stride(0), _p(pm), Np, N, N, scale, _s()))
+    o = ops.linear(pm, ops.transpose(v))                                                     # [N, C] = P V
+    oc = ops.linear(o, w_out, b_out)
+    y = _Grid(H, W, Cn, dev)
+    _lib.check(lib.afx_interior_nhwc(_p(y.t), _p(oc), _p(x.t), H, W, Cn, 1, _s()))
+    return y
+
+
 class AutoencoderKLDecoder:
     def __init__(self, state_dict: Dict[str, torch.Tensor], block_out_channels: Sequence[int] = (128, 256, 512, 512),
                  norm_num_groups: int = 32, layers_per_block: int = 2, scaling_factor: float = 0.3611,
@@ -97,22 +118,9 @@ class AutoencoderKLDecoder:
         return self._conv(p + 'conv2', self._gn(p + 'norm2', h, True), 0, res=skip)
 
     def _attention(self, p: str, x: _Grid) -> _Grid:
-        H, W, Cn = x.H, x.W, x.C
-        N = H * W
         xn = self._gn(p + 'group_norm', x, False)
-        Np = (N + 63) // 64 * 64                 # token count padded for the GEMM contraction; pad keys get P = 0
-        xc = torch.zeros(Np, Cn, dtype=torch.bfloat16, device=self.dev)
-        _lib.check(self.lib.afx_interior_nhwc(_p(xn.t), _p(xc), None, H, W, Cn, 0, _s()))
-        qkv = ops.linear(xc, self.w[p + 'qkv.weight'], self.w[p + 'qkv.bias'])                    # [Np, 3C]
-        q, k, v = qkv[:, :Cn], qkv[:, Cn:2 * Cn], qkv[:, 2 * Cn:]
-        s = ops.linear_f32out(q, k)                                                              # [Np, Np] fp32 logits
-        pm = torch.zeros(Np, Np, dtype=torch.bfloat16, device=self.dev)
-        _lib.check(self.lib.afx_softmax_rows_f32(_p(s), s.stride(0), _p(pm), Np, N, N, Cn ** -0.5, _s()))
-        o = ops.linear(pm, ops.transpose(v))                                                     # [N, C] = P V
-        oc = ops.linear(o, self.w[p + 'to_out.0.weight'], self.w[p + 'to_out.0.bias'])
-        y = _Grid(H, W, Cn, self.dev)
-        _lib.check(self.lib.afx_interior_nhwc(_p(y.t), _p(oc), _p(x.t), H, W, Cn, 1, _s()))
-        return y
+        return _single_head_attention(self.lib, xn, x, self.w[p + 'qkv.weight'], self.w[p + 'qkv.bias'],
+                                      self.w[p + 'to_out.0.weight'], self.w[p + 'to_out.0.bias'], x.C ** -0.5)
 
     # ------------------------------------------------------------------ decode
     @torch.no_grad()
@@ -140,4 +148,107 @@ class AutoencoderKLDecoder:
 
     def decode_packed(self, latents: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
         """[B, hp*wp, 64] packed latents -> [B, 3, 16hp, 16wp]."""
+        return torch.stack([self.decode_tokens(latents[b], hp, wp) for b in range(latents.shape[0])])
+
+
+def _c64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+class AutoencoderKLQwenImageDecoder:
+    """Decoder of AutoencoderKLQwenImage for single images (reference arcqwen_pipeline.py:470-481 and
+    lakonlab/models/architecture/diffusers/pretrained.py:142-149).  With one latent frame the causal 3-D convolutions
+    see two zero frames in front, so each reduces to its LAST temporal tap as a 2-D kernel and the temporal ``time_conv``
+    of the 3-D upsamplers is never reached; those 2-D kernels run as implicit GEMMs like the FLUX decoder's.  Channel
+    counts that are not multiples of 64 (96) live on grids padded to the next multiple (zero weights / gamma there).
+    The per-channel latent un-normalisation and the 1x1x1 ``post_quant_conv`` are folded into the unpack kernel."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], latents_mean: Sequence[float], latents_std: Sequence[float],
+                 dim_mult: Sequence[int] = (1, 2, 4, 4), num_res_blocks: int = 2, z_dim: int = 16, device='cuda'):
+        assert z_dim == 16, 'the packed-latent layout of the pipelines has 16 latent channels'
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.n_up, self.nrb = len(dim_mult), num_res_blocks
+        self.latents_mean, self.latents_std = list(latents_mean), list(latents_std)
+        self.config = type('cfg', (), dict(latents_mean=self.latents_mean, latents_std=self.latents_std, z_dim=z_dim))()
+        self.w: Dict[str, torch.Tensor] = {}
+        self.creal: Dict[str, int] = {}
+        sd = state_dict
+        for k in [k for k in sd if k.startswith('decoder.') and k.endswith('.weight') and 'time_conv' not in k]:
+            name = k[:-len('.weight')]
+            wt, b = sd[k].float(), sd[name + '.bias'].float()
+            if wt.dim() == 5:
+                wt = wt[:, :, -1]                                         # causal: only the last temporal tap sees the frame
+            co, ci = wt.shape[:2]
+            cop = 8 if name == 'decoder.conv_out' else _c64(co)
+            cip = _c64(ci)
+            bp = torch.zeros(cop, dtype=torch.bfloat16)
+            bp[:co] = b.to(torch.bfloat16)
+            if wt.shape[-1] == 3:                                         # 3x3 -> [Cout][tap][Cin], K-contiguous
+                wp = torch.zeros(cop, 9, cip, dtype=torch.bfloat16)
+                wp[:co, :, :ci] = wt.permute(0, 2, 3, 1).reshape(co, 9, ci).to(torch.bfloat16)
+                self.w[name + '.weight'] = wp.reshape(cop, 9 * cip).to(self.dev)
+            else:                                                         # 1x1 -> linear
+                wp = torch.zeros(cop, cip, dtype=torch.bfloat16)
+                wp[:co, :ci] = wt.reshape(co, ci).to(torch.bfloat16)
+                self.w[name + '.weight'] = wp.to(self.dev)
+            self.w[name + '.bias'] = bp.to(self.dev)
+            self.creal[name] = co
+        for k in [k for k in sd if k.startswith('decoder.') and k.endswith('.gamma')]:
+            gm = sd[k].float().flatten()
+            gp = torch.zeros(_c64(gm.numel()), dtype=torch.float32)
+            gp[:gm.numel()] = gm
+            self.w[k], self.creal[k] = gp.to(self.dev), gm.numel()
+        # v = post_quant_conv(lat * std + mean) = (Wq diag(std)) lat + (Wq mean + bq)
+        wq = sd['post_quant_conv.weight'].float().reshape(16, 16)
+        std, mean = torch.tensor(self.latents_std, dtype=torch.float32), torch.tensor(self.latents_mean, dtype=torch.float32)
+        self._A = (wq * std[None, :]).contiguous().to(self.dev)
+        self._b = (wq @ mean + sd['post_quant_conv.bias'].float()).contiguous().to(self.dev)
+
+    def _conv(self, name: str, x: _Grid, res: _Grid = None) -> _Grid:
+        w, b = self.w[name + '.weight'], self.w[name + '.bias']
+        y = _Grid(x.H, x.W, w.shape[0], self.dev)
+        _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, w.shape[0],
+                                             None if res is None else _p(res.t), _s()))
+        return y
+
+    def _norm(self, name: str, x: _Grid, act: bool) -> _Grid:
+        y = _Grid(x.H, x.W, x.C, self.dev)
+        _lib.check(self.lib.afx_rmsnorm_nhwc(_p(x.t), _p(y.t), x.t.shape[0], x.C, self.creal[name + '.gamma'],
+                                             _p(self.w[name + '.gamma']), int(act), _s()))
+        return y
+
+    def _resnet(self, p: str, x: _Grid) -> _Grid:
+        skip = x
+        if p + 'conv_shortcut.weight' in self.w:
+            skip = _Grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0], self.dev)
+            ops.linear(x.t, self.w[p + 'conv_shortcut.weight'], self.w[p + 'conv_shortcut.bias'], out=skip.t)
+        h = self._conv(p + 'conv1', self._norm(p + 'norm1', x, True))
+        return self._conv(p + 'conv2', self._norm(p + 'norm2', h, True), res=skip)
+
+    @torch.no_grad()
+    def decode_tokens(self, tokens: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
+        """tokens: packed latents [hp*wp, 64] fp32 of ONE image -> image [3, 16hp, 16wp] fp32 in [-1, 1]."""
+        x = _Grid(2 * hp, 2 * wp, 64, self.dev)
+        _lib.check(self.lib.afx_latent_to_nhwc_affine(_p(tokens.to(self.dev, torch.float32).contiguous()), _p(x.t), hp, wp, 64,
+                                                      _p(self._A), _p(self._b), _s()))
+        x = self._conv('decoder.conv_in', x)
+        x = self._resnet('decoder.mid_block.resnets.0.', x)
+        a = 'decoder.mid_block.attentions.0.'
+        x = _single_head_attention(self.lib, self._norm(a + 'norm', x, False), x, self.w[a + 'to_qkv.weight'], self.w[a + 'to_qkv.bias'],
+                                   self.w[a + 'proj.weight'], self.w[a + 'proj.bias'], self.creal[a + 'norm.gamma'] ** -0.5)
+        x = self._resnet('decoder.mid_block.resnets.1.', x)
+        for i in range(self.n_up):
+            for j in range(self.nrb + 1):
+                x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
+            if i != self.n_up - 1:
+                up = _Grid(2 * x.H, 2 * x.W, x.C, self.dev)
+                _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
+                x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.resample.1', up)
+        x = self._conv('decoder.conv_out', self._norm('decoder.norm_out', x, True))
+        img = torch.empty(3, x.H, x.W, dtype=torch.float32, device=self.dev)
+        _lib.check(self.lib.afx_nhwc_to_image(_p(x.t), _p(img), x.H, x.W, x.C, _s()))
+        return img.clamp_(-1.0, 1.0)
+
+    def decode_packed(self, latents: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
         return torch.stack([self.decode_tokens(latents[b], hp, wp) for b in range(latents.shape[0])])

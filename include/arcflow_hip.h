@@ -239,6 +239,13 @@ int afx_softmax_rows_f32(const float* s, int64_t lds_, void* p, int64_t ldp, int
 int afx_latent_to_nhwc(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, float scaling_factor,
                        float shift_factor, void* stream);
 int afx_nhwc_to_image(const void* x, float* img, int32_t H, int32_t W, int32_t C, void* stream);
+/* AutoencoderKLQwenImage (lakonlab/pipelines/arcqwen_pipeline.py:470-481): the unpack applies v = A . lat + b on the 16
+ * latent channels per pixel (A [16][16] row-major = post_quant_conv . diag(latents_std), b = post_quant_conv . mean + bias);
+ * the norm is the per-pixel channel RMS norm of that VAE, y = x / max(|x|_2, 1e-12) * sqrt(Creal) * gamma, act 1 = SiLU */
+int afx_latent_to_nhwc_affine(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, const float* A, const float* b,
+                              void* stream);
+int afx_rmsnorm_nhwc(const void* x, void* y, int64_t rows, int32_t Cpad, int32_t Creal, const float* gamma, int32_t act,
+                     void* stream);
 
 /* ---- building-block kernels (exported for the per-kernel parity tests and micro benches) -- */
 

@@ -80,3 +80,74 @@ def test_pipeline_decodes_images_end_to_end():
     pil = pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, latents=lat, width=64, height=64, num_inference_steps=2,
                timestep_ratio=1.0).images[0]
     assert pil.size == (64, 64)
+
+
+def test_rmsnorm_nhwc_padded_channels():
+    import ctypes as C
+    from arcflow_amd import _lib
+    from arcflow_amd.vae import _p, _s
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    rows, creal, cpad = 37, 96, 128
+    x = torch.zeros(rows, cpad)
+    x[:, :creal] = torch.randn(rows, creal, generator=g)
+    x[5] = 0                                           # a border row stays exactly zero
+    gamma = torch.zeros(cpad)
+    gamma[:creal] = 1 + 0.1 * torch.randn(creal, generator=g)
+    xb = x.bfloat16().cuda()
+    for act in (0, 1):
+        y = torch.empty_like(xb)
+        _lib.check(lib.afx_rmsnorm_nhwc(_p(xb), _p(y), rows, cpad, creal, _p(gamma.cuda()), act, _s()))
+        ref = torch.nn.functional.normalize(xb.float().cpu()[:, :creal], dim=1) * creal ** 0.5 * gamma[:creal]
+        ref = torch.nn.functional.silu(ref) if act else ref
+        got = y.float().cpu()
+        assert (got[:, :creal] - ref).abs().max().item() < 2e-2
+        assert got[:, creal:].abs().max().item() == 0 and got[5].abs().max().item() == 0
+
+
+@pytest.mark.parametrize('hp,wp,dim', [(4, 4, 32), (3, 5, 96)])
+def test_qwen_decoder_vs_oracle(hp, wp, dim):
+    """dim=96 is the released width (384/192/96 channels: the 96-channel stage runs on grids padded to 128)."""
+    from arcflow_amd.vae import AutoencoderKLQwenImageDecoder
+    from oracle import arcflow_ref as R
+    from oracle import vae_qwen_ref as V
+    w = V.make_decoder_weights(dim=dim, seed=1)
+    g = torch.Generator().manual_seed(2)
+    mean = (torch.randn(16, generator=g) * 0.3).tolist()
+    std = (1.0 + 0.5 * torch.rand(16, generator=g)).tolist()
+    tok = torch.randn(1, hp * wp, 64, generator=g)
+    dec = AutoencoderKLQwenImageDecoder(w, mean, std)
+    img = dec.decode_packed(tok.cuda(), hp, wp)
+    z = R.unpack_latents(tok, hp, wp) * torch.tensor(std).view(1, 16, 1, 1) + torch.tensor(mean).view(1, 16, 1, 1)
+    ref = V.decode(w, z)
+    assert img.shape == ref.shape == (1, 3, 16 * hp, 16 * wp)
+    rel = ((img.cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-2, rel
+    assert img.abs().max().item() <= 1.0
+
+
+def test_qwen_pipeline_decodes_images_end_to_end():
+    from arcflow_amd import FlowMatchEulerDiscreteScheduler
+    from arcflow_amd.pipelines import ArcQwenImagePipeline
+    from arcflow_amd.vae import AutoencoderKLQwenImageDecoder
+    from oracle import dit_ref as D
+    from oracle import vae_qwen_ref as V
+    cfg = D.QwenCfg(num_layers=2, heads=2, joint_dim=128)
+    w = D.make_qwen_weights(cfg, seed=9)
+    tcfg = dict(num_layers=2, num_attention_heads=2, attention_head_dim=128, in_channels=64, joint_attention_dim=128)
+    pipe = ArcQwenImagePipeline.from_state_dict(tcfg, w, scheduler=FlowMatchEulerDiscreteScheduler(shift=3.2))
+    vw = V.make_decoder_weights(dim=32, seed=3)
+    g = torch.Generator().manual_seed(4)
+    mean, std = (torch.randn(16, generator=g) * 0.3).tolist(), (1.0 + 0.5 * torch.rand(16, generator=g)).tolist()
+    pipe.vae = AutoencoderKLQwenImageDecoder(vw, mean, std)
+    pe = (torch.randn(1, 12, 128, generator=g) * 0.5).bfloat16()
+    lat = torch.randn(1, 16, 64, generator=g)
+    out_lat = pipe(prompt_embeds=pe, prompt_embeds_mask=torch.ones(1, 12, dtype=torch.long), latents=lat, width=64, height=64,
+                   num_inference_steps=2, timestep_ratio=1.0, output_type='latent').images
+    img = pipe(prompt_embeds=pe, prompt_embeds_mask=torch.ones(1, 12, dtype=torch.long), latents=lat, width=64, height=64,
+               num_inference_steps=2, timestep_ratio=1.0, output_type='pt').images
+    from oracle import arcflow_ref as R
+    z = R.unpack_latents(out_lat.float().cpu(), 4, 4) * torch.tensor(std).view(1, 16, 1, 1) + torch.tensor(mean).view(1, 16, 1, 1)
+    ref = V.decode(vw, z)
+    assert img.shape == (1, 3, 64, 64)
+    assert ((img.float().cpu() - ref).norm() / ref.norm()).item() < 3e-2
