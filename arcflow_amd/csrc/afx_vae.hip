@@ -15,31 +15,50 @@
 
 namespace afx {
 
-// ---- GroupNorm statistics: stats[b][g] = {sum, sum of squares} in fp64 (border rows are zero and do not count) ----
+// ---- GroupNorm statistics: stats[g] = {sum, sum of squares} in fp64 (border rows are zero and do not count) ----
+// Every thread owns one 16-byte channel chunk and strides over the rows (the grid is sized to ~4 blocks per CU, so the
+// fp64 atomics on the 2 * groups result words stay in the low thousands).
 __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, int64_t rows, int C, int groups,
-                                                       double* __restrict__ stats, int rows_per_block) {
+                                                       double* __restrict__ stats) {
   __shared__ float part[64][2];
   const int cpr = C >> 3;                       // 16-byte chunks per row
   const int gs = C / groups;                    // channels per group (>= 4)
   if (threadIdx.x < 64) part[threadIdx.x][0] = part[threadIdx.x][1] = 0.f;
   __syncthreads();
-  const int c = threadIdx.x % cpr;
-  const int rl = threadIdx.x / cpr, rstep = 256 / cpr;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const int rstep = 256 / cpr;
+  const int c = threadIdx.x % cpr, rl = threadIdx.x / cpr;
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  for (int64_t r = r0 + rl; r < r1; r += rstep) {
-    float v[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
+  if (rl < rstep) {
+    const int64_t stride = (int64_t)gridDim.x * rstep;
+    int64_t r = (int64_t)blockIdx.x * rstep + rl;
+    for (; r + 3 * stride < rows; r += 4 * stride) {        // four independent 16-byte loads in flight per lane
+      u32x4_t w4[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s0 += v[e]; q0 += v[e] * v[e];
-      s1 += v[4 + e]; q1 += v[4 + e] * v[4 + e];
+      for (int u = 0; u < 4; ++u) w4[u] = *reinterpret_cast<const u32x4_t*>(x + (r + u * stride) * C + c * 8);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack8(w4[u], v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0 += v[e]; q0 += v[e] * v[e];
+          s1 += v[4 + e]; q1 += v[4 + e] * v[4 + e];
+        }
+      }
     }
+    for (; r < rows; r += stride) {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        s0 += v[e]; q0 += v[e] * v[e];
+        s1 += v[4 + e]; q1 += v[4 + e] * v[4 + e];
+      }
+    }
+    const int g0 = (c * 8) / gs, g1 = (c * 8 + 4) / gs;
+    atomicAdd(&part[g0][0], s0); atomicAdd(&part[g0][1], q0);
+    atomicAdd(&part[g1][0], s1); atomicAdd(&part[g1][1], q1);
   }
-  const int g0 = (c * 8) / gs, g1 = (c * 8 + 4) / gs;
-  atomicAdd(&part[g0][0], s0); atomicAdd(&part[g0][1], q0);
-  atomicAdd(&part[g1][0], s1); atomicAdd(&part[g1][1], q1);
   __syncthreads();
   if (threadIdx.x < groups) {
     atomicAdd(stats + threadIdx.x * 2, (double)part[threadIdx.x][0]);
@@ -47,37 +66,46 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
-// y = act((x - mean_g) rstd_g gamma_c + beta_c), border pixels forced to 0.  act: 0 none, 1 SiLU.
+// per-channel affine of the normalisation: y = x * coef[c] + coef[C + c]
+__global__ void gn_coeff_kernel(const double* __restrict__ stats, double count, int C, int groups, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, float* __restrict__ coef) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= C) return;
+  const int gi = ch / (C / groups);
+  const double mean = stats[gi * 2] / count;
+  const double var = stats[gi * 2 + 1] / count - mean * mean;
+  const float a = rsqrtf((float)var + eps) * gamma[ch];
+  coef[ch] = a;
+  coef[C + ch] = beta[ch] - (float)mean * a;
+}
+
+// y = act(x * a_c + b_c), border pixels forced to 0.  act: 0 none, 1 SiLU.  One 16-byte chunk column per thread.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int C,
-                                                       int groups, const double* __restrict__ stats, double count,
-                                                       const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                       int act, int hp, int wp) {
+                                                       const float* __restrict__ coef, int act, int hp, int wp) {
   const int cpr = C >> 3;
-  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= rows * cpr) return;
-  const int64_t r = g / cpr;
-  const int c = (int)(g % cpr);
-  const int yy = (int)((r % ((int64_t)hp * wp)) / wp), xx = (int)(r % wp);
-  float o[8];
-  if (yy == 0 || yy == hp - 1 || xx == 0 || xx == wp - 1) {
+  const int rstep = 256 / cpr;
+  const int c = threadIdx.x % cpr, rl = threadIdx.x / cpr;
+  if (rl >= rstep) return;
+  float a[8], b[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = 0.f;
-  } else {
-    float v[8];
-    unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
-    const int gs = C / groups;
+  for (int e = 0; e < 8; ++e) { a[e] = coef[c * 8 + e]; b[e] = coef[C + c * 8 + e]; }
+  for (int64_t r = (int64_t)blockIdx.x * rstep + rl; r < rows; r += (int64_t)gridDim.x * rstep) {
+    const int yy = (int)(r / wp), xx = (int)(r - (int64_t)yy * wp);
+    float o[8];
+    if (yy == 0 || yy == hp - 1 || xx == 0 || xx == wp - 1) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ch = c * 8 + e;
-      const int gi = ch / gs;
-      const double mean = stats[gi * 2] / count;
-      const double var = stats[gi * 2 + 1] / count - mean * mean;
-      const float rstd = rsqrtf((float)var + eps);
-      float t = (v[e] - (float)mean) * rstd * gamma[ch] + beta[ch];
-      o[e] = act ? silu(t) : t;
+      for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    } else {
+      float v[8];
+      unpack8(*reinterpret_cast<const u32x4_t*>(x + r * C + c * 8), v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = v[e] * a[e] + b[e];
+        o[e] = act ? silu(t) : t;
+      }
     }
+    *reinterpret_cast<u32x4_t*>(y + r * C + c * 8) = pack8(o);
   }
-  *reinterpret_cast<u32x4_t*>(y + r * C + c * 8) = pack8(o);
 }
 
 // nearest 2x upsample between zero-bordered NHWC grids: out[(2h+a+1), (2w+b+1)] = in[h+1, w+1]
@@ -189,39 +217,44 @@ __global__ __launch_bounds__(256) void latent_to_nhwc_affine_kernel(const float*
 }
 
 // Per-pixel RMS norm over the channels of an NHWC row (QwenImageRMS_norm: F.normalize(x, dim=C) * sqrt(C) * gamma), optional
-// SiLU.  One wave per row; Creal channels carry data, channels up to Cpad are zero padding (gamma is zero there).
+// SiLU.  Creal channels carry data, channels up to Cpad are zero padding (gamma is zero there).  A row of Cpad <= 512
+// channels is <= 64 16-byte chunks: LP = next power of two lanes share a row, 64 / LP rows per wave-load, the sum of squares
+// is reduced inside the lane group; every lane keeps its gamma chunk in registers and strides over the rows.
+template <int LP>
 __global__ __launch_bounds__(256) void rmsnorm_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int64_t rows, int Cpad,
                                                            int Creal, const float* __restrict__ gamma, int act) {
+  constexpr int RPW = 64 / LP;                  // rows per wave-load
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const bf16_t* xr = x + row * Cpad;
-  bf16_t* yr = y + row * Cpad;
-  float v[8][8];
-  float ss = 0.f;
-  const int nch = Cpad / 8;                     // 16-byte chunks per row (<= 512 channels)
+  const int sub = lane % LP, rsel = lane / LP;
+  const int nch = Cpad >> 3;
+  const bool live = sub < nch;
+  float gm[8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ch = i * 64 + lane;
-    if (ch < nch) {
-      unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), v[i]);
+  for (int e = 0; e < 8; ++e) gm[e] = live ? gamma[sub * 8 + e] : 0.f;
+  const float sc = sqrtf((float)Creal);
+  const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t nwave = (int64_t)gridDim.x * 4;
+  for (int64_t r0 = wave * RPW; r0 < rows; r0 += nwave * RPW) {
+    const int64_t row = r0 + rsel;
+    const bool ok = live && row < rows;
+    float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
-    }
-  }
-  ss = wave_sum(ss);
-  const float inv = sqrtf((float)Creal) / fmaxf(sqrtf(ss), 1e-12f);
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (ok) unpack8(*reinterpret_cast<const u32x4_t*>(x + row * Cpad + sub * 8), v);
+    float ss = 0.f;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int ch = i * 64 + lane;
-    if (ch < nch) {
+    for (int e = 0; e < 8; ++e) ss += v[e] * v[e];
+#pragma unroll
+    for (int o = LP / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float inv = sc / fmaxf(sqrtf(ss), 1e-12f);
+    if (ok) {
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = v[i][e] * inv * gamma[ch * 8 + e];
+        const float t = v[e] * inv * gm[e];
         o[e] = act ? silu(t) : t;
       }
-      *reinterpret_cast<u32x4_t*>(yr + ch * 8) = pack8(o);
+      *reinterpret_cast<u32x4_t*>(y + row * Cpad + sub * 8) = pack8(o);
     }
   }
 }
@@ -267,17 +300,20 @@ int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, in
 
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
-  if (!x || !y || !stats_ws || !gamma || !beta || C % 8 || groups < 1 || groups > 64 || C % groups || (C / groups) % 4)
+  if (!x || !y || !stats_ws || !gamma || !beta || C % 8 || groups < 1 || groups > 64 || C % groups || (C / groups) % 4 || 256 % (C >> 3))
     return fail(AFX_E_INVALID, "bad argument to afx_groupnorm_nhwc");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)(H + 2) * (W + 2);
+  if (C > 2048) return fail(AFX_E_INVALID, "afx_groupnorm_nhwc: C <= 2048");
   HIP_TRY(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * groups, st));
-  const int rpb = 128;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, (const bf16_t*)x, rows, C,
-                     groups, stats_ws, rpb);
+  const int rstep = 256 / (C >> 3);
+  const unsigned nblk = (unsigned)std::min<int64_t>(2048, (rows + rstep - 1) / rstep);
+  float* coef = reinterpret_cast<float*>(stats_ws + 2 * groups);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, rows, C, groups, stats_ws);
   const double count = (double)H * W * (C / groups);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(vblocks(rows * (C >> 3))), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, C,
-                     groups, stats_ws, count, gamma, beta, eps, act, H + 2, W + 2);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, count, C, groups, gamma, beta, eps, coef);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(4096, (rows + rstep - 1) / rstep)), dim3(256), 0, st,
+                     (const bf16_t*)x, (bf16_t*)y, rows, C, coef, act, H + 2, W + 2);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }
@@ -329,10 +365,19 @@ int afx_latent_to_nhwc_affine(const float* tokens, void* y, int32_t hp, int32_t 
 
 int afx_rmsnorm_nhwc(const void* x, void* y, int64_t rows, int32_t Cpad, int32_t Creal, const float* gamma, int32_t act,
                      void* stream) {
-  if (!x || !y || !gamma || rows < 1 || Cpad % 8 || Cpad > 4096 || Creal < 1 || Creal > Cpad)
-    return fail(AFX_E_INVALID, "afx_rmsnorm_nhwc: need Cpad % 8 == 0, Cpad <= 4096, 1 <= Creal <= Cpad");
-  hipLaunchKernelGGL(rmsnorm_nhwc_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                     (bf16_t*)y, rows, Cpad, Creal, gamma, act);
+  if (!x || !y || !gamma || rows < 1 || Cpad % 8 || Cpad > 512 || Creal < 1 || Creal > Cpad)
+    return fail(AFX_E_INVALID, "afx_rmsnorm_nhwc: need Cpad %% 8 == 0, Cpad <= 512, 1 <= Creal <= Cpad");
+  const int nch = Cpad >> 3;
+  const int lp = nch <= 8 ? 8 : nch <= 16 ? 16 : nch <= 32 ? 32 : 64;
+  const int64_t loads = (rows + (64 / lp) - 1) / (64 / lp);                 // wave-loads of 64 / lp rows
+  const dim3 grid((unsigned)std::min<int64_t>(4096, (loads + 3) / 4)), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xi = (const bf16_t*)x;
+  bf16_t* yo = (bf16_t*)y;
+  if (lp == 8) hipLaunchKernelGGL(rmsnorm_nhwc_kernel<8>, grid, blk, 0, st, xi, yo, rows, Cpad, Creal, gamma, act);
+  else if (lp == 16) hipLaunchKernelGGL(rmsnorm_nhwc_kernel<16>, grid, blk, 0, st, xi, yo, rows, Cpad, Creal, gamma, act);
+  else if (lp == 32) hipLaunchKernelGGL(rmsnorm_nhwc_kernel<32>, grid, blk, 0, st, xi, yo, rows, Cpad, Creal, gamma, act);
+  else hipLaunchKernelGGL(rmsnorm_nhwc_kernel<64>, grid, blk, 0, st, xi, yo, rows, Cpad, Creal, gamma, act);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -29,12 +29,34 @@ class _Grid:
     """Zero-bordered NHWC activation [(H+2)*(W+2), C] with guard rows on both sides (the shifted taps of the implicit
     GEMM read up to W+3 rows outside the grid; what they produce lands on border rows, which the epilogue zeroes)."""
 
-    def __init__(self, H: int, W: int, Cn: int, device):
+    def __init__(self, H: int, W: int, Cn: int, device, buf: torch.Tensor = None):
         self.H, self.W, self.C = H, W, Cn
         self.guard = W + 3
         rows = (H + 2) * (W + 2)
-        self.buf = torch.zeros(rows + 2 * self.guard, Cn, dtype=torch.bfloat16, device=device)
+        self.buf = torch.zeros(rows + 2 * self.guard, Cn, dtype=torch.bfloat16, device=device) if buf is None else buf
         self.t = self.buf[self.guard:self.guard + rows]
+
+
+class _GridPool:
+    """Recycles activation grids between layers and decodes.  Every producer kernel rewrites the whole grid INCLUDING its
+    zero border (conv / linear epilogues, norm kernels, upsample), and nothing ever writes the guard rows, so a recycled
+    buffer needs no re-zeroing.  A ring of 6 buffers per shape covers the longest live range of a ResNet block (input kept
+    for the residual while norm1 / conv1 / norm2 / conv2 outputs are produced)."""
+    RING = 6
+
+    def __init__(self, device):
+        self.dev = device
+        self.rings = {}
+
+    def grid(self, H: int, W: int, Cn: int) -> _Grid:
+        ring = self.rings.setdefault((H, W, Cn), [[], 0])
+        if len(ring[0]) < self.RING:
+            g = _Grid(H, W, Cn, self.dev)
+            ring[0].append(g.buf)
+            return g
+        buf = ring[0][ring[1] % self.RING]
+        ring[1] += 1
+        return _Grid(H, W, Cn, self.dev, buf)
 
 
 def _single_head_attention(lib, xn: _Grid, x: _Grid, w_qkv, b_qkv, w_out, b_out, scale: float) -> _Grid:
@@ -93,18 +115,19 @@ class AutoencoderKLDecoder:
         a = 'decoder.mid_block.attentions.0.'
         self.w[a + 'qkv.weight'] = torch.cat([self.w[a + n + '.weight'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
         self.w[a + 'qkv.bias'] = torch.cat([self.w[a + n + '.bias'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
-        self._stats = torch.zeros(128, dtype=torch.float64, device=self.dev)
+        self._stats = torch.zeros(128 + 2048, dtype=torch.float64, device=self.dev)   # 2*groups doubles + 2*C floats
+        self._pool = _GridPool(self.dev)
 
     # ------------------------------------------------------------------ primitives on grids
     def _conv(self, name: str, x: _Grid, cout: int, res: _Grid = None) -> _Grid:
         w, b = self.w[name + '.weight'], self.w[name + '.bias']
-        y = _Grid(x.H, x.W, w.shape[0], self.dev)
+        y = self._pool.grid(x.H, x.W, w.shape[0])
         _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, w.shape[0],
                                              None if res is None else _p(res.t), _s()))
         return y
 
     def _gn(self, name: str, x: _Grid, act: bool) -> _Grid:
-        y = _Grid(x.H, x.W, x.C, self.dev)
+        y = self._pool.grid(x.H, x.W, x.C)
         _lib.check(self.lib.afx_groupnorm_nhwc(_p(x.t), _p(y.t), _p(self._stats), x.H, x.W, x.C, self.groups,
                                                _p(self.w[name + '.weight']), _p(self.w[name + '.bias']), 1e-6, int(act), _s()))
         return y
@@ -113,7 +136,7 @@ class AutoencoderKLDecoder:
         h = self._conv(p + 'conv1', self._gn(p + 'norm1', x, True), 0)
         skip = x
         if p + 'conv_shortcut.weight' in self.w:
-            skip = _Grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0], self.dev)
+            skip = self._pool.grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0])
             ops.linear(x.t, self.w[p + 'conv_shortcut.weight'], self.w[p + 'conv_shortcut.bias'], out=skip.t)
         return self._conv(p + 'conv2', self._gn(p + 'norm2', h, True), 0, res=skip)
 
@@ -126,7 +149,7 @@ class AutoencoderKLDecoder:
     @torch.no_grad()
     def decode_tokens(self, tokens: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
         """tokens: packed latents [hp*wp, 64] fp32 (the loop's output for ONE image) -> image [3, 16hp, 16wp] fp32."""
-        x = _Grid(2 * hp, 2 * wp, 64, self.dev)
+        x = self._pool.grid(2 * hp, 2 * wp, 64)
         _lib.check(self.lib.afx_latent_to_nhwc(_p(tokens.to(self.dev, torch.float32).contiguous()), _p(x.t), hp, wp, 64,
                                                self.scaling_factor, self.shift_factor, _s()))
         x = self._conv('decoder.conv_in', x, 0)
@@ -138,7 +161,7 @@ class AutoencoderKLDecoder:
             for j in range(self.lpb + 1):
                 x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
             if i < n - 1:
-                up = _Grid(2 * x.H, 2 * x.W, x.C, self.dev)
+                up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
                 _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
                 x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.conv', up, 0)
         x = self._conv('decoder.conv_out', self._gn('decoder.conv_norm_out', x, True), 0)
@@ -202,18 +225,19 @@ class AutoencoderKLQwenImageDecoder:
         # v = post_quant_conv(lat * std + mean) = (Wq diag(std)) lat + (Wq mean + bq)
         wq = sd['post_quant_conv.weight'].float().reshape(16, 16)
         std, mean = torch.tensor(self.latents_std, dtype=torch.float32), torch.tensor(self.latents_mean, dtype=torch.float32)
+        self._pool = _GridPool(self.dev)
         self._A = (wq * std[None, :]).contiguous().to(self.dev)
         self._b = (wq @ mean + sd['post_quant_conv.bias'].float()).contiguous().to(self.dev)
 
     def _conv(self, name: str, x: _Grid, res: _Grid = None) -> _Grid:
         w, b = self.w[name + '.weight'], self.w[name + '.bias']
-        y = _Grid(x.H, x.W, w.shape[0], self.dev)
+        y = self._pool.grid(x.H, x.W, w.shape[0])
         _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, w.shape[0],
                                              None if res is None else _p(res.t), _s()))
         return y
 
     def _norm(self, name: str, x: _Grid, act: bool) -> _Grid:
-        y = _Grid(x.H, x.W, x.C, self.dev)
+        y = self._pool.grid(x.H, x.W, x.C)
         _lib.check(self.lib.afx_rmsnorm_nhwc(_p(x.t), _p(y.t), x.t.shape[0], x.C, self.creal[name + '.gamma'],
                                              _p(self.w[name + '.gamma']), int(act), _s()))
         return y
@@ -221,7 +245,7 @@ class AutoencoderKLQwenImageDecoder:
     def _resnet(self, p: str, x: _Grid) -> _Grid:
         skip = x
         if p + 'conv_shortcut.weight' in self.w:
-            skip = _Grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0], self.dev)
+            skip = self._pool.grid(x.H, x.W, self.w[p + 'conv_shortcut.weight'].shape[0])
             ops.linear(x.t, self.w[p + 'conv_shortcut.weight'], self.w[p + 'conv_shortcut.bias'], out=skip.t)
         h = self._conv(p + 'conv1', self._norm(p + 'norm1', x, True))
         return self._conv(p + 'conv2', self._norm(p + 'norm2', h, True), res=skip)
@@ -229,7 +253,7 @@ class AutoencoderKLQwenImageDecoder:
     @torch.no_grad()
     def decode_tokens(self, tokens: torch.Tensor, hp: int, wp: int) -> torch.Tensor:
         """tokens: packed latents [hp*wp, 64] fp32 of ONE image -> image [3, 16hp, 16wp] fp32 in [-1, 1]."""
-        x = _Grid(2 * hp, 2 * wp, 64, self.dev)
+        x = self._pool.grid(2 * hp, 2 * wp, 64)
         _lib.check(self.lib.afx_latent_to_nhwc_affine(_p(tokens.to(self.dev, torch.float32).contiguous()), _p(x.t), hp, wp, 64,
                                                       _p(self._A), _p(self._b), _s()))
         x = self._conv('decoder.conv_in', x)
@@ -242,7 +266,7 @@ class AutoencoderKLQwenImageDecoder:
             for j in range(self.nrb + 1):
                 x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
             if i != self.n_up - 1:
-                up = _Grid(2 * x.H, 2 * x.W, x.C, self.dev)
+                up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
                 _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
                 x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.resample.1', up)
         x = self._conv('decoder.conv_out', self._norm('decoder.norm_out', x, True))

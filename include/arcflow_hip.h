@@ -224,7 +224,8 @@ int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
  * re-zeroes the border.  x must be readable (W+3) rows before and after the grid.  w: [Cout][3][3][Cin] bf16. */
 int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
                      int32_t Cout, const void* res, void* stream);
-/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: 2*groups doubles of scratch; act 1 = SiLU */
+/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: 2*groups doubles + 2*C floats of scratch; act 1 = SiLU;
+ * C/8 must divide 256 (C = 64, 128, 256, 512, 1024, 2048) */
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream);
 int afx_upsample2x_nhwc(const void* x, void* y, int32_t H, int32_t W, int32_t C, void* stream);
@@ -241,7 +242,8 @@ int afx_latent_to_nhwc(const float* tokens, void* y, int32_t hp, int32_t wp, int
 int afx_nhwc_to_image(const void* x, float* img, int32_t H, int32_t W, int32_t C, void* stream);
 /* AutoencoderKLQwenImage (lakonlab/pipelines/arcqwen_pipeline.py:470-481): the unpack applies v = A . lat + b on the 16
  * latent channels per pixel (A [16][16] row-major = post_quant_conv . diag(latents_std), b = post_quant_conv . mean + bias);
- * the norm is the per-pixel channel RMS norm of that VAE, y = x / max(|x|_2, 1e-12) * sqrt(Creal) * gamma, act 1 = SiLU */
+ * the norm is the per-pixel channel RMS norm of that VAE, y = x / max(|x|_2, 1e-12) * sqrt(Creal) * gamma, act 1 = SiLU,
+ * Cpad <= 512 */
 int afx_latent_to_nhwc_affine(const float* tokens, void* y, int32_t hp, int32_t wp, int32_t Cpad, const float* A, const float* b,
                               void* stream);
 int afx_rmsnorm_nhwc(const void* x, void* y, int64_t rows, int32_t Cpad, int32_t Creal, const float* gamma, int32_t act,
