@@ -15,18 +15,20 @@
 //
 // Work-group = 4 waves x 32 queries; K tile [64 keys][128 d] and V^T tile [128 d][64 keys] stream
 // HBM -> LDS by LDS-DMA into a 2-stage ring with an XOR swizzle (conflict-free ds_read_b128 reads).
+//
+// The kernel is a template <head dim, EXT>.  <128, false> is the MMDiT product path above.  EXT = true adds what the
+// text encoders need (afx_text.hip): a runtime softmax scale, causal masking with tile skipping, an additive
+// relative-position bias table (T5), grouped KV heads (Qwen2.5), and head dim 64 (T5, CLIP).
 #include "afx_common.h"
 #include "afx_kernels.h"
 
 namespace afx {
 
-constexpr int HD = 128;            // head dim
 constexpr int KVB = 64;            // keys per tile
 constexpr int QW = 32;             // queries per wave
 constexpr int ATT_WAVES = 4;
 constexpr int ATT_THREADS = ATT_WAVES * 64;
 constexpr int QB = ATT_WAVES * QW; // queries per work-group
-constexpr int STAGE_BYTES = 2 * KVB * HD * 2;
 constexpr float RESCALE_LOG2 = 5.0f;   // defer the O rescale until a row max grew by > 2^5
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -38,15 +40,17 @@ AFX_DEV int key_of_pos(int p) { return 4 * (p >> 3) + (p & 3) + 8 * ((p >> 2) & 
 // ---------------------------------------------------------------------------------------------
 // V [B*S rows, ldv] (head h at column h*128)  ->  Vt [B][H][128][S_pad], keys permuted per 16-group,
 // keys >= S zero-filled.
+template <int HD>
 __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restrict__ v, int64_t ldv,
                                                           bf16_t* __restrict__ vt, int H, int S, int S_pad) {
   __shared__ bf16_t tile[KVB][HD + 2];
   const int kv0 = blockIdx.x * KVB, h = blockIdx.y, b = blockIdx.z;
   const int tid = threadIdx.x;
+  constexpr int CPR = HD / 8;                         // 16-byte chunks per row
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < KVB * CPR / 256; ++i) {
     const int p = i * 256 + tid;
-    const int r = p >> 4, c = p & 15;
+    const int r = p / CPR, c = p % CPR;
     u32x4_t w = (u32x4_t){0u, 0u, 0u, 0u};
     if (kv0 + r < S) w = *reinterpret_cast<const u32x4_t*>(v + ((int64_t)b * S + kv0 + r) * ldv + h * HD + c * 8);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&tile[r][c * 8]);   // (HD+2)*2 = 260 B rows: 4-byte aligned
@@ -55,7 +59,7 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restri
   __syncthreads();
   bf16_t* out = vt + ((int64_t)(b * H + h) * HD) * S_pad + kv0;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < HD / 32; ++i) {
     const int d = i * 32 + (tid >> 3);
     const int c = tid & 7;                          // 8 consecutive storage positions c*8 .. c*8+7
     uint32_t w[4];
@@ -73,16 +77,28 @@ __global__ __launch_bounds__(256) void v_transpose_kernel(const bf16_t* __restri
 hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
                               hipStream_t stream) {
   const int S_pad = (int)attn_spad(S);
-  hipLaunchKernelGGL(v_transpose_kernel, dim3(S_pad / KVB, H, B), dim3(256), 0, stream, v, ldv, vt, H, S, S_pad);
+  hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(S_pad / KVB, H, B), dim3(256), 0, stream, v, ldv, vt, H, S, S_pad);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------
+struct AttnExt {            // EXT = true only
+  float scale;              // softmax scale (scores are multiplied by it)
+  int causal;               // keys > query masked out
+  const float* bias;        // [H][2 S - 1] additive bias, indexed by key - query + S - 1, already divided by scale; or nullptr
+  int kv_group;             // query heads per KV head (1 = MHA)
+};
+
+template <int HD, bool EXT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
     const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B,
-    float* __restrict__ lse) {
-  // two stages of { K tile [64][128] | V^T tile [128][64] }, 16 KiB each -> 64 KiB
+    float* __restrict__ lse, const AttnExt ext) {
+  constexpr int STAGE_BYTES = 2 * KVB * HD * 2;
+  constexpr int KS = HD / 16;          // k-steps of the score product
+  constexpr int DT = HD / 32;          // 32-row tiles of O^T
+  constexpr int KROW = HD * 2;         // bytes per K row in LDS
+  // two stages of { K tile [64][HD] | V^T tile [HD][64] }
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,24 +114,30 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   const int b = rem / nq;
   const int q0 = (rem % nq) * QB + wave * QW;
   const int qrow = min(q0 + ql, S - 1);
-  const int ntiles = S_pad / KVB;
+  int ntiles = S_pad / KVB;
+  int hk = h, Hk = H;
+  if (EXT) {
+    hk = h / ext.kv_group;
+    Hk = H / ext.kv_group;
+    if (ext.causal) ntiles = min(ntiles, ((rem % nq) * QB + QB - 1) / KVB + 1);     // tiles right of the diagonal are skipped
+  }
 
   const bf16_t* qp = q + ((int64_t)b * S + qrow) * ldq + h * HD;
-  const bf16_t* kbase = k + (int64_t)b * S * ldk + h * HD;
-  const bf16_t* vbase = vt + ((int64_t)(b * H + h) * HD) * S_pad;
+  const bf16_t* kbase = k + (int64_t)b * S * ldk + hk * HD;
+  const bf16_t* vbase = vt + ((int64_t)(b * Hk + hk) * HD) * S_pad;
 
   // Q^T fragments (B operand): query ql, d = 16*step + 8*hi .. +7
-  bf16x8_t qf[8];
+  bf16x8_t qf[KS];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16 + hi * 8);
+  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16 + hi * 8);
 
-  f32x16_t oacc[4];
+  f32x16_t oacc[DT];
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int d = 0; d < DT; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+  const float c = EXT ? ext.scale * 1.4426950408889634f : 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
 
   // K / V^T tiles go HBM -> LDS by LDS-DMA (16 B per lane, lane-linear destination), double
   // buffered; the XOR swizzle is applied to the per-lane SOURCE chunk and undone by the readers.
@@ -128,13 +150,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     // induction pointers: those 16 VGPRs are what pushed the loop into scratch spills.
     int seed = tid;
     asm volatile("" : "+v"(seed));
-    const int r0 = seed >> 4, cp = seed & 15;        // K: row r0 + 16 i, physical chunk cp
-    const int kswz = (cp ^ (r0 & 15)) << 3;
+    // K rows are KROW bytes: 256-byte rows swizzle chunk ^ (row & 15), 128-byte rows chunk ^ ((row >> 1) & 7)
+    constexpr int KCPR = HD / 8;                     // chunks per K row
+    const int r0 = seed / KCPR, cp = seed % KCPR;    // K: row r0 + (256 / KCPR) i, physical chunk cp
+    const int kswz = (HD == 128 ? (cp ^ (r0 & 15)) : (cp ^ ((r0 >> 1) & 7))) << 3;
     const int d0 = seed >> 3, vp = seed & 7;         // V^T: row d0 + 32 i, physical chunk vp
     const int vswz = (vp ^ ((d0 >> 1) & 7)) << 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int kr = min(kv0 + r0 + 16 * i, S - 1);
+    for (int i = 0; i < DT; ++i) {                   // DT = KVB * KCPR / 256 = HD / 32 pieces of each tile per thread
+      const int kr = min(kv0 + r0 + (256 / KCPR) * i, S - 1);
       const bf16_t* ksrc = kbase + (int64_t)kr * ldk + kswz;
       __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
       const bf16_t* vsrc = vbase + (int64_t)(d0 + 32 * i) * S_pad + kv0 + vswz;
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   // Pin the Q fragments as landed HERE: otherwise their pending global loads reach the loop header and
   // hipcc's conservative merge turns the first in-loop wait into vmcnt(0).
 #pragma unroll
-  for (int s = 0; s < 8; ++s) asm volatile("" : "+v"(qf[s]));
+  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
 
   // Software pipeline per KV tile t (buffer t&1):
   //   A  ds_read all 16 K fragments of tile t
@@ -158,7 +182,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   //   E  __syncthreads: tile t+1 landed (vmcnt 0), nobody reads buffer t&1 any more
   //   F  LDS-DMA tile t+2 into buffer t&1                              [hides under G and the next B..D]
   //   G  16 MFMAs  O^T += V^T P^T
-  bf16x8_t kf0[8], kf1[8], vf[4][4];
+  bf16x8_t kf0[KS], kf1[KS], vf[DT][4];
 
   for (int t = 0; t < ntiles; ++t) {
     const char* ks = smem + (t & 1) * STAGE_BYTES;
@@ -166,10 +190,11 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     // ---- A ----
     {
       const int krow = 32 + ql;
+      const int sw0 = HD == 128 ? (ql & 15) : ((ql >> 1) & 7), sw1 = HD == 128 ? (krow & 15) : ((krow >> 1) & 7);
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        kf0[s] = *reinterpret_cast<const bf16x8_t*>(ks + ql * 256 + (((s * 2 + hi) ^ (ql & 15)) << 4));
-        kf1[s] = *reinterpret_cast<const bf16x8_t*>(ks + krow * 256 + (((s * 2 + hi) ^ (krow & 15)) << 4));
+      for (int s = 0; s < KS; ++s) {
+        kf0[s] = *reinterpret_cast<const bf16x8_t*>(ks + ql * KROW + (((s * 2 + hi) ^ sw0) << 4));
+        kf1[s] = *reinterpret_cast<const bf16x8_t*>(ks + krow * KROW + (((s * 2 + hi) ^ sw1) << 4));
       }
     }
     // ---- B ----
@@ -179,13 +204,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+    for (int s = 0; s < KS; ++s) sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
 #pragma unroll
-    for (int s = 0; s < 8; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
+    for (int s = 0; s < KS; ++s) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
     // ---- C ----
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
+    for (int d = 0; d < DT; ++d) {
       const int vrow = d * 32 + ql;
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -203,6 +228,19 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
           if (key >= S) sacc[kb][r] = -INFINITY;
         }
     }
+    if (EXT) {               // relative-position bias and the causal mask, per score
+      const int kv0 = t * KVB;
+      const int qi = q0 + ql;
+      const float* brow = ext.bias ? ext.bias + (int64_t)h * (2 * S - 1) + (S - 1) - qi : nullptr;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (brow != nullptr && key < S && qi < S) sacc[kb][r] += brow[key];
+          if (ext.causal && key > qi) sacc[kb][r] = -INFINITY;
+        }
+    }
     float mt = sacc[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -218,7 +256,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < DT; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
@@ -245,7 +283,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+      for (int d = 0; d < DT; ++d)
         oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][g], pf[g], oacc[d], 0, 0, 0);
   }
 
@@ -257,7 +295,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   if (q0 + ql < S) {
     bf16_t* op = o + ((int64_t)b * S + q0 + ql) * ldo + h * HD;
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < DT; ++d)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t w;
@@ -275,7 +313,28 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
   const int nq = (S + QB - 1) / QB;
   const int heads_per_xcd = (H + 7) / 8;
   dim3 grid(8 * heads_per_xcd * nq * B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B, lse);
+  hipLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad,
+                     nq, B, lse, AttnExt{});
+  return hipGetLastError();
+}
+
+// Text-encoder attention (afx_text.hip): V [B*S, ldv] with Hkv heads is transposed into vt_ws [B][Hkv][HD][S_pad] first.
+hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                                uint16_t* vt_ws, uint16_t* o, int64_t ldo, int B, int H, int Hkv, int S, int head_dim, float scale,
+                                int causal, const float* bias, hipStream_t stream) {
+  const int S_pad = (int)attn_spad(S);
+  const int nq = (S + QB - 1) / QB;
+  dim3 grid(8 * ((H + 7) / 8) * nq * B);
+  const AttnExt ext{scale, causal, bias, H / Hkv};
+  if (head_dim == 128) {
+    hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(S_pad / KVB, Hkv, B), dim3(256), 0, stream, v, ldv, vt_ws, Hkv, S, S_pad);
+    hipLaunchKernelGGL((attention_kernel<128, true>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt_ws, o, ldo, H, S, S_pad,
+                       nq, B, (float*)nullptr, ext);
+  } else {
+    hipLaunchKernelGGL(v_transpose_kernel<64>, dim3(S_pad / KVB, Hkv, B), dim3(256), 0, stream, v, ldv, vt_ws, Hkv, S, S_pad);
+    hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt_ws, o, ldo, H, S, S_pad,
+                       nq, B, (float*)nullptr, ext);
+  }
   return hipGetLastError();
 }
 

@@ -554,8 +554,8 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
   if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 8)
     return fail(AFX_E_INVALID, "afx_linear_bf16: need K%%64==0, N%%8==0, strides%%8==0");
   if (epi < 0 || epi > 2) return fail(AFX_E_INVALID, "bad epilogue");
-  if (epi == EPI_GATE_RES && (!gate || !res || ldr % 8 || rows_per_batch < 1))
-    return fail(AFX_E_INVALID, "gated residual epilogue needs gate, res, rows_per_batch");
+  if (epi == EPI_GATE_RES && (!res || ldr % 8 || (gate && rows_per_batch < 1)))
+    return fail(AFX_E_INVALID, "gated residual epilogue needs res (and rows_per_batch with a gate)");
   GemmBatch gb{};
   gb.nprob = 1;
   GemmProblem& p = gb.p[0];

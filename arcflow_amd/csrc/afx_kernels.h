@@ -40,6 +40,10 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
                             hipStream_t stream, float* lse = nullptr);
+// text encoders: runtime scale, causal mask, additive bias table [H][2S-1] (pre-divided by scale), grouped KV heads, d 64|128
+hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
+                                uint16_t* vt_ws, uint16_t* o, int64_t ldo, int B, int H, int Hkv, int S, int head_dim, float scale,
+                                int causal, const float* bias, hipStream_t stream);
 // backward: see afx_attn_bwd.hip.  ws layout: Kt | Qt | dOt (each B*H*128*S_pad bf16) | delta (B*H*S_pad f32)
 int64_t attn_bwd_ws_bytes(int B, int H, int S);
 hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,

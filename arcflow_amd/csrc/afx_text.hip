@@ -1,0 +1,186 @@
+// Text-encoder glue kernels (the prompt-embedding step in front of the denoiser -- T5-XXL + CLIP-L for FLUX,
+// Qwen2.5-VL's language model for Qwen-Image; reference call sites lakonlab/models/architecture/diffusers/pretrained.py:152-238,
+// the encoders themselves are transformers models).  GEMMs run on the grouped MFMA kernel (afx_gemm.hip), attention on the
+// EXT instantiations of the flash kernel (afx_attn.hip); what is here is HBM-bound: embedding gather, LayerNorm / RMSNorm
+// rows, activation (* gate) for the plain and gated MLPs, and the rotate-half RoPE of the Qwen2.5 language model.
+#include "afx_api_util.h"
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+
+// out[s, :] = table[ids[s], :] (+ pos[s, :])
+__global__ __launch_bounds__(256) void embed_rows_kernel(const bf16_t* __restrict__ table, const int32_t* __restrict__ ids,
+                                                         const bf16_t* __restrict__ pos, bf16_t* __restrict__ out, int S, int D) {
+  const int cpr = D >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)S * cpr) return;
+  const int s = (int)(g / cpr), c = (int)(g % cpr);
+  u32x4_t w = *reinterpret_cast<const u32x4_t*>(table + (int64_t)ids[s] * D + c * 8);
+  if (pos != nullptr) {
+    float a[8], b[8];
+    unpack8(w, a);
+    unpack8(*reinterpret_cast<const u32x4_t*>(pos + (int64_t)s * D + c * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    w = pack8(a);
+  }
+  *reinterpret_cast<u32x4_t*>(out + (int64_t)s * D + c * 8) = w;
+}
+
+// One wave per row.  rms = 0: LayerNorm (x - mean) * rstd * w + b;  rms = 1: x * rsqrt(mean(x^2) + eps) * w  (T5LayerNorm,
+// Qwen2RMSNorm: statistics in fp32).  D <= 8192.
+__global__ __launch_bounds__(256) void norm_rows_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ y, int64_t ldy,
+                                                        int rows, int D, const float* __restrict__ w, const float* __restrict__ b,
+                                                        float eps, int rms) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const int nch = D >> 3;
+  float v[16][8];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = i * 64 + lane;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1 += v[i][e]; s2 += v[i][e] * v[i][e]; }
+    }
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  const float mean = rms ? 0.f : s1 / D;
+  const float var = rms ? s2 / D : s2 / D - mean * mean;
+  const float rstd = rsqrtf(var + eps);
+  bf16_t* yr = y + (int64_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int ch = i * 64 + lane;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int cc = ch * 8 + e;
+        o[e] = (v[i][e] - mean) * rstd * w[cc] + (b != nullptr ? b[cc] : 0.f);
+      }
+      *reinterpret_cast<u32x4_t*>(yr + ch * 8) = pack8(o);
+    }
+  }
+}
+
+AFX_DEV float act_fn(float x, int act) {
+  if (act == 1) return silu(x);
+  if (act == 2) return gelu_tanh(x);
+  if (act == 3) return x / (1.0f + __expf(-1.702f * x));          // quick_gelu (CLIP)
+  return x;
+}
+
+// out[m, j] = act(x[m, j]) * (gate_off >= 0 ? x[m, gate_off + j] : 1)     -- plain and gated MLP activations
+__global__ __launch_bounds__(256) void act_mul_kernel(const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo,
+                                                      int64_t M, int F, int gate_off, int act) {
+  const int cpr = F >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= M * cpr) return;
+  const int64_t m = g / cpr;
+  const int c = (int)(g % cpr);
+  float a[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(x + m * ldx + c * 8), a);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = act_fn(a[e], act);
+  if (gate_off >= 0) {
+    float b[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(x + m * ldx + gate_off + c * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] *= b[e];
+  }
+  *reinterpret_cast<u32x4_t*>(out + m * ldo + c * 8) = pack8(a);
+}
+
+// rotate-half RoPE in place on H heads of dimension d stored side by side in a row: for i < d/2
+//   x[i] <- x[i] cos[s,i] - x[i + d/2] sin[s,i];   x[i + d/2] <- x[i + d/2] cos[s,i] + x[i] sin[s,i]
+__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ cs,
+                                                        const float* __restrict__ sn, int S, int H, int d) {
+  const int half = d >> 1, cph = half >> 3;                         // 16-byte chunks per half head
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= (int64_t)S * H * cph) return;
+  const int c = (int)(g % cph);
+  const int h = (int)((g / cph) % H);
+  const int s = (int)(g / ((int64_t)cph * H));
+  bf16_t* p = x + (int64_t)s * ldx + h * d + c * 8;
+  float a[8], b[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(p), a);
+  unpack8(*reinterpret_cast<const u32x4_t*>(p + half), b);
+  float oa[8], ob[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float co = cs[(int64_t)s * half + c * 8 + e], si = sn[(int64_t)s * half + c * 8 + e];
+    oa[e] = a[e] * co - b[e] * si;
+    ob[e] = b[e] * co + a[e] * si;
+  }
+  *reinterpret_cast<u32x4_t*>(p) = pack8(oa);
+  *reinterpret_cast<u32x4_t*>(p + half) = pack8(ob);
+}
+
+}  // namespace afx
+
+using namespace afx;
+
+static inline unsigned tblocks(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+extern "C" {
+
+int afx_embed_rows_bf16(const void* table, const int32_t* ids, const void* pos, void* out, int32_t S, int32_t D, void* stream) {
+  if (!table || !ids || !out || S < 1 || D % 8) return fail(AFX_E_INVALID, "bad argument to afx_embed_rows_bf16");
+  hipLaunchKernelGGL(embed_rows_kernel, dim3(tblocks((int64_t)S * (D >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)table,
+                     ids, (const bf16_t*)pos, (bf16_t*)out, S, D);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_norm_rows_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t D, const float* w, const float* b,
+                       float eps, int32_t rms, void* stream) {
+  if (!x || !y || !w || rows < 1 || D % 8 || D > 8192 || ldx % 8 || ldy % 8)
+    return fail(AFX_E_INVALID, "afx_norm_rows_bf16: need D %% 8 == 0, D <= 8192, strides %% 8 == 0");
+  hipLaunchKernelGGL(norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
+                     rows, D, w, b, eps, rms);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_act_mul_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t M, int32_t F, int32_t gate_off, int32_t act,
+                     void* stream) {
+  if (!x || !out || M < 1 || F % 8 || ldx % 8 || ldo % 8 || (gate_off >= 0 && gate_off % 8) || act < 0 || act > 3)
+    return fail(AFX_E_INVALID, "bad argument to afx_act_mul_bf16");
+  hipLaunchKernelGGL(act_mul_kernel, dim3(tblocks(M * (F >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (bf16_t*)out, ldo, M, F, gate_off, act);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t S, int32_t H, int32_t head_dim,
+                       void* stream) {
+  if (!x || !cos_t || !sin_t || S < 1 || H < 1 || head_dim % 16 || ldx % 8) return fail(AFX_E_INVALID, "bad argument to afx_rope_half_bf16");
+  hipLaunchKernelGGL(rope_half_kernel, dim3(tblocks((int64_t)S * H * (head_dim >> 4))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
+                     ldx, cos_t, sin_t, S, H, head_dim);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int64_t afx_attention_ext_ws_bytes(int32_t B, int32_t Hkv, int32_t S, int32_t head_dim) {
+  return (int64_t)B * Hkv * head_dim * attn_spad(S) * 2;
+}
+
+int afx_attention_ext_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                           void* ws, int32_t B, int32_t H, int32_t Hkv, int32_t S, int32_t head_dim, float scale, int32_t causal,
+                           const float* bias, void* stream) {
+  if (!q || !k || !v || !o || !ws || B < 1 || S < 1 || H < 1 || Hkv < 1 || H % Hkv || (head_dim != 64 && head_dim != 128) ||
+      ldq % 8 || ldk % 8 || ldv % 8 || ldo % 8 || !(scale > 0.f))
+    return fail(AFX_E_INVALID, "afx_attention_ext_bf16: head_dim 64 or 128, H %% Hkv == 0, strides %% 8 == 0, scale > 0");
+  HIP_TRY(launch_attention_ext((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)v, ldv, (uint16_t*)ws, (uint16_t*)o,
+                               ldo, B, H, Hkv, S, head_dim, scale, causal, bias, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+}  // extern "C"

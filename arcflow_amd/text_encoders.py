@@ -1,0 +1,241 @@
+"""Prompt encoders on the MI355X engine: the step in front of the denoiser.
+
+The reference gets its prompt embeddings from diffusers' ``encode_prompt`` (lakonlab/models/architecture/diffusers/
+pretrained.py:152-238; pipeline call sites arcflux_pipeline.py / arcqwen_pipeline.py ``encode_prompt``), i.e. from three
+``transformers`` models:
+
+* ``T5Encoder``         -- T5 v1.1 XXL encoder (FLUX ``text_encoder_2``): ``prompt_embeds`` [B, 512, 4096]
+* ``CLIPTextEncoder``   -- CLIP ViT-L/14 text model (FLUX ``text_encoder``): ``pooled_prompt_embeds`` [B, 768]
+* ``Qwen25TextEncoder`` -- the language model of Qwen2.5-VL-7B (Qwen-Image ``text_encoder``): last hidden states
+
+Each class takes the ``state_dict`` of the corresponding transformers module (its key names) and runs the forward on the
+hand-written kernels: grouped MFMA GEMMs with fused bias / residual epilogues (q|k|v and the gated-MLP pairs are stacked
+into one weight), the EXT instantiations of the flash-attention kernel (relative-position bias table for T5, causal mask
+for CLIP / Qwen, grouped KV heads for Qwen, head dim 64 / 128), and the row kernels of afx_text.hip.
+Parity: tests/test_text_encoders.py runs the real transformers modules (random-init small configs) on the CPU in fp32 as
+the oracle -- the third-party dependency itself, not a restatement.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _s():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Base:
+    def __init__(self, device):
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.w: Dict[str, torch.Tensor] = {}
+
+    def _bf(self, t):
+        return t.to(self.dev, torch.bfloat16).contiguous()
+
+    def _f32(self, t):
+        return t.to(self.dev, torch.float32).contiguous()
+
+    def _embed(self, table, ids, pos=None):
+        S, D = ids.numel(), table.shape[1]
+        out = torch.empty(S, D, dtype=torch.bfloat16, device=self.dev)
+        ids32 = ids.to(self.dev, torch.int32).contiguous()
+        _lib.check(self.lib.afx_embed_rows_bf16(_p(table), _p(ids32), _p(pos), _p(out), S, D, _s()))
+        return out
+
+    def _norm(self, x, w, b=None, eps=1e-6, rms=True, out=None):
+        out = torch.empty_like(x) if out is None else out
+        _lib.check(self.lib.afx_norm_rows_bf16(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1], _p(w), _p(b),
+                                               eps, int(rms), _s()))
+        return out
+
+    def _act_mul(self, x, F, gate_off, act):
+        out = torch.empty(x.shape[0], F, dtype=torch.bfloat16, device=self.dev)
+        _lib.check(self.lib.afx_act_mul_bf16(_p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], F, gate_off, act, _s()))
+        return out
+
+    def _attention(self, qkv, Dq, Dk, H, Hkv, d, scale, causal, bias=None):
+        """qkv [S, Dq + 2 Dk] rows q | k | v -> [S, Dq]."""
+        S = qkv.shape[0]
+        o = torch.empty(S, Dq, dtype=torch.bfloat16, device=self.dev)
+        ws = torch.empty(self.lib.afx_attention_ext_ws_bytes(1, Hkv, S, d), dtype=torch.uint8, device=self.dev)
+        ld = qkv.stride(0)
+        _lib.check(self.lib.afx_attention_ext_bf16(_p(qkv), ld, _p(qkv[:, Dq:]), ld, _p(qkv[:, Dq + Dk:]), ld, _p(o), o.stride(0),
+                                                   _p(ws), 1, H, Hkv, S, d, scale, int(causal), _p(bias), _s()))
+        return o
+
+
+# ------------------------------------------------------------------------------------------------------------- T5
+def t5_relative_buckets(delta: torch.Tensor, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
+    """Bidirectional bucket of relative position key - query (transformers T5Attention._relative_position_bucket)."""
+    nb = num_buckets // 2
+    out = (delta > 0).long() * nb
+    n = delta.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, nb - 1))
+    return out + torch.where(n < max_exact, n, large)
+
+
+class T5Encoder(_Base):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int = 24, num_heads: int = 64, d_kv: int = 64,
+                 num_buckets: int = 32, max_distance: int = 128, eps: float = 1e-6, device='cuda'):
+        super().__init__(device)
+        sd = state_dict
+        self.L, self.H, self.dkv, self.eps = num_layers, num_heads, d_kv, eps
+        self.nb, self.maxd = num_buckets, max_distance
+        self.w['embed'] = self._bf(sd['shared.weight'] if 'shared.weight' in sd else sd['encoder.embed_tokens.weight'])
+        self.D = self.w['embed'].shape[1]
+        for i in range(num_layers):
+            a, f = f'encoder.block.{i}.layer.0.', f'encoder.block.{i}.layer.1.'
+            self.w[f'{i}.qkv'] = self._bf(torch.cat([sd[a + f'SelfAttention.{n}.weight'] for n in 'qkv']))
+            self.w[f'{i}.o'] = self._bf(sd[a + 'SelfAttention.o.weight'])
+            self.w[f'{i}.ln1'] = self._f32(sd[a + 'layer_norm.weight'])
+            self.w[f'{i}.wi'] = self._bf(torch.cat([sd[f + 'DenseReluDense.wi_0.weight'], sd[f + 'DenseReluDense.wi_1.weight']]))
+            self.w[f'{i}.wo'] = self._bf(sd[f + 'DenseReluDense.wo.weight'])
+            self.w[f'{i}.ln2'] = self._f32(sd[f + 'layer_norm.weight'])
+        self.F = self.w['0.wo'].shape[1]
+        self.w['ln_f'] = self._f32(sd['encoder.final_layer_norm.weight'])
+        self.rel = sd['encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight'].float()     # [buckets, H]
+        self._bias_cache: Dict[int, torch.Tensor] = {}
+
+    def _bias(self, S: int) -> torch.Tensor:
+        if S not in self._bias_cache:      # [H][2S-1], index key - query + S - 1; T5 does not scale its scores (scale 1)
+            b = t5_relative_buckets(torch.arange(-(S - 1), S), self.nb, self.maxd)
+            self._bias_cache[S] = self.rel[b].t().contiguous().to(self.dev)
+        return self._bias_cache[S]
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor) -> torch.Tensor:
+        """input_ids [B, S] -> last_hidden_state [B, S, d_model] bf16 (no attention mask: FLUX passes none, so padding
+        tokens attend and are attended like any other -- diffusers ``_get_t5_prompt_embeds``)."""
+        outs = []
+        inner = self.H * self.dkv
+        for ids in input_ids:
+            S = ids.numel()
+            x = self._embed(self.w['embed'], ids)
+            bias = self._bias(S)
+            for i in range(self.L):
+                qkv = ops.linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'])
+                o = self._attention(qkv, inner, inner, self.H, self.H, self.dkv, 1.0, False, bias)
+                x = ops.linear(o, self.w[f'{i}.o'], epilogue='gate_res', residual=x)
+                h = ops.linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.wi'])
+                x = ops.linear(self._act_mul(h, self.F, self.F, 2), self.w[f'{i}.wo'], epilogue='gate_res', residual=x)
+            outs.append(self._norm(x, self.w['ln_f'], eps=self.eps))
+        return torch.stack(outs)
+
+
+# ------------------------------------------------------------------------------------------------------------- CLIP
+class CLIPTextEncoder(_Base):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int = 12, num_heads: int = 12, eps: float = 1e-5,
+                 eos_token_id: int = 2, hidden_act: str = 'quick_gelu', device='cuda'):
+        super().__init__(device)
+        sd = {k[len('text_model.'):] if k.startswith('text_model.') else k: v for k, v in state_dict.items()}
+        self.L, self.H, self.eps, self.eos = num_layers, num_heads, eps, eos_token_id
+        self.act = {'quick_gelu': 3, 'gelu': 2, 'gelu_pytorch_tanh': 2}[hidden_act]
+        self.w['tok'] = self._bf(sd['embeddings.token_embedding.weight'])
+        self.w['pos'] = self._bf(sd['embeddings.position_embedding.weight'])
+        self.D = self.w['tok'].shape[1]
+        for i in range(num_layers):
+            p = f'encoder.layers.{i}.'
+            self.w[f'{i}.qkv'] = self._bf(torch.cat([sd[p + f'self_attn.{n}_proj.weight'] for n in 'qkv']))
+            self.w[f'{i}.qkv_b'] = self._bf(torch.cat([sd[p + f'self_attn.{n}_proj.bias'] for n in 'qkv']))
+            for nm, key in (('o', 'self_attn.out_proj'), ('fc1', 'mlp.fc1'), ('fc2', 'mlp.fc2')):
+                self.w[f'{i}.{nm}'], self.w[f'{i}.{nm}_b'] = self._bf(sd[p + key + '.weight']), self._bf(sd[p + key + '.bias'])
+            for nm, key in (('ln1', 'layer_norm1'), ('ln2', 'layer_norm2')):
+                self.w[f'{i}.{nm}'], self.w[f'{i}.{nm}_b'] = self._f32(sd[p + key + '.weight']), self._f32(sd[p + key + '.bias'])
+        self.w['ln_f'], self.w['ln_f_b'] = self._f32(sd['final_layer_norm.weight']), self._f32(sd['final_layer_norm.bias'])
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor):
+        """input_ids [B, S] -> (last_hidden_state [B, S, D], pooler_output [B, D]); causal attention, no padding mask."""
+        hs, pooled = [], []
+        d = self.D // self.H
+        for ids in input_ids:
+            S = ids.numel()
+            x = self._embed(self.w['tok'], ids, self.w['pos'][:S].contiguous())
+            for i in range(self.L):
+                y = self._norm(x, self.w[f'{i}.ln1'], self.w[f'{i}.ln1_b'], self.eps, rms=False)
+                qkv = ops.linear(y, self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
+                o = self._attention(qkv, self.D, self.D, self.H, self.H, d, d ** -0.5, True)
+                x = ops.linear(o, self.w[f'{i}.o'], self.w[f'{i}.o_b'], epilogue='gate_res', residual=x)
+                y = self._norm(x, self.w[f'{i}.ln2'], self.w[f'{i}.ln2_b'], self.eps, rms=False)
+                h = ops.linear(y, self.w[f'{i}.fc1'], self.w[f'{i}.fc1_b'])
+                x = ops.linear(self._act_mul(h, h.shape[1], -1, self.act), self.w[f'{i}.fc2'], self.w[f'{i}.fc2_b'], epilogue='gate_res', residual=x)
+            x = self._norm(x, self.w['ln_f'], self.w['ln_f_b'], self.eps, rms=False)
+            # pooled output = the EOS token's features (transformers CLIPTextTransformer: argmax for the legacy eos id 2)
+            idc = ids.to(self.dev)
+            pos = int(idc.argmax()) if self.eos == 2 else int((idc == self.eos).int().argmax())
+            hs.append(x)
+            pooled.append(x[pos])
+        return torch.stack(hs), torch.stack(pooled)
+
+
+# ------------------------------------------------------------------------------------------------------------- Qwen2.5
+class Qwen25TextEncoder(_Base):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], num_layers: int = 28, num_heads: int = 28, num_kv_heads: int = 4,
+                 rope_theta: float = 1e6, eps: float = 1e-6, device='cuda'):
+        super().__init__(device)
+        sd = {}
+        for k, v in state_dict.items():          # language-model tensors under any of the prefixes transformers has used
+            for pre in ('model.language_model.', 'language_model.model.', 'model.'):
+                if k.startswith(pre) and not k.startswith('model.visual.'):
+                    sd.setdefault(k[len(pre):], v)
+                    break
+        self.L, self.H, self.Hkv, self.theta, self.eps = num_layers, num_heads, num_kv_heads, rope_theta, eps
+        self.w['embed'] = self._bf(sd['embed_tokens.weight'])
+        self.D = self.w['embed'].shape[1]
+        self.d = self.D // num_heads
+        for i in range(num_layers):
+            p = f'layers.{i}.'
+            self.w[f'{i}.qkv'] = self._bf(torch.cat([sd[p + f'self_attn.{n}_proj.weight'] for n in 'qkv']))
+            self.w[f'{i}.qkv_b'] = self._bf(torch.cat([sd[p + f'self_attn.{n}_proj.bias'] for n in 'qkv']))
+            self.w[f'{i}.o'] = self._bf(sd[p + 'self_attn.o_proj.weight'])
+            self.w[f'{i}.gu'] = self._bf(torch.cat([sd[p + 'mlp.gate_proj.weight'], sd[p + 'mlp.up_proj.weight']]))
+            self.w[f'{i}.down'] = self._bf(sd[p + 'mlp.down_proj.weight'])
+            self.w[f'{i}.ln1'] = self._f32(sd[p + 'input_layernorm.weight'])
+            self.w[f'{i}.ln2'] = self._f32(sd[p + 'post_attention_layernorm.weight'])
+        self.F = self.w['0.down'].shape[1]
+        self.w['ln_f'] = self._f32(sd['norm.weight'])
+
+    def _rope(self, S: int):
+        # text-only prompts: the three M-RoPE position streams are identical, so the sectioned table is the plain 1-D one
+        inv = 1.0 / (self.theta ** (torch.arange(0, self.d, 2, dtype=torch.float32) / self.d))
+        ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
+        return ang.cos().contiguous().to(self.dev), ang.sin().contiguous().to(self.dev)
+
+    @torch.no_grad()
+    def __call__(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """input_ids [B, S] (+ right-padding mask) -> hidden_states[-1] [B, S, D] (after the final norm); padded
+        positions are computed on their own prefix only (causal) and are meaningless, as in transformers."""
+        outs = []
+        Dq, Dk = self.H * self.d, self.Hkv * self.d
+        for bi, ids in enumerate(input_ids):
+            n = int(attention_mask[bi].sum()) if attention_mask is not None else ids.numel()
+            if attention_mask is not None and not bool(attention_mask[bi, :n].all()):
+                raise ValueError('only right-padded attention masks are supported')
+            S = n
+            x = self._embed(self.w['embed'], ids[:S])
+            cos, sin = self._rope(S)
+            for i in range(self.L):
+                qkv = ops.linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
+                _lib.check(self.lib.afx_rope_half_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), S, self.H + self.Hkv, self.d, _s()))
+                o = self._attention(qkv, Dq, Dk, self.H, self.Hkv, self.d, self.d ** -0.5, True)
+                x = ops.linear(o, self.w[f'{i}.o'], epilogue='gate_res', residual=x)
+                h = ops.linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.gu'])
+                x = ops.linear(self._act_mul(h, self.F, self.F, 1), self.w[f'{i}.down'], epilogue='gate_res', residual=x)
+            x = self._norm(x, self.w['ln_f'], eps=self.eps)
+            if S < ids.numel():
+                x = torch.cat([x, x.new_zeros(ids.numel() - S, self.D)])
+            outs.append(x)
+        return torch.stack(outs)

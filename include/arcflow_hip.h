@@ -249,10 +249,31 @@ int afx_latent_to_nhwc_affine(const float* tokens, void* y, int32_t hp, int32_t 
 int afx_rmsnorm_nhwc(const void* x, void* y, int64_t rows, int32_t Cpad, int32_t Creal, const float* gamma, int32_t act,
                      void* stream);
 
+/* ---- text encoders: T5-XXL + CLIP-L (FLUX), Qwen2.5-VL language model (Qwen-Image) -----------------------
+ * Replaces the transformers modules behind lakonlab/models/architecture/diffusers/pretrained.py:152-238
+ * (PretrainedFluxTextEncoder / PretrainedQwenImageTextEncoder -> pipeline.encode_prompt). */
+/* out[s, :] = table[ids[s], :] (+ pos[s, :]) */
+int afx_embed_rows_bf16(const void* table, const int32_t* ids, const void* pos, void* out, int32_t S, int32_t D, void* stream);
+/* rms 0: LayerNorm(x) * w + b;  rms 1: x * rsqrt(mean(x^2) + eps) * w (b ignored).  fp32 statistics, D <= 8192 */
+int afx_norm_rows_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t D, const float* w, const float* b,
+                       float eps, int32_t rms, void* stream);
+/* out[m, j] = act(x[m, j]) * (gate_off >= 0 ? x[m, gate_off + j] : 1);  act 0 none, 1 SiLU, 2 GELU(tanh), 3 quick-GELU */
+int afx_act_mul_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t M, int32_t F, int32_t gate_off, int32_t act,
+                     void* stream);
+/* rotate-half RoPE in place on H heads side by side in a row; cos/sin [S, head_dim / 2] f32 */
+int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t S, int32_t H, int32_t head_dim,
+                       void* stream);
+/* softmax(scale * Q K^T + scale * bias [, causal]) V with H query heads over Hkv KV heads (H % Hkv == 0), head_dim 64 or 128;
+ * bias: [H][2S-1] f32 indexed by key - query + S - 1, ALREADY DIVIDED by scale, or NULL; ws: afx_attention_ext_ws_bytes */
+int64_t afx_attention_ext_ws_bytes(int32_t B, int32_t Hkv, int32_t S, int32_t head_dim);
+int afx_attention_ext_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
+                           void* ws, int32_t B, int32_t H, int32_t Hkv, int32_t S, int32_t head_dim, float scale, int32_t causal,
+                           const float* bias, void* stream);
+
 /* ---- building-block kernels (exported for the per-kernel parity tests and micro benches) -- */
 
 /* C[M,N] = epi(A[M,K] . W[N,K]^T + bias)   bf16 in/out, fp32 accumulate (nn.Linear semantics).
- * epi 0: none; 1: GELU(tanh) on columns >= gelu_col0; 2: C = res + gate[m / rows_per_batch, n] * (.)
+ * epi 0: none; 1: GELU(tanh) on columns >= gelu_col0; 2: C = res + gate[m / rows_per_batch, n] * (.)  (gate NULL: C = res + (.))
  * K % 64 == 0, N % 8 == 0, lda/ldw/ldc/ldr % 8 == 0. */
 int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                     void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
