@@ -508,6 +508,35 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
   return AFX_OK;
 }
 
+int32_t afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k) {
+  const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / 64;
+  if (split_k <= 0) {                    // ~2 work-groups per CU (512 in flight), at least 4 K-tiles per chunk
+    split_k = (512 + tiles / 2) / tiles;
+    if (split_k > nk / 4) split_k = nk / 4;
+    if (split_k < 1) split_k = 1;
+  }
+  split_k = split_k < nk ? split_k : nk;
+  const int per = (nk + split_k - 1) / split_k;
+  return (nk + per - 1) / per;           // no empty chunk
+}
+
+int afx_linear_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, float* partials, int32_t M,
+                           int32_t N, int32_t K, int32_t split_k, void* stream) {
+  if (!A || !W || !partials) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16_splitk");
+  if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || split_k < 0)
+    return fail(AFX_E_INVALID, "afx_linear_bf16_splitk: need K%%64==0, N%%8==0, lda/ldw%%8==0, split_k >= 0");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = (const uint16_t*)bias; p.C = (uint16_t*)partials;
+  p.ldc = N; p.M = M; p.N = N; p.K = K; p.epi = EPI_NONE; p.rows_per_batch = 1; p.out_f32 = 3;
+  p.split_k = afx_linear_splitk_chunks(M, N, K, split_k);
+  p.split_stride = (int64_t)M * N;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt, void* stream) {
   if (!c || !what || !dst || !c->ws) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_export");
   Workspace ws = carve(c, c->ws, batch, n_img, n_txt);

@@ -123,7 +123,8 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
 // v_permlane16_swap per register between the column tiles jj, jj+1 pairs the 16-lane groups fq, fq^1: afterwards an even-fq
 // lane owns 8 consecutive columns of tile jj, an odd-fq lane 8 of tile jj+1 -> every bias / gate / residual access and the
 // store are 16 bytes per lane (64 contiguous bytes per row and instruction), no LDS round trip, no barrier.
-AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq) {
+AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
+  const bool first_chunk = chunk == 0;
   int gcol[2];
   bool col_ok[2];
   float bias[2][8];
@@ -133,7 +134,7 @@ AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int ro
     col_ok[jp] = gcol[jp] < P.N;
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
-    if (P.bias != nullptr && col_ok[jp]) {
+    if (P.bias != nullptr && col_ok[jp] && first_chunk) {
       const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol[jp]);
       unpack8(bw, bias[jp]);
     }
@@ -185,6 +186,10 @@ AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int ro
       }
       if (P.out_f32 == 0) {
         *reinterpret_cast<u32x4_t*>(P.C + (int64_t)grow * P.ldc + gcol[jp]) = pack8(v);
+      } else if (P.out_f32 == 3) {          // split-K partial tile into this chunk's slab
+        float* cp = reinterpret_cast<float*>(P.C) + chunk * P.split_stride + (int64_t)grow * P.ldc + gcol[jp];
+        *reinterpret_cast<f32x4_t*>(cp) = (f32x4_t){v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4_t*>(cp + 4) = (f32x4_t){v[4], v[5], v[6], v[7]};
       } else {
         float* cp = reinterpret_cast<float*>(P.C) + (int64_t)grow * P.ldc + gcol[jp];
         f32x4_t o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
@@ -356,6 +361,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
     if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
   const GemmProblem& P = batch.p[pi];
   wg -= P.tile_start;
+  int chunk = 0;
+  if (P.split_k > 1) {                  // chunk fastest: the work-groups of one output tile run side by side
+    chunk = wg % P.split_k;
+    wg /= P.split_k;
+  }
   const int GM_ = batch.group_m;
   const int per_group = GM_ * P.tiles_n;
   const int grp = wg / per_group;
@@ -365,7 +375,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   const int tm = first_m + in_grp % gsz;
   const int tn = in_grp / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int nk = P.K / BK;
+  int t0 = 0, nk = P.K / BK;
+  if (P.split_k > 1) {
+    const int per = (nk + P.split_k - 1) / P.split_k;
+    t0 = chunk * per;
+    nk = min(per, nk - t0);
+    if (nk <= 0) return;                // (the launcher's chunking leaves no empty chunk; uniform, before any barrier)
+  }
 #ifdef AFX_GEMM_TRACE
   unsigned tr[24];
   const int trace_t = nk / 2;
@@ -391,13 +407,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   }
   // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
   auto slot = [&](int t, int h) -> char* { return smem + (((t & 1) << 2) + h) * HALF_BYTES; };
-  auto kb = [&](int t) -> int64_t { return (int64_t)(t < nk ? t : nk - 1) * (BK * 2); };
+  auto kb = [&](int t) -> int64_t { return (int64_t)(t0 + (t < nk ? t : nk - 1)) * (BK * 2); };
   // implicit 3x3 convolution on a zero-bordered NHWC grid (conv_cin_tiles > 0): K-tile t = (tap, 64-channel chunk);
   // its A rows are the SAME flat pixel rows shifted by (dy * row_pitch + dx) -- no im2col, the tap is a row offset.
   const int ct = P.conv_cin_tiles;
   auto ka = [&](int t) -> int64_t {
     t = t < nk ? t : nk - 1;
-    if (ct == 0) return (int64_t)t * (BK * 2);
+    if (ct == 0) return (int64_t)(t0 + t) * (BK * 2);
     const int tap = t / ct, cc = t - tap * ct;
     const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
     return ((int64_t)(dy * P.conv_wp + dx) * P.lda + cc * BK) * 2;
@@ -493,7 +509,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   AFX_TRC(20)
 
   // ---- epilogue: straight from the (transposed) accumulators ------------------------------------
-  epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq);
+  epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq, chunk);
 #ifdef AFX_GEMM_TRACE
   AFX_TRC(21)
   if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0)
@@ -508,7 +524,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     p.tile_start = total;
-    total += p.tiles_m * p.tiles_n;
+    if (p.split_k < 1 || p.out_f32 != 3) p.split_k = 1;
+    total += p.tiles_m * p.tiles_n * p.split_k;
   }
   batch.total_tiles = total;
   if (total == 0) return hipSuccess;
@@ -530,6 +547,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   bool conv = false;
   for (int i = 0; i < batch.nprob; ++i) conv = conv || batch.p[i].conv_cin_tiles > 0;
   if (conv) use = 2;                                 // the implicit-conv addressing lives in the 8-phase kernel
+  for (int i = 0; i < batch.nprob; ++i)
+    if (batch.p[i].out_f32 == 3) use = 2;            // ... and so do split-K and the atomic epilogue
   if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else

@@ -19,7 +19,9 @@ struct GemmProblem {
   int64_t lda, ldw, ldc, ldg, ldr;
   int32_t M, N, K;
   int32_t epi, gelu_col0, rows_per_batch;
-  int32_t out_f32;      // 0: C is bf16; 1: C is float (ldc in floats); 2: C (float) += result
+  int32_t out_f32;      // 0: C is bf16; 1: C is float (ldc in floats); 2: C (float) += result; 3: split-K partial slabs (float)
+  int32_t split_k;      // > 1 (out_f32 == 3 only): the K range is cut into split_k chunks, one work-group per (tile, chunk);
+  int64_t split_stride; //   chunk c stores its partial tile at C + c * split_stride floats (summed by a finishing pass)
   int32_t conv_cin_tiles, conv_wp, conv_hp;   // > 0: implicit 3x3 conv on a padded [conv_hp][conv_wp] NHWC grid, K = 9 * 64 * conv_cin_tiles
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };

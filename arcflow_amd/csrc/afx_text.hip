@@ -123,6 +123,30 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
   *reinterpret_cast<u32x4_t*>(p + half) = pack8(ob);
 }
 
+// out (bf16) = sum of the split-K partial slabs (f32, [nslab][M][N]) [+ res (bf16)]
+__global__ __launch_bounds__(256) void finish_f32_kernel(const float* __restrict__ src, int nslab, const bf16_t* __restrict__ res,
+                                                         int64_t ldr, bf16_t* __restrict__ out, int64_t ldo, int64_t M, int N) {
+  const int cpr = N >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= M * cpr) return;
+  const int64_t m = g / cpr;
+  const int c = (int)(g % cpr);
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s = 0; s < nslab; ++s) {
+    const float* p = src + ((int64_t)s * M + m) * N + c * 8;
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(p);
+    const f32x4_t a1 = *reinterpret_cast<const f32x4_t*>(p + 4);
+    v[0] += a0[0]; v[1] += a0[1]; v[2] += a0[2]; v[3] += a0[3]; v[4] += a1[0]; v[5] += a1[1]; v[6] += a1[2]; v[7] += a1[3];
+  }
+  if (res != nullptr) {
+    float r[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(res + m * ldr + c * 8), r);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += r[e];
+  }
+  *reinterpret_cast<u32x4_t*>(out + m * ldo + c * 8) = pack8(v);
+}
+
 }  // namespace afx
 
 using namespace afx;
@@ -164,6 +188,15 @@ int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* si
   if (!x || !cos_t || !sin_t || S < 1 || H < 1 || head_dim % 16 || ldx % 8) return fail(AFX_E_INVALID, "bad argument to afx_rope_half_bf16");
   hipLaunchKernelGGL(rope_half_kernel, dim3(tblocks((int64_t)S * H * (head_dim >> 4))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
                      ldx, cos_t, sin_t, S, H, head_dim);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_finish_f32_bf16(const float* partials, int32_t nslab, const void* res, int64_t ldr, void* out, int64_t ldo, int64_t M, int32_t N,
+                        void* stream) {
+  if (!partials || !out || M < 1 || N % 8 || nslab < 1 || ldo % 8 || (res && ldr % 8)) return fail(AFX_E_INVALID, "bad argument to afx_finish_f32_bf16");
+  hipLaunchKernelGGL(finish_f32_kernel, dim3(tblocks(M * (N >> 3))), dim3(256), 0, (hipStream_t)stream, partials, nslab, (const bf16_t*)res,
+                     ldr, (bf16_t*)out, ldo, M, N);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -250,6 +250,22 @@ def linear_f32out(a, w, out=None, accumulate: bool = False):
     return out
 
 
+def linear_splitk(a, w, bias=None, residual=None, out=None, split_k: int = 0):
+    """bf16 out = a @ w.T (+ bias) (+ residual) for few-row operands: split-K GEMM into per-chunk fp32 partial slabs, then one
+    summing / converting pass.  Fills the chip when M x N alone gives only a handful of 256x256 tiles."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    n = lib.afx_linear_splitk_chunks(M, N, K, split_k)
+    part = torch.empty(n, M, N, dtype=torch.float32, device=a.device)
+    _lib.check(lib.afx_linear_bf16_splitk(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(part), M, N, K, split_k, _s()))
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _lib.check(lib.afx_finish_f32_bf16(_p(part), n, _p(residual), 0 if residual is None else residual.stride(0), _p(out), out.stride(0),
+                                       M, N, _s()))
+    return out
+
+
 def transpose(x, pad_to: int = 1):
     """[R,C] bf16 (row-strided view allowed) -> [C, roundup(R, pad_to)], zero padded."""
     lib = _lib.load()

@@ -199,6 +199,13 @@ class ArcFluxPipeline(_PipelineBase):
             pipe.vae = AutoencoderKLDecoder(vsd, tuple(vcfg.get('block_out_channels', (128, 256, 512, 512))),
                                             vcfg.get('norm_num_groups', 32), vcfg.get('layers_per_block', 2),
                                             vcfg.get('scaling_factor', 0.3611), vcfg.get('shift_factor', 0.1159))
+        if os.path.isdir(os.path.join(root, 'text_encoder')) and os.path.isdir(os.path.join(root, 'text_encoder_2')):
+            from ..text_encoders import load_clip_text_encoder, load_t5_encoder       # prompt encoders on the HIP engine
+            pipe.text_encoder = load_clip_text_encoder(os.path.join(root, 'text_encoder'))
+            pipe.text_encoder_2 = load_t5_encoder(os.path.join(root, 'text_encoder_2'))
+            from transformers import AutoTokenizer                                      # tokenisation is host-side plumbing
+            pipe.tokenizer = AutoTokenizer.from_pretrained(os.path.join(root, 'tokenizer'))
+            pipe.tokenizer_2 = AutoTokenizer.from_pretrained(os.path.join(root, 'tokenizer_2'))
         if 'proj_out.weight' in sd:          # plain FLUX: usable as the teacher until an adapter is loaded
             pipe.transformer = pipe._build_engine(teacher_head=True)
             pipe.transformer.load_state_dict(sd)
@@ -223,12 +230,19 @@ class ArcFluxPipeline(_PipelineBase):
                 raise RuntimeError('no text encoders attached: pass prompt_embeds and pooled_prompt_embeds')
             prompt = [prompt] if isinstance(prompt, str) else prompt
             prompt_2 = prompt if prompt_2 is None else ([prompt_2] if isinstance(prompt_2, str) else prompt_2)
-            with torch.no_grad():
+            from ..text_encoders import CLIPTextEncoder, T5Encoder
+            with torch.no_grad():      # diffusers FluxPipeline._get_clip_prompt_embeds / _get_t5_prompt_embeds: no attention masks
                 ids = self.tokenizer(prompt, padding='max_length', max_length=77, truncation=True, return_tensors='pt').input_ids
-                pooled_prompt_embeds = self.text_encoder(ids.to(self.text_encoder.device)).pooler_output
+                if isinstance(self.text_encoder, CLIPTextEncoder):
+                    pooled_prompt_embeds = self.text_encoder(ids)[1]
+                else:
+                    pooled_prompt_embeds = self.text_encoder(ids.to(self.text_encoder.device)).pooler_output
                 ids2 = self.tokenizer_2(prompt_2, padding='max_length', max_length=max_sequence_length, truncation=True,
                                         return_tensors='pt').input_ids
-                prompt_embeds = self.text_encoder_2(ids2.to(self.text_encoder_2.device))[0]
+                if isinstance(self.text_encoder_2, T5Encoder):
+                    prompt_embeds = self.text_encoder_2(ids2)
+                else:
+                    prompt_embeds = self.text_encoder_2(ids2.to(self.text_encoder_2.device))[0]
         prompt_embeds = prompt_embeds.to(device, torch.bfloat16).repeat_interleave(num_images_per_prompt, dim=0)
         pooled_prompt_embeds = pooled_prompt_embeds.to(device, torch.bfloat16).repeat_interleave(num_images_per_prompt, dim=0)
         return prompt_embeds, pooled_prompt_embeds

@@ -55,6 +55,11 @@ class ArcQwenImagePipeline(_PipelineBase):
             pipe.vae = AutoencoderKLQwenImageDecoder(vsd, vcfg['latents_mean'], vcfg['latents_std'],
                                                      tuple(vcfg.get('dim_mult', (1, 2, 4, 4))), vcfg.get('num_res_blocks', 2),
                                                      vcfg.get('z_dim', 16))
+        if os.path.isdir(os.path.join(root, 'text_encoder')) and os.path.isdir(os.path.join(root, 'tokenizer')):
+            from ..text_encoders import load_qwen25_text_encoder
+            pipe.text_encoder = load_qwen25_text_encoder(os.path.join(root, 'text_encoder'))
+            from transformers import AutoTokenizer
+            pipe.tokenizer = AutoTokenizer.from_pretrained(os.path.join(root, 'tokenizer'))
         if 'proj_out.weight' in sd:
             pipe.transformer = pipe._build_engine(teacher_head=True)
             pipe.transformer.load_state_dict(sd)
@@ -68,6 +73,35 @@ class ArcQwenImagePipeline(_PipelineBase):
                                               transformer_config.get('logweights_channels', 4), teacher_head=not student)
         pipe.transformer.load_state_dict(state_dict)
         return pipe
+
+    # diffusers QwenImagePipeline prompt template (the reference inherits encode_prompt from it: arcqwen_pipeline.py:65,346)
+    prompt_template_encode = ('<|im_start|>system\nDescribe the image by detailing the color, shape, size, texture, quantity, text, '
+                              'spatial relationships of the objects and background:<|im_end|>\n<|im_start|>user\n{}<|im_end|>\n'
+                              '<|im_start|>assistant\n')
+    prompt_template_encode_start_idx = 34
+    tokenizer_max_length = 1024
+
+    def encode_prompt(self, prompt, max_sequence_length: int = 1024):
+        """-> (prompt_embeds [B, T, D] zero padded, prompt_embeds_mask [B, T]): wrap in the template, run the language model,
+        keep the valid tokens and drop the template's first ``prompt_template_encode_start_idx`` of them."""
+        if self.text_encoder is None or self.tokenizer is None:
+            raise RuntimeError('no text encoder attached: pass prompt_embeds (+ prompt_embeds_mask)')
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        drop = self.prompt_template_encode_start_idx
+        tok = self.tokenizer([self.prompt_template_encode.format(e) for e in prompt], max_length=self.tokenizer_max_length + drop,
+                             padding=True, truncation=True, return_tensors='pt')
+        from ..text_encoders import Qwen25TextEncoder
+        if isinstance(self.text_encoder, Qwen25TextEncoder):
+            hidden = self.text_encoder(tok.input_ids, tok.attention_mask)
+        else:
+            hidden = self.text_encoder(input_ids=tok.input_ids.to(self.text_encoder.device), attention_mask=tok.attention_mask.to(self.text_encoder.device),
+                                       output_hidden_states=True).hidden_states[-1]
+        mask = tok.attention_mask.to(hidden.device).bool()
+        rows = [hidden[b][mask[b]][drop:] for b in range(hidden.shape[0])]
+        T = max(r.shape[0] for r in rows)
+        embeds = torch.stack([torch.cat([r, r.new_zeros(T - r.shape[0], r.shape[1])]) for r in rows])
+        emask = torch.stack([torch.cat([torch.ones(r.shape[0], dtype=torch.long), torch.zeros(T - r.shape[0], dtype=torch.long)]) for r in rows])
+        return embeds[:, :max_sequence_length], emask[:, :max_sequence_length].to(hidden.device)
 
     @torch.inference_mode()
     def __call__(self, prompt: Union[str, List[str]] = None, height: Optional[int] = None, width: Optional[int] = None,
@@ -86,7 +120,9 @@ class ArcQwenImagePipeline(_PipelineBase):
         if prompt is not None and prompt_embeds is not None:
             raise ValueError('Cannot forward both `prompt` and `prompt_embeds`.')
         if prompt_embeds is None:
-            raise RuntimeError('no text encoder attached (SURVEY 8f f2): pass prompt_embeds (+ prompt_embeds_mask)')
+            if prompt is None:
+                raise ValueError('Provide either `prompt` or `prompt_embeds`.')
+            prompt_embeds, prompt_embeds_mask = self.encode_prompt(prompt, max_sequence_length=max_sequence_length)
         if attention_kwargs and attention_kwargs.get('scale', 1.0) != 1.0:
             raise NotImplementedError('LoRA is merged at load time; a runtime lora scale is not supported')
         if self.transformer is None or self.transformer.teacher_head:

@@ -39,6 +39,33 @@ class _Base:
         self.lib = _lib.load()
         self.dev = torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
+        self.use_graphs = True
+        self._graphs: Dict[int, tuple] = {}
+
+    def _run(self, ids: torch.Tensor) -> torch.Tensor:
+        """One sequence through ``self._forward`` (ids int32 on the device -> [S, D]).  A layer is ~10 short launches and
+        a prompt has few rows, so the host would be the bottleneck: the launch sequence is captured once per sequence length
+        into a HIP graph (torch.cuda.CUDAGraph; every kernel here runs on torch's current stream) and replayed."""
+        S = ids.numel()
+        ids = ids.to(self.dev, torch.int32).contiguous()
+        if not self.use_graphs:
+            return self._forward(ids)
+        if S not in self._graphs:
+            self._prepare(S)
+            self._forward(ids)                       # eager warm-up (lazy one-time kernel attribute setup)
+            torch.cuda.synchronize()
+            static_ids = ids.clone()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                static_out = self._forward(static_ids)
+            self._graphs[S] = (g, static_ids, static_out)
+        g, static_ids, static_out = self._graphs[S]
+        static_ids.copy_(ids)
+        g.replay()
+        return static_out.clone()
+
+    def _prepare(self, S: int) -> None:              # per-length tables, built outside the capture
+        pass
 
     def _bf(self, t):
         return t.to(self.dev, torch.bfloat16).contiguous()
@@ -46,10 +73,19 @@ class _Base:
     def _f32(self, t):
         return t.to(self.dev, torch.float32).contiguous()
 
-    def _embed(self, table, ids, pos=None):
-        S, D = ids.numel(), table.shape[1]
+    def _linear(self, x, w, b=None, residual=None):
+        """y = x w^T (+ b) (+ residual).  A prompt is one or two 256-row tiles: when M x N alone cannot fill the chip the
+        K range is split across work-groups (ops.linear_splitk), otherwise the plain fused-epilogue GEMM runs."""
+        M, N, K = x.shape[0], w.shape[0], w.shape[1]
+        if ((M + 255) // 256) * ((N + 255) // 256) <= 170 and K >= 512:
+            return ops.linear_splitk(x, w, b, residual)
+        if residual is not None:
+            return ops.linear(x, w, b, epilogue='gate_res', residual=residual)
+        return ops.linear(x, w, b)
+
+    def _embed(self, table, ids32, pos=None):
+        S, D = ids32.numel(), table.shape[1]
         out = torch.empty(S, D, dtype=torch.bfloat16, device=self.dev)
-        ids32 = ids.to(self.dev, torch.int32).contiguous()
         _lib.check(self.lib.afx_embed_rows_bf16(_p(table), _p(ids32), _p(pos), _p(out), S, D, _s()))
         return out
 
@@ -115,24 +151,26 @@ class T5Encoder(_Base):
             self._bias_cache[S] = self.rel[b].t().contiguous().to(self.dev)
         return self._bias_cache[S]
 
+    def _prepare(self, S: int) -> None:
+        self._bias(S)
+
+    def _forward(self, ids32: torch.Tensor) -> torch.Tensor:
+        inner = self.H * self.dkv
+        x = self._embed(self.w['embed'], ids32)
+        bias = self._bias(ids32.numel())
+        for i in range(self.L):
+            qkv = self._linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'])
+            o = self._attention(qkv, inner, inner, self.H, self.H, self.dkv, 1.0, False, bias)
+            x = self._linear(o, self.w[f'{i}.o'], residual=x)
+            h = self._linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.wi'])
+            x = self._linear(self._act_mul(h, self.F, self.F, 2), self.w[f'{i}.wo'], residual=x)
+        return self._norm(x, self.w['ln_f'], eps=self.eps)
+
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor) -> torch.Tensor:
         """input_ids [B, S] -> last_hidden_state [B, S, d_model] bf16 (no attention mask: FLUX passes none, so padding
         tokens attend and are attended like any other -- diffusers ``_get_t5_prompt_embeds``)."""
-        outs = []
-        inner = self.H * self.dkv
-        for ids in input_ids:
-            S = ids.numel()
-            x = self._embed(self.w['embed'], ids)
-            bias = self._bias(S)
-            for i in range(self.L):
-                qkv = ops.linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'])
-                o = self._attention(qkv, inner, inner, self.H, self.H, self.dkv, 1.0, False, bias)
-                x = ops.linear(o, self.w[f'{i}.o'], epilogue='gate_res', residual=x)
-                h = ops.linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.wi'])
-                x = ops.linear(self._act_mul(h, self.F, self.F, 2), self.w[f'{i}.wo'], epilogue='gate_res', residual=x)
-            outs.append(self._norm(x, self.w['ln_f'], eps=self.eps))
-        return torch.stack(outs)
+        return torch.stack([self._run(ids) for ids in input_ids])
 
 
 # ------------------------------------------------------------------------------------------------------------- CLIP
@@ -156,26 +194,28 @@ class CLIPTextEncoder(_Base):
                 self.w[f'{i}.{nm}'], self.w[f'{i}.{nm}_b'] = self._f32(sd[p + key + '.weight']), self._f32(sd[p + key + '.bias'])
         self.w['ln_f'], self.w['ln_f_b'] = self._f32(sd['final_layer_norm.weight']), self._f32(sd['final_layer_norm.bias'])
 
+    def _forward(self, ids32: torch.Tensor) -> torch.Tensor:
+        d = self.D // self.H
+        S = ids32.numel()
+        x = self._embed(self.w['tok'], ids32, self.w['pos'][:S])
+        for i in range(self.L):
+            y = self._norm(x, self.w[f'{i}.ln1'], self.w[f'{i}.ln1_b'], self.eps, rms=False)
+            qkv = self._linear(y, self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
+            o = self._attention(qkv, self.D, self.D, self.H, self.H, d, d ** -0.5, True)
+            x = self._linear(o, self.w[f'{i}.o'], self.w[f'{i}.o_b'], residual=x)
+            y = self._norm(x, self.w[f'{i}.ln2'], self.w[f'{i}.ln2_b'], self.eps, rms=False)
+            h = self._linear(y, self.w[f'{i}.fc1'], self.w[f'{i}.fc1_b'])
+            x = self._linear(self._act_mul(h, h.shape[1], -1, self.act), self.w[f'{i}.fc2'], self.w[f'{i}.fc2_b'], residual=x)
+        return self._norm(x, self.w['ln_f'], self.w['ln_f_b'], self.eps, rms=False)
+
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor):
         """input_ids [B, S] -> (last_hidden_state [B, S, D], pooler_output [B, D]); causal attention, no padding mask."""
         hs, pooled = [], []
-        d = self.D // self.H
         for ids in input_ids:
-            S = ids.numel()
-            x = self._embed(self.w['tok'], ids, self.w['pos'][:S].contiguous())
-            for i in range(self.L):
-                y = self._norm(x, self.w[f'{i}.ln1'], self.w[f'{i}.ln1_b'], self.eps, rms=False)
-                qkv = ops.linear(y, self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
-                o = self._attention(qkv, self.D, self.D, self.H, self.H, d, d ** -0.5, True)
-                x = ops.linear(o, self.w[f'{i}.o'], self.w[f'{i}.o_b'], epilogue='gate_res', residual=x)
-                y = self._norm(x, self.w[f'{i}.ln2'], self.w[f'{i}.ln2_b'], self.eps, rms=False)
-                h = ops.linear(y, self.w[f'{i}.fc1'], self.w[f'{i}.fc1_b'])
-                x = ops.linear(self._act_mul(h, h.shape[1], -1, self.act), self.w[f'{i}.fc2'], self.w[f'{i}.fc2_b'], epilogue='gate_res', residual=x)
-            x = self._norm(x, self.w['ln_f'], self.w['ln_f_b'], self.eps, rms=False)
+            x = self._run(ids)
             # pooled output = the EOS token's features (transformers CLIPTextTransformer: argmax for the legacy eos id 2)
-            idc = ids.to(self.dev)
-            pos = int(idc.argmax()) if self.eos == 2 else int((idc == self.eos).int().argmax())
+            pos = int(ids.argmax()) if self.eos == 2 else int((ids == self.eos).int().argmax())
             hs.append(x)
             pooled.append(x[pos])
         return torch.stack(hs), torch.stack(pooled)
@@ -207,6 +247,7 @@ class Qwen25TextEncoder(_Base):
             self.w[f'{i}.ln2'] = self._f32(sd[p + 'post_attention_layernorm.weight'])
         self.F = self.w['0.down'].shape[1]
         self.w['ln_f'] = self._f32(sd['norm.weight'])
+        self._rope_cache: Dict[int, tuple] = {}
 
     def _rope(self, S: int):
         # text-only prompts: the three M-RoPE position streams are identical, so the sectioned table is the plain 1-D one
@@ -214,28 +255,75 @@ class Qwen25TextEncoder(_Base):
         ang = torch.arange(S, dtype=torch.float32)[:, None] * inv[None]
         return ang.cos().contiguous().to(self.dev), ang.sin().contiguous().to(self.dev)
 
+    def _prepare(self, S: int) -> None:
+        self._rope_cache[S] = self._rope(S)
+
+    def _forward(self, ids32: torch.Tensor) -> torch.Tensor:
+        Dq, Dk = self.H * self.d, self.Hkv * self.d
+        S = ids32.numel()
+        if S not in self._rope_cache:
+            self._prepare(S)
+        cos, sin = self._rope_cache[S]
+        x = self._embed(self.w['embed'], ids32)
+        for i in range(self.L):
+            qkv = self._linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
+            _lib.check(self.lib.afx_rope_half_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), S, self.H + self.Hkv, self.d, _s()))
+            o = self._attention(qkv, Dq, Dk, self.H, self.Hkv, self.d, self.d ** -0.5, True)
+            x = self._linear(o, self.w[f'{i}.o'], residual=x)
+            h = self._linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.gu'])
+            x = self._linear(self._act_mul(h, self.F, self.F, 1), self.w[f'{i}.down'], residual=x)
+        return self._norm(x, self.w['ln_f'], eps=self.eps)
+
     @torch.no_grad()
     def __call__(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """input_ids [B, S] (+ right-padding mask) -> hidden_states[-1] [B, S, D] (after the final norm); padded
-        positions are computed on their own prefix only (causal) and are meaningless, as in transformers."""
+        """input_ids [B, S] (+ padding mask, either side) -> hidden_states[-1] [B, S, D] (after the final norm).  Only the
+        valid tokens are run (positions = running count of valid tokens, as transformers derives them from the mask);
+        rows of masked positions are zero (transformers leaves meaningless values there; callers drop them)."""
         outs = []
-        Dq, Dk = self.H * self.d, self.Hkv * self.d
-        for bi, ids in enumerate(input_ids):
-            n = int(attention_mask[bi].sum()) if attention_mask is not None else ids.numel()
-            if attention_mask is not None and not bool(attention_mask[bi, :n].all()):
-                raise ValueError('only right-padded attention masks are supported')
-            S = n
-            x = self._embed(self.w['embed'], ids[:S])
-            cos, sin = self._rope(S)
-            for i in range(self.L):
-                qkv = ops.linear(self._norm(x, self.w[f'{i}.ln1'], eps=self.eps), self.w[f'{i}.qkv'], self.w[f'{i}.qkv_b'])
-                _lib.check(self.lib.afx_rope_half_bf16(_p(qkv), qkv.stride(0), _p(cos), _p(sin), S, self.H + self.Hkv, self.d, _s()))
-                o = self._attention(qkv, Dq, Dk, self.H, self.Hkv, self.d, self.d ** -0.5, True)
-                x = ops.linear(o, self.w[f'{i}.o'], epilogue='gate_res', residual=x)
-                h = ops.linear(self._norm(x, self.w[f'{i}.ln2'], eps=self.eps), self.w[f'{i}.gu'])
-                x = ops.linear(self._act_mul(h, self.F, self.F, 1), self.w[f'{i}.down'], epilogue='gate_res', residual=x)
-            x = self._norm(x, self.w['ln_f'], eps=self.eps)
-            if S < ids.numel():
-                x = torch.cat([x, x.new_zeros(ids.numel() - S, self.D)])
-            outs.append(x)
+        for bi, ids_full in enumerate(input_ids):
+            keep = attention_mask[bi].bool() if attention_mask is not None else torch.ones_like(ids_full, dtype=torch.bool)
+            x = self._run(ids_full[keep])
+            full = x.new_zeros(ids_full.numel(), self.D)
+            full[keep.to(self.dev)] = x
+            outs.append(full)
         return torch.stack(outs)
+
+
+# ------------------------------------------------------------------------------------------------------------- loading
+def _read_dir(path: str):
+    """config.json + every safetensors shard of a transformers model directory."""
+    import glob
+    import json
+    import os
+    from safetensors import safe_open
+    with open(os.path.join(path, 'config.json')) as f:
+        cfg = json.load(f)
+    sd: Dict[str, torch.Tensor] = {}
+    files = sorted(glob.glob(os.path.join(path, '*.safetensors')))
+    if not files:
+        raise EnvironmentError(f'no safetensors weights under {path}')
+    for fn in files:
+        with safe_open(fn, framework='pt', device='cpu') as f:
+            for k in f.keys():
+                sd[k] = f.get_tensor(k)
+    return cfg, sd
+
+
+def load_t5_encoder(path: str, device='cuda') -> T5Encoder:
+    c, sd = _read_dir(path)
+    return T5Encoder(sd, c['num_layers'], c['num_heads'], c['d_kv'], c.get('relative_attention_num_buckets', 32),
+                     c.get('relative_attention_max_distance', 128), c.get('layer_norm_epsilon', 1e-6), device)
+
+
+def load_clip_text_encoder(path: str, device='cuda') -> CLIPTextEncoder:
+    c, sd = _read_dir(path)
+    c = c.get('text_config', c)
+    return CLIPTextEncoder(sd, c['num_hidden_layers'], c['num_attention_heads'], c.get('layer_norm_eps', 1e-5),
+                           c.get('eos_token_id', 2), c.get('hidden_act', 'quick_gelu'), device)
+
+
+def load_qwen25_text_encoder(path: str, device='cuda') -> Qwen25TextEncoder:
+    c, sd = _read_dir(path)
+    t = c.get('text_config', c)
+    return Qwen25TextEncoder(sd, t['num_hidden_layers'], t['num_attention_heads'], t['num_key_value_heads'],
+                             t.get('rope_theta', 1e6), t.get('rms_norm_eps', 1e-6), device)

@@ -242,3 +242,17 @@ def test_linear_full_size_vs_device_reference(ops, M, N, K):
         out = ops.linear(a, w, b)
         assert rel_l2(out, ref) < 4e-3
         assert (out.float() - ref).abs().max().item() < 0.02 * ref.abs().max().item() + 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,split', [(162, 3584, 18944, 0), (512, 4096, 10240, 0), (77, 768, 3072, 3), (300, 520, 1024, 16)])
+def test_linear_splitk_matches_plain_gemm(M, N, K, split):
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(M, K, generator=g) * 0.5).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.03).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    got = ops.linear_splitk(a, w, b, r, split_k=split)
+    ref = a.float() @ w.float().t() + b.float() + r.float()
+    assert ((got.float() - ref).norm() / ref.norm()).item() < 4e-3

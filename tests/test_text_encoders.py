@@ -122,3 +122,74 @@ def test_qwen25_text_encoder_vs_transformers():
     out = enc(ids, mask)
     assert _rel(out[0], ref[0]) < 2e-2, _rel(out[0], ref[0])
     assert _rel(out[1, :70], ref[1, :70]) < 2e-2
+
+
+class _Tok:
+    """Stand-in tokenizer (the real ones are transformers tokenizers read from the model snapshot): hashes characters to ids."""
+
+    def __init__(self, vocab, pad_id, eos_id=None, bos_id=None, left_pad=False):
+        self.vocab, self.pad, self.eos, self.bos, self.left = vocab, pad_id, eos_id, bos_id, left_pad
+
+    def __call__(self, texts, padding=True, max_length=None, truncation=True, return_tensors='pt'):
+        rows = []
+        for t in texts:
+            ids = [(ord(c) * 7) % (self.vocab - 10) for c in t]
+            ids = ([self.bos] if self.bos is not None else []) + ids + ([self.eos] if self.eos is not None else [])
+            rows.append(ids[:max_length])
+        L = max_length if padding == 'max_length' else max(len(r) for r in rows)
+        ids = torch.full((len(rows), L), self.pad, dtype=torch.long)
+        mask = torch.zeros(len(rows), L, dtype=torch.long)
+        for i, r in enumerate(rows):
+            sl = slice(L - len(r), L) if self.left else slice(0, len(r))
+            ids[i, sl] = torch.tensor(r)
+            mask[i, sl] = 1
+        return type('Enc', (), dict(input_ids=ids, attention_mask=mask))()
+
+
+def test_qwen_encode_prompt_matches_transformers_path():
+    """pipe.encode_prompt (template, valid-token extraction, 34-token drop, zero padding) with the HIP encoder vs the same
+    host logic around the transformers module; a left-padding tokenizer checks the mask handling."""
+    from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+    from arcflow_amd.pipelines import ArcQwenImagePipeline
+    from arcflow_amd.text_encoders import Qwen25TextEncoder
+    torch.manual_seed(3)
+    text = dict(vocab_size=400, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                max_position_embeddings=2048, rope_theta=1e6, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                rope_scaling=dict(type='mrope', mrope_section=[16, 24, 24]))
+    cfg = Qwen2_5_VLConfig(text_config=text, vision_config=dict(depth=1, hidden_size=64, intermediate_size=128, num_heads=2, out_hidden_size=256))
+    m = _bf16_weights(Qwen2_5_VLForConditionalGeneration(cfg).eval())
+    prompts = ['a red cube on a glass table', 'two cats']
+    for left in (False, True):
+        pipe = ArcQwenImagePipeline()
+        pipe.tokenizer = _Tok(400, pad_id=399, left_pad=left)
+        pipe.text_encoder = Qwen25TextEncoder(m.state_dict(), num_layers=2, num_heads=2, num_kv_heads=1)
+        emb, mask = pipe.encode_prompt(prompts)
+        ref_pipe = ArcQwenImagePipeline()
+        ref_pipe.tokenizer, ref_pipe.text_encoder = pipe.tokenizer, m
+        with torch.no_grad():
+            remb, rmask = ref_pipe.encode_prompt(prompts)
+        assert emb.shape == remb.shape and torch.equal(mask.cpu(), rmask.cpu())
+        assert mask.sum(1).tolist() == [len(pipe.prompt_template_encode.format(p)) - 34 for p in prompts]
+        assert _rel(emb, remb) < 2e-2, (left, _rel(emb, remb))
+
+
+def test_flux_encode_prompt_with_hip_encoders():
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+    from arcflow_amd.pipelines import ArcFluxPipeline
+    from arcflow_amd.text_encoders import CLIPTextEncoder, T5Encoder
+    torch.manual_seed(4)
+    t5 = _bf16_weights(T5EncoderModel(T5Config(vocab_size=300, d_model=128, d_kv=64, d_ff=256, num_layers=2, num_heads=2,
+                                               feed_forward_proj='gated-gelu', dropout_rate=0.0)).eval())
+    clip = _bf16_weights(CLIPTextModel(CLIPTextConfig(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=1,
+                                                      max_position_embeddings=77, eos_token_id=2, bos_token_id=298, pad_token_id=299)).eval())
+    pipe = ArcFluxPipeline()
+    pipe.tokenizer, pipe.tokenizer_2 = _Tok(300, pad_id=299, eos_id=299, bos_id=298), _Tok(300, pad_id=0, eos_id=1)
+    pipe.text_encoder = CLIPTextEncoder(clip.state_dict(), num_layers=2, num_heads=1, eos_token_id=2)
+    pipe.text_encoder_2 = T5Encoder(t5.state_dict(), num_layers=2, num_heads=2, d_kv=64)
+    pe, pooled = pipe.encode_prompt('a photo of a fox', None, None, None, 'cuda', 2, 128)
+    with torch.no_grad():
+        ids = pipe.tokenizer(['a photo of a fox'], padding='max_length', max_length=77).input_ids
+        ids2 = pipe.tokenizer_2(['a photo of a fox'], padding='max_length', max_length=128).input_ids
+        rp, re = clip(input_ids=ids).pooler_output, t5(input_ids=ids2).last_hidden_state
+    assert pe.shape == (2, 128, 128) and pooled.shape == (2, 64)
+    assert _rel(pe[0], re[0]) < 2e-2 and _rel(pooled[1], rp[0]) < 2e-2
