@@ -34,18 +34,26 @@ def main():
     dev = f'cuda:{local}'
     from arcflow_amd.train import ArcFlowDistiller, DistillConfig
     from arcflow_amd.weights import random_packed
-    assert args.model == 'flux'
+    assert args.model in ('flux', 'qwen')
     D = 3072
-    packed = random_packed('flux', 19, 38, dev, seed=0)
+    flux = args.model == 'flux'
+    nd, ns, joint, T = (19, 38, 4096, 512) if flux else (60, 0, 3584, 128)
+    packed = random_packed(args.model, nd, ns, dev, joint_dim=joint, seed=0)
     g = torch.Generator(device=dev).manual_seed(1)
     packed['teacher_head.weight'] = (torch.randn(64, D, generator=g, device=dev) * 0.02).bfloat16()
     packed['teacher_head.bias'] = torch.zeros(64, device=dev, dtype=torch.bfloat16)
     packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
     packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
-    dist_ = ArcFlowDistiller('flux', dict(num_double=19, num_single=38), None, DistillConfig(lora_rank=args.lora_rank), device=dev, packed=packed)
+    # configs/qwen/arcqwen_2nfe_k16.py: true-CFG teacher (scale 4.0, negative prompt), decay 1000, batch 2 per GPU
+    dc = DistillConfig(lora_rank=args.lora_rank) if flux else DistillConfig(lora_rank=args.lora_rank, teacher_guidance_scale=4.0, num_decay_iters=1000)
+    eng = dict(num_double=nd, num_single=ns) if flux else dict(num_double=nd, joint_dim=joint)
+    dist_ = ArcFlowDistiller(args.model, eng, None, dc, device=dev, packed=packed)
     B = args.batch
-    cond = dict(prompt_embeds=(torch.randn(B, 512, 4096, device=dev, generator=g) * 0.1).bfloat16(),
-                pooled=(torch.randn(B, 768, device=dev, generator=g) * 0.1).bfloat16(), hp=64, wp=64)
+    cond = dict(prompt_embeds=(torch.randn(B, T, joint, device=dev, generator=g) * 0.1).bfloat16(), hp=64, wp=64)
+    if flux:
+        cond['pooled'] = (torch.randn(B, 768, device=dev, generator=g) * 0.1).bfloat16()
+    else:
+        cond['negative_prompt_embeds'] = (torch.randn(B, T, joint, device=dev, generator=g) * 0.1).bfloat16()
     rng = torch.Generator(device=dev).manual_seed(100 + rank)
     for _ in range(args.warmup):
         info = dist_.train_step(cond, B, rng=rng)
@@ -56,13 +64,13 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.iters
     # student fwd 2 + teacher fwd 8 (+ per-block recompute 2 + backward ~4 with the LoRA trunk): SURVEY 3.3 counts 16
-    fwd_equiv = 16 if args.lora_rank > 0 else 10
+    fwd_equiv = (16 if flux else 24) if args.lora_rank > 0 else (10 if flux else 18)     # Qwen's CFG teacher doubles the 8
     if rank == 0:
         print(json.dumps({'metric': 'distillation samples/s (' + ('LoRA r=%d + ' % args.lora_rank if args.lora_rank else '') + 'heads + norm_out trainable)', 'value': world * B / dt,
                           's_per_iter': dt, 'batch_per_gpu': B, 'n_gpus': world, 'last': info,
                           'forward_equivalents_per_sample': fwd_equiv, 'trainable_params': int(dist_.params.numel()),
                           'max_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30,
-                          'denoiser_tflops': world * B * fwd_equiv * 74.41 / dt}))
+                          'denoiser_tflops': world * B * fwd_equiv * (74.41 if flux else 70.6) / dt}))
 
 
 if __name__ == '__main__':
