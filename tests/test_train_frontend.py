@@ -162,3 +162,12 @@ def test_train_cli_runs_saves_and_resumes(tmp_path):
     logs2 = [json.loads(l) for l in r2.stdout.splitlines() if l.startswith('{')]
     assert [l['iter'] for l in logs2] == [4] and 'resumed from' in r2.stdout
     assert (tmp_path / 'adapter' / 'config.json').exists() and (tmp_path / 'adapter' / 'diffusion_pytorch_model.safetensors').exists()
+
+
+def test_t5_relative_bucket_function_matches_transformers():
+    """CPU: the restated T5 bucket function (host side of the bias table) against transformers' own static method."""
+    from transformers.models.t5.modeling_t5 import T5Attention
+    from arcflow_amd.text_encoders import t5_relative_buckets
+    d = torch.arange(-600, 601)
+    for nb, md in ((32, 128), (16, 64), (64, 256)):
+        assert torch.equal(t5_relative_buckets(d, nb, md), T5Attention._relative_position_bucket(d, True, nb, md))
