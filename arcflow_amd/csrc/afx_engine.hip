@@ -508,7 +508,7 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
   return AFX_OK;
 }
 
-int32_t afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k) {
+int afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k) {
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / 64;
   if (split_k <= 0) {                    // ~2 work-groups per CU (512 in flight), at least 4 K-tiles per chunk
     split_k = (512 + tiles / 2) / tiles;

@@ -266,7 +266,7 @@ int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* si
 /* Split-K GEMM for few-row operands (M <= 1-2 tiles: the prompt encoders): the K range is cut into chunks, chunk c stores
  * its partial A . W^T (+ bias on chunk 0) into the f32 slab partials[c][M][N]; afx_finish_f32_bf16 sums the slabs into bf16
  * (+ residual).  afx_linear_splitk_chunks = number of slabs for (M, N, K, split_k); split_k 0: chosen to fill the chip. */
-int32_t afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k);
+int afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k);
 int afx_linear_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, float* partials, int32_t M,
                            int32_t N, int32_t K, int32_t split_k, void* stream);
 int afx_finish_f32_bf16(const float* partials, int32_t nslab, const void* res, int64_t ldr, void* out, int64_t ldo, int64_t M, int32_t N,
