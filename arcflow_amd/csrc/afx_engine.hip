@@ -266,6 +266,13 @@ int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes) {
 int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void* pooled, const float* t,
                       const float* g, const float* rope_cos, const float* rope_sin, int32_t B, int32_t N,
                       int32_t T, void* means, void* logw, void* logg, void* stream_) {
+  return afx_mmdit_forward_stage(c, x, ctx_emb, pooled, t, g, rope_cos, rope_sin, B, N, T, means, logw, logg, 0, stream_);
+}
+
+int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, const void* pooled, const float* t,
+                            const float* g, const float* rope_cos, const float* rope_sin, int32_t B, int32_t N,
+                            int32_t T, void* means, void* logw, void* logg, int32_t stage, void* stream_) {
+  if (stage < 0 || stage > 2) return fail(AFX_E_INVALID, "stage must be 0 (all), 1 (conditioning + embedders) or 2 (norm_out + head)");
   if (!c || !x || !ctx_emb || !t || !rope_cos || !rope_sin || !means)
     return fail(AFX_E_INVALID, "null argument to afx_mmdit_forward");
   if (!c->finalized) return fail(AFX_E_MISSING, "afx_finalize() has not succeeded on this context");
@@ -285,6 +292,7 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   ModLayout ml{D, d.num_double, d.num_single};
   const int64_t ldm = c->n_mod;
 
+  if (stage != 2) {
   // ---- conditioning: temb = t_mlp(sincos(1000 t)) [+ g_mlp(sincos(1000 g))] [+ p_mlp(pooled)] ------
   HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, st));
   HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
@@ -331,6 +339,8 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
     }
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
   }
+  }   // stage != 2
+  if (stage == 1) return AFX_OK;       // the caller runs the blocks itself on the exported token matrix
 
   // helper: one grouped GEMM over the image and text row ranges of every sample
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const std::string& pre, const char* suffix,
@@ -370,7 +380,7 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   // ---- dual-stream blocks ---------------------------------------------------------------------------
   uint16_t* QKV = ws.F;                 // [R, 3D]  rows k|v|q
   uint16_t* Hb = ws.F + R * 3 * D;      // [R, 4D]  MLP hidden
-  for (int i = 0; i < d.num_double; ++i) {
+  for (int i = 0; stage == 0 && i < d.num_double; ++i) {
     const std::string p = "d" + std::to_string(i) + ".";
     const float* qkn = W32(c, p + "qknorm");   // [img_q, img_k, txt_q, txt_k][128]
     if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
@@ -387,7 +397,7 @@ int afx_mmdit_forward(afx_ctx* c, const void* x, const void* ctx_emb, const void
   }
 
   // ---- single-stream blocks on the joint sequence -------------------------------------------------
-  for (int i = 0; i < d.num_single; ++i) {
+  for (int i = 0; stage == 0 && i < d.num_single; ++i) {
     const std::string p = "s" + std::to_string(i) + ".";
     const float* qkn = W32(c, p + "qknorm");   // [q, k][128]
     if (c->ckpt)
@@ -508,6 +518,13 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
   return AFX_OK;
 }
 
+int afx_mmdit_import_tokens(afx_ctx* c, const void* src, int32_t batch, int32_t n_img, int32_t n_txt, void* stream) {
+  if (!c || !src || !c->ws) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_import_tokens");
+  Workspace ws = carve(c, c->ws, batch, n_img, n_txt);
+  HIP_TRY(hipMemcpyAsync(ws.X, src, (size_t)batch * (n_img + n_txt) * c->D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int afx_linear_splitk_chunks(int32_t M, int32_t N, int32_t K, int32_t split_k) {
   const int tiles = ((M + 255) / 256) * ((N + 255) / 256), nk = K / 64;
   if (split_k <= 0) {                    // ~2 work-groups per CU (512 in flight), at least 4 K-tiles per chunk
@@ -550,6 +567,8 @@ int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int
     for (int b = 0; b < batch; ++b)
       HIP_TRY(hipMemcpyAsync((char*)dst + (size_t)b * n_img * D * 2, ws.X + ((int64_t)b * (n_img + n_txt) + n_txt) * D,
                              (size_t)n_img * D * 2, hipMemcpyDeviceToDevice, st));
+  } else if (w == "x_tokens") {    // [B*(T+N), D] bf16: the joint token matrix (after the embedders / after the last block)
+    HIP_TRY(hipMemcpyAsync(dst, ws.X, (size_t)batch * (n_img + n_txt) * D * 2, hipMemcpyDeviceToDevice, st));
   } else if (w == "silu_temb") {   // [B, D] f32
     HIP_TRY(hipMemcpyAsync(dst, ws.semb, (size_t)batch * D * 4, hipMemcpyDeviceToDevice, st));
   } else if (w == "mod_all") {     // [B, n_mod] f32: every AdaLN modulation vector of the network
@@ -579,7 +598,16 @@ int afx_arcflow_velocity(const void* means, const void* logw, const void* logg, 
 int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
                     int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
                     int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, void* stream) {
+  return afx_linear_bf16_pre(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gelu_col0, gate, ldg, rows_per_batch, res, ldr, nullptr, 0,
+                             stream);
+}
+
+int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
+                        int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
+                        int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp,
+                        void* stream) {
   if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16");
+  if (pre && ldp % 8) return fail(AFX_E_INVALID, "afx_linear_bf16_pre: ldp %% 8 == 0");
   if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 8)
     return fail(AFX_E_INVALID, "afx_linear_bf16: need K%%64==0, N%%8==0, strides%%8==0");
   if (epi < 0 || epi > 2) return fail(AFX_E_INVALID, "bad epilogue");
@@ -592,6 +620,7 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
   p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = (const uint16_t*)bias;
   p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
   p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
+  p.pre = (const uint16_t*)pre; p.ldp = ldp;
   HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;
 }

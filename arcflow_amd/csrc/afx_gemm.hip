@@ -76,6 +76,12 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
       float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      if (P.pre != nullptr) {
+        float pr[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(P.pre + (int64_t)grow * P.ldp + gcol), pr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += pr[e];
+      }
       if (P.epi == EPI_GELU) {
         if (gcol >= P.gelu_col0) {
 #pragma unroll
@@ -162,6 +168,12 @@ AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int ro
       if (!row_ok || !col_ok[jp]) continue;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias[jp][e];
+      if (P.pre != nullptr) {
+        float pr[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(P.pre + (int64_t)grow * P.ldp + gcol[jp]), pr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += pr[e];
+      }
       if (P.epi == EPI_GELU) {
         if (gcol[jp] >= P.gelu_col0) {
 #pragma unroll

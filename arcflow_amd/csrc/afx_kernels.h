@@ -16,7 +16,8 @@ struct GemmProblem {
   uint16_t* C;          // [M,N], row stride ldc
   const float* gate;    // EPI_GATE_RES: [*, ldg] f32, row = m / rows_per_batch
   const uint16_t* res;  // EPI_GATE_RES: [M,N] residual, row stride ldr (may alias C)
-  int64_t lda, ldw, ldc, ldg, ldr;
+  const uint16_t* pre;  // optional [M,N] bf16 added to A.W^T + bias BEFORE the activation / gate (LoRA-dropout correction term)
+  int64_t lda, ldw, ldc, ldg, ldr, ldp;
   int32_t M, N, K;
   int32_t epi, gelu_col0, rows_per_batch;
   int32_t out_f32;      // 0: C is bf16; 1: C is float (ldc in floats); 2: C (float) += result; 3: split-K partial slabs (float)

@@ -370,6 +370,38 @@ __global__ __launch_bounds__(256) void cfg_kernel(const float* __restrict__ pos,
   if (i < n) out[i] = pos[i] + (pos[i] - neg[i]) * (scale - 1.0f);
 }
 
+// LoRA input dropout (peft: y = W x + B A dropout(x); the engine folds B A into W, so what remains is the zero-mean
+// correction B A (x . delta), delta = keep / (1 - p) - 1).  keep(row, col) is a counter-based hash of (seed, global row, col):
+// the batched forward and the per-sample recompute / backward regenerate identical masks from the seed.
+//   mode 0: dst = src . delta      mode 1: dst = src . (1 + delta) = dropout(src)      mode 2: dst += src . delta
+AFX_DEV uint32_t mix32(uint32_t h) {
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+
+__global__ __launch_bounds__(256) void lora_dropout_kernel(const bf16_t* __restrict__ src, int64_t lds_, bf16_t* __restrict__ dst, int64_t ldd,
+                                                           int64_t M, int N, int64_t row0, uint32_t thresh, float inv_keep, uint32_t seed,
+                                                           int mode) {
+  const int cpr = N >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= M * cpr) return;
+  const int64_t m = g / cpr;
+  const int c = (int)(g % cpr);
+  float a[8], o[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(src + m * lds_ + c * 8), a);
+  if (mode == 2) unpack8(*reinterpret_cast<const u32x4_t*>(dst + m * ldd + c * 8), o);
+  const uint32_t hr = mix32(seed ^ (uint32_t)((row0 + m) * 0x9e3779b1u));
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bool keep = mix32(hr + (uint32_t)(c * 8 + e) * 0x85ebca77u) >= thresh;
+    const float delta = keep ? inv_keep - 1.0f : -1.0f;
+    if (mode == 0) o[e] = a[e] * delta;
+    else if (mode == 1) o[e] = a[e] * (1.0f + delta);
+    else o[e] += a[e] * delta;
+  }
+  *reinterpret_cast<u32x4_t*>(dst + m * ldd + c * 8) = pack8(o);
+}
+
 }  // namespace afx
 
 using namespace afx;
@@ -760,6 +792,17 @@ int afx_add_scale_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, c
   if (n == 0) return AFX_OK;
   hipLaunchKernelGGL(addscale_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
                      (const bf16_t*)b, ldb, gate, ldg, rows_per_batch > 0 ? rows_per_batch : 1, (bf16_t*)out, ldo, rows, cols);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_lora_dropout_bf16(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t N, int64_t row0, float p,
+                          uint32_t seed, int32_t mode, void* stream) {
+  if (!src || !dst || M < 1 || N % 8 || lds_ % 8 || ldd % 8 || !(p >= 0.f && p < 1.f) || mode < 0 || mode > 2)
+    return fail(AFX_E_INVALID, "bad argument to afx_lora_dropout_bf16");
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  hipLaunchKernelGGL(lora_dropout_kernel, dim3((unsigned)((M * (N >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     lds_, (bf16_t*)dst, ldd, M, N, row0, thresh, 1.0f / (1.0f - p), seed, mode);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -152,15 +152,18 @@ class MMDiTEngine:
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 pooled_projections: Optional[torch.Tensor] = None, guidance: Optional[torch.Tensor] = None,
-                height_tokens: Optional[int] = None, width_tokens: Optional[int] = None):
+                height_tokens: Optional[int] = None, width_tokens: Optional[int] = None, stage: int = 0):
         """hidden_states [B,N,C] packed latents; timestep [B] sigma in [0,1]; encoder_hidden_states [B,T,joint];
-        returns ArcFlowModelOutput (student) or the velocity [B,N,C] (teacher head)."""
+        returns ArcFlowModelOutput (student) or the velocity [B,N,C] (teacher head).
+        stage 1 / 2 (B <= 4): conditioning + embedders only / norm_out + head only -- the caller runs the blocks in between
+        on ``export('x_tokens')`` and hands the result back with ``import_tokens`` (training with LoRA dropout)."""
         B, N, Cc = hidden_states.shape
         T = encoder_hidden_states.shape[1]
         if height_tokens is None:
             height_tokens = width_tokens = int(round(N ** 0.5))
         assert height_tokens * width_tokens == N, 'pass height_tokens/width_tokens for non-square latents'
         if B > 4:   # the grouped launches hold 2 problems per sample
+            assert stage == 0, 'staged forwards take at most 4 samples'
             outs = [self.forward(hidden_states[i:i + 4], timestep[i:i + 4], encoder_hidden_states[i:i + 4],
                                  None if pooled_projections is None else pooled_projections[i:i + 4],
                                  None if guidance is None else guidance[i:i + 4], height_tokens, width_tokens)
@@ -184,10 +187,13 @@ class MMDiTEngine:
             means = torch.empty(B, N, K, Cc, dtype=torch.bfloat16, device=dev)
             logw = torch.empty(B, N, K, L, dtype=torch.bfloat16, device=dev)
             logg = torch.empty(B, N, K - 1, L, dtype=torch.bfloat16, device=dev)
-        _lib.check(self.lib.afx_mmdit_forward(self._ctx, _ptr(x), _ptr(ctx), _ptr(pooled), _ptr(t), _ptr(g), _ptr(cos),
-                                              _ptr(sin), B, N, T, _ptr(means), _ptr(logw), _ptr(logg), _stream()))
+        _lib.check(self.lib.afx_mmdit_forward_stage(self._ctx, _ptr(x), _ptr(ctx), _ptr(pooled), _ptr(t), _ptr(g), _ptr(cos),
+                                                    _ptr(sin), B, N, T, _ptr(means), _ptr(logw), _ptr(logg), stage, _stream()))
         if self.teacher_head:
             return means
         return ArcFlowModelOutput(means, logw, logg)
 
     __call__ = forward
+
+    def import_tokens(self, x_tokens: torch.Tensor, B: int, N: int, T: int) -> None:
+        _lib.check(self.lib.afx_mmdit_import_tokens(self._ctx, _ptr(x_tokens), B, N, T, _stream()))

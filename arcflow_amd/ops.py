@@ -29,9 +29,10 @@ def _cuda(t: torch.Tensor, dtype) -> torch.Tensor:
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = 'none',
            gelu_col0: int = 0, gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           rows_per_batch: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out = epi(a @ w.T + bias); a [M,K] (last-dim contiguous, may be a strided view), w [N,K] bf16.
-    epilogue: 'none' | 'gelu' (tanh, on columns >= gelu_col0) | 'gate_res' (residual + gate[b] * (.))."""
+           rows_per_batch: int = 0, out: Optional[torch.Tensor] = None, pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = epi(a @ w.T + bias + pre); a [M,K] (last-dim contiguous, may be a strided view), w [N,K] bf16.
+    epilogue: 'none' | 'gelu' (tanh, on columns >= gelu_col0) | 'gate_res' (residual + gate[b] * (.)).
+    pre [M,N] bf16 is added before the activation / gate (LoRA-dropout correction)."""
     lib = _lib.load()
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(-1) == 1 and w.stride(-1) == 1
     M, K = a.shape
@@ -44,9 +45,22 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if gate.dim() == 1:
             gate = gate[None]
     rpb = rows_per_batch if rows_per_batch > 0 else max(M, 1)
-    _lib.check(lib.afx_linear_bf16(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
-                                   epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
-                                   _p(residual), 0 if residual is None else residual.stride(0), _s()))
+    _lib.check(lib.afx_linear_bf16_pre(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                       epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
+                                       _p(residual), 0 if residual is None else residual.stride(0),
+                                       _p(pre), 0 if pre is None else pre.stride(0), _s()))
+    return out
+
+
+def lora_dropout(src: torch.Tensor, p: float, seed: int, row0: int = 0, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Counter-based LoRA input dropout (keep probability 1-p, delta = keep/(1-p) - 1):
+    mode 0: out = src * delta;  1: out = src * (1 + delta) = dropout(src);  2: out += src * delta."""
+    lib = _lib.load()
+    M, N = src.shape
+    if out is None:
+        assert mode != 2
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=src.device)
+    _lib.check(lib.afx_lora_dropout_bf16(_p(src), src.stride(0), _p(out), out.stride(0), M, N, row0, float(p), int(seed) & 0xffffffff, mode, _s()))
     return out
 
 

@@ -90,7 +90,8 @@ def distill_setup(cfg: Dict[str, Any]) -> Tuple[str, Dict[str, Any], DistillConf
         warmup_iters=lr_cfg.get('warmup_iters', 0), warmup_ratio=lr_cfg.get('warmup_ratio', 1.0),
         grad_clip=tc.get('diffusion_grad_clip', 0.0), grad_clip_begin_iter=tc.get('diffusion_grad_clip_begin_iter', 0),
         ema_gamma=ema.get('momentum_cfg', {}).get('gamma', 7.0), ema_start_iter=ema.get('start_iter', 0),
-        lora_rank=den.get('lora_rank', 0) if den.get('use_lora', False) else 0)
+        lora_rank=den.get('lora_rank', 0) if den.get('use_lora', False) else 0,
+        lora_dropout=den.get('lora_dropout', 0.0) if den.get('use_lora', False) else 0.0)
     runner = cfg.get('runner', {})
     ck = cfg.get('checkpoint_config', {})
     run = dict(name=cfg.get('name', 'arcflow'), total_iters=cfg.get('total_iters', 10000),

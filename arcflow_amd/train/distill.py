@@ -58,6 +58,7 @@ class DistillConfig:
     ema_gamma: float = 7.0
     ema_start_iter: int = 100
     lora_rank: int = 0                    # 0: train heads + norm_out only; 256 in the reference configs
+    lora_dropout: float = 0.0             # peft lora_dropout on the adapters' input (0.05 in the reference configs)
 
 
 def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
@@ -159,6 +160,10 @@ class ArcFlowDistiller:
             'norm_out.linear.bias': self._view(src, 3).clone(),
         }
 
+    def dropout_seed(self, step_id: int) -> int:
+        """Seed of the LoRA dropout masks of one student step: differs per iteration, step and rank (train.py --diff_seed)."""
+        return (self.iteration * 7919 + step_id * 104729 + self.reducer.rank * 15485863 + 12345) & 0x7fffffff
+
     def _student(self, x, sigma, cond):
         return self.student(x.to(torch.bfloat16), sigma, cond['prompt_embeds'], cond.get('pooled'),
                             self._guid(x.shape[0]), cond['hp'], cond['wp'])
@@ -192,7 +197,27 @@ class ArcFlowDistiller:
             if self._ckpt is None or self._ckpt.shape[1] != B * (T + N):
                 self._ckpt = torch.empty(nb, B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
             self.student.set_checkpoint_buffer(self._ckpt)
-        out = self._student(x_src, sigma_src, cond)
+        mod_all = None
+        if self.trunk is not None and c.lora_dropout > 0:
+            # LoRA input dropout: the engine runs conditioning + embedders (stage 1) and norm_out + head (stage 2); the blocks
+            # in between run through the trunk's own block forward, which adds the B A (x . delta) correction per adapter.
+            self.trunk.p_drop = c.lora_dropout
+            self.trunk.seed = self.dropout_seed(step_id)
+            self.student.set_checkpoint_buffer(None)
+            args = (x_src.to(torch.bfloat16), sigma_src, cond['prompt_embeds'], cond.get('pooled'), self._guid(B), cond['hp'], cond['wp'])
+            self.student(*args, stage=1)
+            xt = torch.empty(B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
+            mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
+            self.student.export('x_tokens', xt, B, N, T)
+            self.student.export('mod_all', mod_all, B, N, T)
+            for b in range(B):
+                self.trunk.forward_sample(xt, self._ckpt, b, mod_all, T, N, cond['hp'], cond['wp'])
+            self.student.import_tokens(xt, B, N, T)
+            out = self.student(*args, stage=2)
+        else:
+            if self.trunk is not None:
+                self.trunk.p_drop = 0.0
+            out = self._student(x_src, sigma_src, cond)
         if self.trunk is not None:
             self.student.set_checkpoint_buffer(None)      # the teacher-free forwards below must not overwrite it
         means, logw, logg = out.means, out.logweights, out.loggammas
@@ -202,8 +227,7 @@ class ArcFlowDistiller:
         self.student.export('head_in', xn, B, N, T)
         self.student.export('x_final', xf, B, N, T)
         self.student.export('silu_temb', semb, B, N, T)
-        mod_all = None
-        if self.trunk is not None:
+        if self.trunk is not None and mod_all is None:
             mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
             self.student.export('mod_all', mod_all, B, N, T)
 

@@ -21,6 +21,7 @@ class GradReducer:
         self.dist = dist if dist.is_available() and dist.is_initialized() else None
         self.group = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
+        self.rank = self.dist.get_rank(process_group) if self.dist else 0
         self._pending: List = []
 
     def launch(self, flat_grad: torch.Tensor) -> None:

@@ -90,7 +90,12 @@ class LoraTrunk:
             self.B(sp).zero_()
         self.wt: Dict[str, torch.Tensor] = {}        # transposed weights for the dgrad GEMMs
         self.a16: Dict[str, torch.Tensor] = {}
+        self.b16: Dict[str, torch.Tensor] = {}
+        self.at16: Dict[str, torch.Tensor] = {}
         self.bt16: Dict[str, torch.Tensor] = {}
+        self.p_drop = 0.0           # LoRA input dropout (peft lora_dropout); masks are regenerated from (seed, site, row, col)
+        self.seed = 0
+        self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
         self._ones: Dict[int, torch.Tensor] = {}
         self._build_frozen_transposes()
         self.refresh()
@@ -126,8 +131,10 @@ class LoraTrunk:
                 a16 = ops.cast_bf16(self.A(sp))
                 b16 = ops.cast_bf16(self.B(sp))
                 self.a16[sp.name] = a16
+                self.b16[sp.name] = b16
                 self.bt16[sp.name] = ops.transpose(b16)          # [r, out]
                 at = ops.transpose(a16)                          # [in, r]
+                self.at16[sp.name] = at
                 ones = self._ones.setdefault(sp.in_f, torch.ones(1, sp.in_f, dtype=torch.float32, device=self.dev))
                 rows = slice(sp.row0, sp.row0 + sp.out_f)
                 ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=self.base[key][rows], rows_per_batch=sp.out_f,
@@ -138,14 +145,34 @@ class LoraTrunk:
         return {sp.name: self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f] for sp in self.specs}
 
     # ------------------------------------------------------------------ LoRA gradients of one linear
-    def _lora_grad(self, sp: LoraSpec, x: torch.Tensor, dy: torch.Tensor, grads: torch.Tensor):
-        """x [M, in], dy [M, out] bf16 (row-strided views).  dA += (dy B)^T x ;  dB += dy^T (x A^T)."""
+    def _site_seed(self, sp: LoraSpec) -> int:
+        return (self.seed * 0x9E3779B1 + (sp.off_a * 2654435761 % (1 << 32))) & 0xffffffff
+
+    def _corr(self, sp: Optional[LoraSpec], x: torch.Tensor, row_off: int) -> Optional[torch.Tensor]:
+        """B A (x . delta): what lora_dropout adds to the merged-weight product (None without dropout / adapter)."""
+        if sp is None or self.p_drop <= 0:
+            return None
+        xd = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=0)
+        return ops.linear(ops.linear(xd, self.a16[sp.name]), self.b16[sp.name])
+
+    def _dx_extra(self, sp: Optional[LoraSpec], dT: Optional[torch.Tensor], dx: torch.Tensor, row_off: int) -> None:
+        """dx += ((dy B) A) . delta -- the input gradient of the dropout correction."""
+        if sp is None or dT is None or self.p_drop <= 0:
+            return
+        ops.lora_dropout(ops.linear(dT, self.at16[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=2, out=dx)
+
+    def _lora_grad(self, sp: LoraSpec, x: torch.Tensor, dy: torch.Tensor, grads: torch.Tensor, row_off: int = 0):
+        """x [M, in], dy [M, out] bf16 (row-strided views).  dA += (dy B)^T x~ ;  dB += dy^T (x~ A^T), x~ = dropout(x).
+        Returns dy B [M, r]."""
+        if self.p_drop > 0:
+            x = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
         t = ops.linear(x, self.a16[sp.name])                     # [M, r]
         dT = ops.linear(dy, self.bt16[sp.name])                  # [M, r]
         xt, dyt = ops.transpose(x, 64), ops.transpose(dy, 64)    # contraction over the M tokens
         tt, dTt = ops.transpose(t, 64), ops.transpose(dT, 64)
         ops.linear_f32out(dyt, tt, out=self.B(sp, grads), accumulate=True)
         ops.linear_f32out(dTt, xt, out=self.A(sp, grads), accumulate=True)
+        return dT
 
     # ------------------------------------------------------------------ helpers on strided 2-D views
     def _rope(self, x, y, w_txt, w_img, cos, sin, S, T, dy=None):
@@ -156,9 +183,11 @@ class LoraTrunk:
     def _streams(self, T: int, S: int):
         return (('img', slice(T, S), 0), ('txt', slice(0, T), 1))
 
-    # ------------------------------------------------------------------ block recompute + backward (one sample)
-    def _double_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: torch.Tensor, grads) -> torch.Tensor:
-        """X [S, D] block input, mod [n_mod] f32 of this sample, dXo [S, D] grad of the block output -> grad of X."""
+    # ------------------------------------------------------------------ block forward / recompute + backward (one sample)
+    def _double_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: Optional[torch.Tensor], grads,
+                      fwd_only: bool = False) -> torch.Tensor:
+        """X [S, D] block input, mod [n_mod] f32 of this sample.  fwd_only: returns the block output (training forward with
+        LoRA dropout).  Otherwise dXo [S, D] is the grad of the block output: recompute, backward, returns the grad of X."""
         D, S = self.D, X.shape[0]
         dev = self.dev
         pk, p = self.packed, f'd{i}.'
@@ -179,25 +208,33 @@ class LoraTrunk:
         lse = ops.attention_fwd_lse_2d(Q, K, V, O, 1, S, self.H)
         X1, Xn2 = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         Pre, Hh = torch.empty(S, 4 * D, **bf), torch.empty(S, 4 * D, **bf)
+        Xo = torch.empty(S, D, **bf) if fwd_only else None
         for s, rows, _ in self._streams(T, S):
+            sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
             ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], epilogue='gate_res', gate=mv[(s, 2)],
                        residual=X[rows], out=X1[rows])
             ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-            ops.linear(Xn2[rows], pk[p + s + '_mlp1.weight'], pk[p + s + '_mlp1.bias'], out=Pre[rows])
+            ops.linear(Xn2[rows], pk[p + s + '_mlp1.weight'], pk[p + s + '_mlp1.bias'], out=Pre[rows],
+                       pre=self._corr(sp1, Xn2[rows], rows.start))
             ops.gelu(Pre[rows], out=Hh[rows])
+            if fwd_only:
+                ops.linear(Hh[rows], pk[p + s + '_mlp2.weight'], pk[p + s + '_mlp2.bias'], epilogue='gate_res', gate=mv[(s, 5)],
+                           residual=X1[rows], out=Xo[rows], pre=self._corr(sp2, Hh[rows], rows.start))
+        if fwd_only:
+            return Xo
         # ---- backward ----
         dX1 = torch.empty(S, D, **bf)
         dO = torch.empty(S, D, **bf)
         for s, rows, _ in self._streams(T, S):
             dY2 = ops.add_scale(dXo[rows], gate=mv[(s, 5)])
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-            if sp2 is not None:
-                self._lora_grad(sp2, Hh[rows], dY2, grads)
+            dT2 = self._lora_grad(sp2, Hh[rows], dY2, grads, rows.start) if sp2 is not None else None
             dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
+            self._dx_extra(sp2, dT2, dH, rows.start)
             dPre = ops.gelu(Pre[rows], dh=dH)
-            if sp1 is not None:
-                self._lora_grad(sp1, Xn2[rows], dPre, grads)
+            dT1 = self._lora_grad(sp1, Xn2[rows], dPre, grads, rows.start) if sp1 is not None else None
             dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
+            self._dx_extra(sp1, dT1, dXn2, rows.start)
             ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
             dYo = ops.add_scale(dX1[rows], gate=mv[(s, 2)])
             ops.linear(dYo, self.wt[p + s + '_out'], out=dO[rows])
@@ -212,7 +249,8 @@ class LoraTrunk:
             ops.ln_modulate_backward(X[rows], dXn1, mv[(s, 1)], dres=dX1[rows], out=dX[rows])
         return dX
 
-    def _single_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: torch.Tensor, grads) -> torch.Tensor:
+    def _single_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: Optional[torch.Tensor], grads,
+                      fwd_only: bool = False) -> torch.Tensor:
         D, S = self.D, X.shape[0]
         dev = self.dev
         pk, p = self.packed, f's{i}.'
@@ -220,8 +258,16 @@ class LoraTrunk:
         sh, sc, gt = mod[m0:m0 + D], mod[m0 + D:m0 + 2 * D], mod[m0 + 2 * D:m0 + 3 * D]
         qkn = pk[p + 'qknorm']                                   # [q, k]
         bf = dict(dtype=torch.bfloat16, device=dev)
+        sp_out, sp_mlp = self._spec(p + 'out'), self._spec(p + 'fused')
         Xn = ops.norm_modulate(X, sc, sh)
-        Fp = ops.linear(Xn, pk[p + 'fused.weight'], pk[p + 'fused.bias'])          # [S, 7D] pre-activation k|v|q|mlp
+        corr = self._corr(sp_mlp, Xn, 0)
+        if corr is None:
+            Fp = ops.linear(Xn, pk[p + 'fused.weight'], pk[p + 'fused.bias'])      # [S, 7D] pre-activation k|v|q|mlp
+        else:                                                    # the correction only touches the proj_mlp columns
+            Fp = torch.empty(S, 7 * D, **bf)
+            w, bias = pk[p + 'fused.weight'], pk[p + 'fused.bias']
+            ops.linear(Xn, w[:3 * D], bias[:3 * D], out=Fp[:, :3 * D])
+            ops.linear(Xn, w[3 * D:], bias[3 * D:], out=Fp[:, 3 * D:], pre=corr)
         Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         G = torch.empty(S, 5 * D, **bf)                          # [O | gelu(mlp)] = proj_out operand
@@ -229,26 +275,46 @@ class LoraTrunk:
         self._rope(Qp, Q, qkn[0], qkn[0], cos, sin, S, T)
         lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
         ops.gelu(Mp, out=G[:, D:])
+        if fwd_only:
+            return ops.linear(G, pk[p + 'out.weight'], pk[p + 'out.bias'], epilogue='gate_res', gate=gt, residual=X,
+                              pre=self._corr(sp_out, G, 0))
         # ---- backward ----
         dY = ops.add_scale(dXo, gate=gt)
-        sp_out, sp_mlp = self._spec(p + 'out'), self._spec(p + 'fused')
-        if sp_out is not None:
-            self._lora_grad(sp_out, G, dY, grads)
+        dT_out = self._lora_grad(sp_out, G, dY, grads) if sp_out is not None else None
         dG = ops.linear(dY, self.wt[p + 'out'])                  # [S, 5D]
+        self._dx_extra(sp_out, dT_out, dG, 0)
         dFp = torch.empty(S, 7 * D, **bf)
         ops.gelu(Mp, dh=dG[:, D:], out=dFp[:, 3 * D:])
-        if sp_mlp is not None:
-            self._lora_grad(sp_mlp, Xn, dFp[:, 3 * D:], grads)
+        dT_mlp = self._lora_grad(sp_mlp, Xn, dFp[:, 3 * D:], grads) if sp_mlp is not None else None
         dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         ops.attention_bwd_2d(Q, K, V, G[:, :D], dG[:, :D], lse, dQ, dK, dFp[:, D:2 * D], 1, S, self.H)
         self._rope(Kp, dFp[:, :D], qkn[1], qkn[1], cos, sin, S, T, dy=dK)
         self._rope(Qp, dFp[:, 2 * D:3 * D], qkn[0], qkn[0], cos, sin, S, T, dy=dQ)
         dXn = ops.linear(dFp, self.wt[p + 'fused'])
+        self._dx_extra(sp_mlp, dT_mlp, dXn, 0)
         return ops.ln_modulate_backward(X, dXn, sc, dres=dXo)
 
     def _spec(self, key: str) -> Optional[LoraSpec]:
         sps = self.by_key.get(key)
         return sps[0] if sps else None
+
+    # ------------------------------------------------------------------ training forward of one sample (LoRA dropout active)
+    def forward_sample(self, x_tokens: torch.Tensor, ckpt: torch.Tensor, b: int, mod_all: torch.Tensor, T: int, N: int, hp: int,
+                       wp: int) -> None:
+        """x_tokens [B*S, D]: the joint token matrix after the embedders (engine stage 1); sample b's rows are run through
+        every block IN PLACE, each block input is stored in ckpt[block, b rows] for the backward."""
+        S = T + N
+        self.row0 = b * S
+        mod = mod_all[b]
+        cos, sin = self.eng.rope_tables(hp, wp, T)
+        X = x_tokens[b * S:(b + 1) * S]
+        for i in range(self.nd):
+            ckpt[i, b * S:(b + 1) * S].copy_(X)
+            X = self._double_block(i, X, mod, cos, sin, T, None, None, fwd_only=True)
+        for i in range(self.ns):
+            ckpt[self.nd + i, b * S:(b + 1) * S].copy_(X)
+            X = self._single_block(i, X, mod, cos, sin, T, None, None, fwd_only=True)
+        x_tokens[b * S:(b + 1) * S].copy_(X)
 
     # ------------------------------------------------------------------ whole-trunk backward of one sample
     def backward_sample(self, ckpt: torch.Tensor, b: int, mod_all: torch.Tensor, x_final_img: torch.Tensor,
@@ -258,6 +324,7 @@ class LoraTrunk:
         LoRA gradients of sample b into ``grads``."""
         D, S = self.D, T + N
         mod = mod_all[b]
+        self.row0 = b * S
         cos, sin = self.eng.rope_tables(hp, wp, T)
         fin = (self.nd * 12 + self.ns * 3) * D
         dX = torch.zeros(S, D, dtype=torch.bfloat16, device=self.dev)

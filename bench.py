@@ -201,7 +201,7 @@ def main():
         if prof and gemm_n:
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
-                'bound': 'mfma', 'kernel': 'afx::gemm_bf16_kernel', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
+                'bound': 'mfma', 'kernel': 'afx::gemm_bf16_kernel_v2', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
                 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': _traffic(args.model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,
@@ -210,7 +210,7 @@ def main():
             if att_n:
                 a2 = att_fl / (att_ms * 1e-3) / 1e12
                 line['roofline_attention'] = {
-                    'bound': 'mfma', 'kernel': 'afx::attention_kernel', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
+                    'bound': 'mfma', 'kernel': 'afx::attention_kernel<128, false>', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
                     'unit': 'TFLOP/s', 'frac': a2 / MFMA_BF16_PEAK_TF, 'launches': att_n,
                     'avg_launch_us': att_ms * 1e3 / att_n, 'share_of_step_time': att_ms * 1e-3 / dt}
         if not args.no_cpu_baseline and world == 1:

@@ -189,6 +189,15 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
                          int32_t D, int32_t rows_per_batch, void* stream);
 /* dW_accum[J,Kd] += sum_b dmod[b,J] x[b,Kd]   (norm_out.linear weight gradient, B <= 8) */
 int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t B, int32_t J, int32_t Kd, void* stream);
+/* Staged forward for the training student with LoRA input dropout (lakonlab .../arcflux.py:294-302 lora_dropout): stage 1 runs
+ * the conditioning + embedders only, the caller runs the blocks itself on the token matrix (afx_mmdit_export "x_tokens",
+ * [B*(T+N), D] bf16, text rows first per sample), puts the result back with afx_mmdit_import_tokens and calls stage 2
+ * (norm_out + velocity head).  stage 0 = afx_mmdit_forward. */
+int afx_mmdit_forward_stage(afx_ctx* ctx, const void* x, const void* ctx_emb, const void* pooled, const float* t, const float* g,
+                            const float* rope_cos, const float* rope_sin, int32_t B, int32_t N, int32_t T, void* means, void* logw,
+                            void* logg, int32_t stage, void* stream);
+int afx_mmdit_import_tokens(afx_ctx* ctx, const void* src, int32_t batch, int32_t n_img, int32_t n_txt, void* stream);
+
 /* Copy an activation of the LAST afx_mmdit_forward out of the workspace: "head_in" [B*N,D] bf16,
  * "x_final" [B*N,D] bf16, "silu_temb" [B,D] f32, "mod_final" [B,2D] f32 (scale|shift of norm_out),
  * "mod_all" [B, n_mod] f32 (every modulation vector: per double block img 6D | txt 6D, per single block 3D, final 2D). */
@@ -287,6 +296,15 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
                     void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                     int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
                     int32_t rows_per_batch, const void* res, int64_t ldr, void* stream);
+/* same, with pre [M,N] bf16 added to A.W^T + bias BEFORE the activation / gate (the LoRA-dropout correction B A (x . delta)) */
+int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                        void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                        int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
+                        int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp, void* stream);
+/* LoRA input dropout masks from a counter-based hash of (seed, row0 + row, col), keep probability 1 - p, delta = keep/(1-p) - 1:
+ * mode 0: dst = src * delta;  1: dst = src * (1 + delta) (= dropout(src));  2: dst += src * delta */
+int afx_lora_dropout_bf16(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t N, int64_t row0, float p,
+                          uint32_t seed, int32_t mode, void* stream);
 
 /* Joint attention over S tokens, no mask: O = softmax(Q K^T / sqrt(128)) V per (batch, head).
  * q,k,v,o: row (b*S + s), head h at column h*128, row strides ld* (elements).  head_dim = 128.

@@ -77,8 +77,15 @@ class QwenCfg:
 
 # ----------------------------------------------------------------------------- primitives
 def lin(w: Dict[str, Tensor], name: str, x: Tensor) -> Tensor:
+    """nn.Linear; with ``w[name + '.lora'] = (A [r,in], B [out,r], keep_scale)`` also the peft LoRA branch with input dropout
+    (peft 0.17 LoraLayer.forward, configured at lakonlab/models/architecture/arcflow/arcflux.py:294-302, alpha = r):
+    y = W x + b + B A (x * keep_scale), keep_scale = keep / (1 - p) broadcastable to x (the dropout draw is an input)."""
     b = w.get(name + '.bias')
-    return F.linear(x, w[name + '.weight'].float(), None if b is None else b.float())
+    y = F.linear(x, w[name + '.weight'].float(), None if b is None else b.float())
+    if name + '.lora' in w:
+        a_, b_, keep_scale = w[name + '.lora']
+        y = y + F.linear(F.linear(x * keep_scale, a_), b_)
+    return y
 
 
 def layer_norm(x: Tensor) -> Tensor:

@@ -293,3 +293,112 @@ def test_qwen_distill_step_with_true_cfg_teacher():
         for got, ref in ((tr.A(sp, gsum).cpu(), leaves[sp.name][0].grad), (tr.B(sp, gsum).cpu(), leaves[sp.name][1].grad)):
             e = ((got - ref).norm() / ref.norm().clamp(min=1e-12)).item()
             assert e < 8e-2, (sp.name, e)
+
+
+@pytest.mark.gpu
+def test_lora_dropout_masks_and_kernel_modes():
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(300, 256, generator=g).bfloat16().cuda()
+    p, seed = 0.25, 1234567
+    keep_scale = ops.lora_dropout(torch.ones_like(x), p, seed, row0=40, mode=1).float()
+    vals = set(keep_scale.unique().tolist())
+    assert vals == {0.0, float(torch.tensor(1 / (1 - p)).bfloat16())}
+    frac = (keep_scale == 0).float().mean().item()
+    assert abs(frac - p) < 0.01                                        # drop rate
+    # the mask depends on (seed, global row, col) only: a row-shifted call sees the shifted mask
+    part = ops.lora_dropout(torch.ones(100, 256, dtype=torch.bfloat16, device='cuda'), p, seed, row0=140, mode=1).float()
+    assert torch.equal(part, keep_scale[100:200])
+    assert not torch.equal(ops.lora_dropout(torch.ones_like(x), p, seed + 1, row0=40, mode=1).float(), keep_scale)
+    d0 = ops.lora_dropout(x, p, seed, row0=40, mode=0).float()
+    d1 = ops.lora_dropout(x, p, seed, row0=40, mode=1).float()
+    exact = (keep_scale > 0).float() / (1 - p)                          # the read-back value is bf16-rounded
+    assert torch.allclose(d1, (x.float() * exact).bfloat16().float()) and torch.allclose(d1 - d0, x.float(), atol=2e-2, rtol=2e-2)
+    acc = x.clone()
+    ops.lora_dropout(x, p, seed, row0=40, mode=2, out=acc)
+    assert torch.allclose(acc.float(), (x.float() + d0).bfloat16().float(), atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.gpu
+def test_lora_dropout_train_step_matches_cpu_autograd():
+    """peft lora_dropout on the adapters' input: staged student forward (engine conditioning -> trunk blocks with the
+    B A (x . delta) correction -> engine head), recompute and backward, against autograd through the fp32 oracle with the
+    LoRA branch applied to the SAME dropped inputs (masks read back from the kernel)."""
+    from arcflow_amd import ops
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg, w = _setup()
+    B, hp, wp, T, r, pdrop = 2, 8, 8, 64, 64, 0.25
+    N, S = hp * wp, hp * wp + T
+    g = torch.Generator().manual_seed(6)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, N, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r, lora_dropout=pdrop)
+    dist = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+    tr = dist.trunk
+    AB = {}
+    for sp in tr.specs:
+        tr.B(sp).copy_((torch.randn(sp.out_f, r, generator=g) * 0.05).cuda())       # a LoRA branch big enough to matter
+        AB[sp.name] = (tr.A(sp).cpu().clone(), tr.B(sp).cpu().clone())
+    tr.refresh()
+    dist.iteration = 1
+    seeds = [dist.dropout_seed(0), dist.dropout_seed(1)]
+    cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+    info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+    torch.cuda.synchronize()
+    gsum = dist.grads[0]
+
+    wt = {k: v.float() for k, v in w.items()}
+    leaves = {sp.name: (AB[sp.name][0].bfloat16().float().requires_grad_(True), AB[sp.name][1].bfloat16().float().requires_grad_(True))
+              for sp in tr.specs}
+    gd = torch.full((B,), 3.5)
+
+    def student_weights(step):
+        ws = dict(wt)
+        tr.seed = seeds[step]
+        for sp in tr.specs:
+            ks = ops.lora_dropout(torch.ones(B * S, sp.in_f, dtype=torch.bfloat16, device='cuda'), pdrop, tr._site_seed(sp), 0, mode=1)
+            ks = (ks.float().cpu().view(B, S, sp.in_f) > 0).float() / (1 - pdrop)
+            if 'ff_context' in sp.name:
+                ks = ks[:, :T]
+            elif 'transformer_blocks' in sp.name and 'single' not in sp.name:
+                ks = ks[:, T:]
+            ws[sp.name + '.lora'] = (leaves[sp.name][0], leaves[sp.name][1], ks)
+        return ws
+
+    def teacher(x_lat, t):
+        with torch.no_grad():
+            u = D.flux_teacher_forward(wt, cfg, R.pack_latents(x_lat).bfloat16().float(), pe.float(), pooled.float(), t, gd, hp, wp)
+            return R.unpack_latents(u.bfloat16().float(), hp, wp)
+    rnd = lambda t: t + (t.bfloat16().float() - t).detach()   # noqa: E731
+    x, raw = x0.clone(), torch.ones(B)
+    total = 0
+    for step in range(2):
+        m, lw, lg = D.flux_forward(student_weights(step), cfg, x.bfloat16().float(), pe.float(), pooled.float(), R.shift_sigma(raw), gd, hp, wp)
+        ml, lwl, lgl = R.unpack_mixture(rnd(m), rnd(lw), rnd(lg), hp, wp)
+        u_drop, u_stu, u_tea = draws[step]
+        mask = R.gm_dropout_mask(u_drop.reshape(B, 16, 1, 1, 1), 0.1)
+        loss, x_dst, raw = R.segment_distill(teacher, R.unpack_latents(x, hp, wp), ml, lwl, lgl, raw, 0.75, 0.5, u_stu, u_tea, drop_mask=mask)
+        total = total + loss * 0.5
+        x = R.pack_latents(x_dst.detach())
+    total.backward()
+    assert abs(info['loss'] - total.item()) < 3e-2 * abs(total.item()) + 1e-4, (info['loss'], total.item())
+    for sp in tr.specs:
+        ga, gb = tr.A(sp, gsum).cpu(), tr.B(sp, gsum).cpu()
+        ra, rb = leaves[sp.name][0].grad, leaves[sp.name][1].grad
+        ea = ((ga - ra).norm() / ra.norm()).item()
+        eb = ((gb - rb).norm() / rb.norm()).item()
+        assert ea < 8e-2 and eb < 8e-2, (sp.name, ea, eb)
+    # and dropout really changed the result: the same step without it gives a different loss
+    dist2 = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w,
+                             DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r))
+    for sp in dist2.trunk.specs:
+        dist2.trunk.A(sp).copy_(AB[sp.name][0].cuda())
+        dist2.trunk.B(sp).copy_(AB[sp.name][1].cuda())
+    dist2.trunk.refresh()
+    dist2.iteration = 1
+    info2 = dist2.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+    assert abs(info2['loss'] - info['loss']) > 1e-4 * abs(info['loss'])

@@ -78,7 +78,7 @@ def test_config_reader_merges_bases_and_maps_to_distill_config(tmp_path):
     fam, eng, dc, run = CFG.distill_setup(cfg)
     assert fam == 'flux' and eng['num_double'] == 19 and eng['num_single'] == 38 and eng['joint_dim'] == 4096
     assert (dc.lr, dc.betas, dc.loggamma_lr_mult, dc.warmup_iters, dc.warmup_ratio) == (1e-4, (0.9, 0.95), 0.1, 100, 0.001)
-    assert (dc.grad_clip, dc.grad_clip_begin_iter, dc.loss_scale, dc.shift, dc.lora_rank) == (50.0, 100, 30.0, 3.2, 256)
+    assert (dc.grad_clip, dc.grad_clip_begin_iter, dc.loss_scale, dc.shift, dc.lora_rank, dc.lora_dropout) == (50.0, 100, 30.0, 3.2, 256, 0.05)
     assert (dc.ema_gamma, dc.ema_start_iter, dc.gm_dropout, dc.num_decay_iters) == (7.0, 100, 0.1, 2000)
     assert run['samples_per_gpu'] == 4 and run['ckpt_fp16'] and run['ckpt_dir'] == 'checkpoints/exp_k16'
     assert run['resume_from'] == 'checkpoints/exp_k16/latest.pth' and run['lora_dropout'] == 0.05
@@ -92,7 +92,7 @@ def test_reference_configs_load():
                                        ('/root/reference/configs/qwen/arcqwen_2nfe_k16.py', 'qwen', 60, 4.0, 1000)):
         f, eng, dc, run = CFG.distill_setup(CFG.load_config(path))
         assert (f, eng['num_double'], dc.teacher_guidance_scale, dc.num_decay_iters) == (fam, nd, tgs, decay)
-        assert dc.lora_rank == 256 and dc.lr == 1e-4 and dc.grad_clip == 50.0 and dc.loss_scale == 30.0 and dc.nfe == 2
+        assert dc.lora_rank == 256 and dc.lora_dropout == 0.05 and dc.lr == 1e-4 and dc.grad_clip == 50.0 and dc.loss_scale == 30.0 and dc.nfe == 2
 
 
 def test_prompt_cache_items_and_collate(tmp_path):
@@ -125,7 +125,7 @@ name = 'tiny'
 model = dict(diffusion=dict(type='ArcFlowImitationDataFree', policy_type='ArcFlow', policy_kwargs=dict(),
     denoising=dict(type='ArcFluxTransformer2DModel', num_gaussians=16, logweights_channels=4, in_channels=64, num_layers=1,
         num_single_layers=1, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64,
-        guidance_embeds=True, use_lora=True, lora_rank=64, lora_dropout=0.0),
+        guidance_embeds=True, use_lora=True, lora_rank=64, lora_dropout=0.05),
     flow_loss=dict(type='DiffusionMSELoss', rescale_cfg=dict(scale=30.0)), timestep_sampler=dict(shift=3.2)))
 train_cfg = dict(num_decay_iters=4, window_substeps=3, gm_dropout=0.1, num_intermediate_states=4, nfe=2, timestep_ratio=1.0,
                  total_substeps=128, diffusion_grad_clip=50.0, diffusion_grad_clip_begin_iter=1)

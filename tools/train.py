@@ -67,8 +67,6 @@ def main():
         pg = dist.group.WORLD
     seed = args.seed + (rank if args.diff_seed else 0)              # train.py:222-225
     rng = torch.Generator(device=dev).manual_seed(seed)
-    if run['lora_dropout'] and rank == 0:
-        print(f"[train] note: lora_dropout={run['lora_dropout']} of the config is not applied (LoRA is trained through merged weights)")
 
     # ---- weights --------------------------------------------------------------------------------------
     if args.synthetic:

@@ -23,6 +23,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--model', default='flux')
     ap.add_argument('--lora-rank', type=int, default=256)
+    ap.add_argument('--lora-dropout', type=float, default=0.05, help='peft lora_dropout of the reference configs')
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -45,7 +46,8 @@ def main():
     packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
     packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
     # configs/qwen/arcqwen_2nfe_k16.py: true-CFG teacher (scale 4.0, negative prompt), decay 1000, batch 2 per GPU
-    dc = DistillConfig(lora_rank=args.lora_rank) if flux else DistillConfig(lora_rank=args.lora_rank, teacher_guidance_scale=4.0, num_decay_iters=1000)
+    dc = DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout) if flux else \
+        DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout, teacher_guidance_scale=4.0, num_decay_iters=1000)
     eng = dict(num_double=nd, num_single=ns) if flux else dict(num_double=nd, joint_dim=joint)
     dist_ = ArcFlowDistiller(args.model, eng, None, dc, device=dev, packed=packed)
     B = args.batch
