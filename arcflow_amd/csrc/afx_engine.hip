@@ -57,6 +57,7 @@ struct afx_ctx {
   int64_t n_mod = 0;       // rows of the stacked modulation linear
   int head_n = 0;          // padded head width
   uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
+  const float* temb_override = nullptr;   // optional [B, D] f32 replacing timestep_embedder(t) (training student with its LoRA pair)
   // optional per-launch-class timing (HIP events on the forward's stream)
   bool prof_on = false;
   struct ProfRec { hipEvent_t a, b; int klass; double flops; };
@@ -294,9 +295,13 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
 
   if (stage != 2) {
   // ---- conditioning: temb = t_mlp(sincos(1000 t)) [+ g_mlp(sincos(1000 g))] [+ p_mlp(pooled)] ------
-  HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, st));
-  HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
-  HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 0, st));
+  if (c->temb_override != nullptr) {
+    HIP_TRY(hipMemcpyAsync(ws.temb, c->temb_override, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+  } else {
+    HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, st));
+    HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
+    HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 0, st));
+  }
   if (d.guidance_embeds) {
     HIP_TRY(launch_sincos(g, 1000.0f, ws.sincos, B, st));
     HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.g.l1.weight"), W16(c, "temb.g.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
@@ -449,6 +454,12 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   return AFX_OK;
 }
 
+int afx_set_temb_override(afx_ctx* ctx, const float* temb_t) {
+  if (!ctx) return fail(AFX_E_INVALID, "null ctx");
+  ctx->temb_override = temb_t;
+  return AFX_OK;
+}
+
 int afx_set_checkpoint_buffer(afx_ctx* ctx, void* dptr) {
   if (!ctx) return fail(AFX_E_INVALID, "null ctx");
   ctx->ckpt = (uint16_t*)dptr;     // nullptr switches checkpointing off
@@ -569,6 +580,8 @@ int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int
                              (size_t)n_img * D * 2, hipMemcpyDeviceToDevice, st));
   } else if (w == "x_tokens") {    // [B*(T+N), D] bf16: the joint token matrix (after the embedders / after the last block)
     HIP_TRY(hipMemcpyAsync(dst, ws.X, (size_t)batch * (n_img + n_txt) * D * 2, hipMemcpyDeviceToDevice, st));
+  } else if (w == "temb") {        // [B, D] f32: the summed conditioning embedding before SiLU
+    HIP_TRY(hipMemcpyAsync(dst, ws.temb, (size_t)batch * D * 4, hipMemcpyDeviceToDevice, st));
   } else if (w == "silu_temb") {   // [B, D] f32
     HIP_TRY(hipMemcpyAsync(dst, ws.semb, (size_t)batch * D * 4, hipMemcpyDeviceToDevice, st));
   } else if (w == "mod_all") {     // [B, n_mod] f32: every AdaLN modulation vector of the network

@@ -261,6 +261,68 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   atomicAdd(out + c, acc);
 }
 
+// out[c] += sum_r a[r, c] * b[r, c]: gradient of an AdaLN gate, d_gate = sum_tokens dX_out * branch_output
+__global__ __launch_bounds__(256) void coldot_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb,
+                                                     float* __restrict__ out, int R, int C, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const int r0 = blockIdx.y * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  float acc = 0.f;
+  for (int r = r0; r < r1; ++r) acc += bf16_to_f32(a[(int64_t)r * lda + c]) * bf16_to_f32(b[(int64_t)r * ldb + c]);
+  atomicAdd(out + c, acc);
+}
+
+// out[r, c] = res[r, c] + gate[c] * y[r, c]   (the gated residual, kept apart from the GEMM when y itself is needed later)
+__global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* __restrict__ y, int64_t ldy, const float* __restrict__ gate,
+                                                            const bf16_t* __restrict__ res, int64_t ldr, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int64_t R, int C) {
+  const int cpr = C >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= R * cpr) return;
+  const int64_t r = g / cpr;
+  const int c = (int)(g % cpr);
+  float a[8], b[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(y + r * ldy + c * 8), a);
+  unpack8(*reinterpret_cast<const u32x4_t*>(res + r * ldr + c * 8), b);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) a[e] = b[e] + gate[c * 8 + e] * a[e];
+  *reinterpret_cast<u32x4_t*>(out + r * ldo + c * 8) = pack8(a);
+}
+
+// out[b, k] += sum_n x[b, n] * W[n, k]: the transposed weight-streaming product (gradient of silu(temb) through the stacked
+// AdaLN modulation matrix W [n_mod, D]).  Every block owns a slab of rows n, every thread 8 consecutive columns k; W is read
+// once, coalesced; B <= 4 partial rows live in registers and are added atomically.
+__global__ __launch_bounds__(256) void gemv_t_kernel(const float* __restrict__ x, int64_t ldx, const bf16_t* __restrict__ W, int64_t ldw,
+                                                     float* __restrict__ out, int B, int64_t N, int K, int rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;          // 16-byte column chunk
+  if (c >= (K >> 3)) return;
+  const int64_t n0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
+  float acc[4][8];
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[b][e] = 0.f;
+  for (int64_t n = n0; n < n1; ++n) {
+    float w[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(W + n * ldw + c * 8), w);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      if (b < B) {
+        const float xv = x[(int64_t)b * ldx + n];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[b][e] += xv * w[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b < B)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(out + (int64_t)b * K + c * 8 + e, acc[b][e]);
+}
+
 // AdaLayerNormContinuous backward w.r.t. its modulation:  xn = LN(x) (1 + scale) + shift
 //   d_scale[b, c] += sum_rows dxn * LN(x),   d_shift[b, c] += sum_rows dxn     (rows of batch b)
 // One wave per row computes the row statistics, then every lane adds its 8-column chunks atomically into the
@@ -497,6 +559,35 @@ int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, 
   const int rpb = 256;
   hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, ldx, out_accum, rows, cols, rpb);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_coldot_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* out_accum, int32_t rows, int32_t cols, void* stream) {
+  if (!a || !b || !out_accum || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_coldot_bf16");
+  const int rpb = 256;
+  hipLaunchKernelGGL(coldot_kernel, dim3((cols + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out_accum, rows, cols, rpb);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_gate_residual_bf16(const void* y, int64_t ldy, const float* gate, const void* res, int64_t ldr, void* out, int64_t ldo,
+                           int64_t rows, int32_t cols, void* stream) {
+  if (!y || !gate || !res || !out || rows < 1 || cols % 8 || ldy % 8 || ldr % 8 || ldo % 8)
+    return fail(AFX_E_INVALID, "bad argument to afx_gate_residual_bf16");
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(blocks_for(rows * (cols >> 3))), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, ldy,
+                     gate, (const bf16_t*)res, ldr, (bf16_t*)out, ldo, rows, cols);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_gemv_t_bf16(const float* x, int64_t ldx, const void* W, int64_t ldw, float* out_accum, int32_t B, int64_t N, int32_t K,
+                    void* stream) {
+  if (!x || !W || !out_accum || B < 1 || B > 4 || N < 1 || K % 8 || ldw % 8) return fail(AFX_E_INVALID, "afx_gemv_t_bf16: 1 <= B <= 4, K %% 8 == 0");
+  const int rpb = 512;
+  hipLaunchKernelGGL(gemv_t_kernel, dim3(((K >> 3) + 255) / 256, (unsigned)((N + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                     (const bf16_t*)W, ldw, out_accum, B, N, K, rpb);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -195,5 +195,10 @@ class MMDiTEngine:
 
     __call__ = forward
 
+    def set_temb_override(self, temb_t: Optional[torch.Tensor]) -> None:
+        """[B, D] fp32 replacing timestep_embedder(t) in the next forwards (None clears); the caller keeps it alive."""
+        self._temb_override = temb_t
+        _lib.check(self.lib.afx_set_temb_override(self._ctx, _ptr(temb_t)))
+
     def import_tokens(self, x_tokens: torch.Tensor, B: int, N: int, T: int) -> None:
         _lib.check(self.lib.afx_mmdit_import_tokens(self._ctx, _ptr(x_tokens), B, N, T, _stream()))

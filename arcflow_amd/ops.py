@@ -290,6 +290,30 @@ def transpose(x, pad_to: int = 1):
     return y
 
 
+def coldot(a, b, out_accum):
+    """out_accum[c] += sum_r a[r,c] * b[r,c]   (a, b bf16 row-strided views, out fp32 [C])."""
+    lib = _lib.load()
+    _lib.check(lib.afx_coldot_bf16(_p(a), a.stride(0), _p(b), b.stride(0), _p(out_accum), a.shape[0], a.shape[1], _s()))
+    return out_accum
+
+
+def gate_residual(y, gate, res, out=None):
+    """out = res + gate[c] * y   (y, res bf16 [R,C], gate fp32 [C])."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(y.shape[0], y.shape[1], dtype=torch.bfloat16, device=y.device)
+    _lib.check(lib.afx_gate_residual_bf16(_p(y), y.stride(0), _p(_cuda(gate, torch.float32)), _p(res), res.stride(0), _p(out), out.stride(0),
+                                          y.shape[0], y.shape[1], _s()))
+    return out
+
+
+def gemv_t(x, w, out_accum):
+    """out_accum[b,k] += sum_n x[b,n] w[n,k]   (x fp32 [B<=4, N], w bf16 [N, K], out fp32 [B, K])."""
+    lib = _lib.load()
+    _lib.check(lib.afx_gemv_t_bf16(_p(x), x.stride(0), _p(w), w.stride(0), _p(out_accum), x.shape[0], x.shape[1], w.shape[1], _s()))
+    return out_accum
+
+
 def colsum(x, out_accum):
     lib = _lib.load()
     _lib.check(lib.afx_colsum_bf16(_p(x), x.stride(0), _p(out_accum), x.shape[0], x.shape[1], _s()))

@@ -196,30 +196,32 @@ class ArcFlowDistiller:
             nb = self.student.num_double + self.student.num_single
             if self._ckpt is None or self._ckpt.shape[1] != B * (T + N):
                 self._ckpt = torch.empty(nb, B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
-            self.student.set_checkpoint_buffer(self._ckpt)
         mod_all = None
-        if self.trunk is not None and c.lora_dropout > 0:
-            # LoRA input dropout: the engine runs conditioning + embedders (stage 1) and norm_out + head (stage 2); the blocks
-            # in between run through the trunk's own block forward, which adds the B A (x . delta) correction per adapter.
+        if self.trunk is not None:
+            # With adapters the student's blocks run through the trunk's own block forward: it adds the LoRA-dropout correction
+            # B A (x . delta) per adapter and keeps the pre-gate branch outputs the modulation gradients need.  The engine
+            # runs conditioning + embedders (stage 1, with the timestep embedding of the LoRA-adapted embedder handed in) and
+            # norm_out + head (stage 2).
             self.trunk.p_drop = c.lora_dropout
             self.trunk.seed = self.dropout_seed(step_id)
             self.student.set_checkpoint_buffer(None)
+            temb_t = self.trunk.temb_forward(sigma_src)
+            self.student.set_temb_override(temb_t)
             args = (x_src.to(torch.bfloat16), sigma_src, cond['prompt_embeds'], cond.get('pooled'), self._guid(B), cond['hp'], cond['wp'])
             self.student(*args, stage=1)
             xt = torch.empty(B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
             mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
+            temb_sum = torch.empty(B, self.D, dtype=torch.float32, device=dev)
             self.student.export('x_tokens', xt, B, N, T)
             self.student.export('mod_all', mod_all, B, N, T)
+            self.student.export('temb', temb_sum, B, N, T)
             for b in range(B):
                 self.trunk.forward_sample(xt, self._ckpt, b, mod_all, T, N, cond['hp'], cond['wp'])
             self.student.import_tokens(xt, B, N, T)
             out = self.student(*args, stage=2)
+            self.student.set_temb_override(None)
         else:
-            if self.trunk is not None:
-                self.trunk.p_drop = 0.0
             out = self._student(x_src, sigma_src, cond)
-        if self.trunk is not None:
-            self.student.set_checkpoint_buffer(None)      # the teacher-free forwards below must not overwrite it
         means, logw, logg = out.means, out.logweights, out.loggammas
         xn = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
         xf = torch.empty(B * N, self.D, dtype=torch.bfloat16, device=dev)
@@ -298,9 +300,16 @@ class ArcFlowDistiller:
         ops.outer_accum(dflat, semb, self._view(gbuf, 2).view(2 * self.D, self.D))
         ops.outer_accum(dflat, torch.ones(B, 1, device=dev), self._view(gbuf, 3).view(2 * self.D, 1))
         if self.trunk is not None:                          # LoRA adapters: per-sample recompute + backward of every block
+            dmod_all = torch.zeros(B, self.student.n_mod, dtype=torch.float32, device=dev)
             for b in range(B):
                 self.trunk.backward_sample(self._ckpt, b, mod_all, xf[b * N:(b + 1) * N], dxn[b * N:(b + 1) * N], T, N,
-                                           cond['hp'], cond['wp'], gbuf)
+                                           cond['hp'], cond['wp'], gbuf, dmod_out=dmod_all[b])
+            # timestep-embedder LoRA pair: d silu(temb) = W_mod^T d mod (all blocks) + W_norm_out^T d mod_final, then SiLU'
+            dsemb = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
+            ops.gemv_t(dmod_all, self.student._weights['mod.weight'], dsemb)
+            dsemb += dflat @ self._view(self.params, 2).view(2 * self.D, self.D)
+            sg = torch.sigmoid(temb_sum)
+            self.trunk.temb_backward(dsemb * (sg * (1 + temb_sum * (1 - sg))), gbuf)
         return x_dst, raw_dst
 
     # ------------------------------------------------------------------ one iteration

@@ -18,6 +18,7 @@ of every block.  Both are listed in DESIGN.md.
 from __future__ import annotations
 
 import ctypes as C
+import math
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -54,6 +55,9 @@ def lora_targets(family: str, num_double: int, num_single: int, D: int) -> List[
     for i in range(num_single):
         t.append((f'single_transformer_blocks.{i}.proj_mlp', f's{i}.fused', 3 * D, 4 * D, D))
         t.append((f'single_transformer_blocks.{i}.proj_out', f's{i}.out', 0, D, 5 * D))
+    # 'timestep_embedder.linear_1/2' of lora_target_modules (arcflux_2nfe_k16.py:46-47, arcqwen_2nfe_k16.py:50-51)
+    t.append(('time_text_embed.timestep_embedder.linear_1', 'temb.t.l1', 0, D, 256))
+    t.append(('time_text_embed.timestep_embedder.linear_2', 'temb.t.l2', 0, D, D))
     return t
 
 
@@ -93,6 +97,9 @@ class LoraTrunk:
         self.b16: Dict[str, torch.Tensor] = {}
         self.at16: Dict[str, torch.Tensor] = {}
         self.bt16: Dict[str, torch.Tensor] = {}
+        self.ybuf: Optional[torch.Tensor] = None     # [2 nd + ns, B*S, D] pre-gate branch outputs of the last training forward
+        self.dmod: Optional[torch.Tensor] = None     # [n_mod] fp32: modulation gradients of the sample being back-propagated
+        self._tmp2 = torch.zeros(2, self.D, dtype=torch.float32, device=self.dev)
         self.p_drop = 0.0           # LoRA input dropout (peft lora_dropout); masks are regenerated from (seed, site, row, col)
         self.seed = 0
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
@@ -145,6 +152,55 @@ class LoraTrunk:
         return {sp.name: self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f] for sp in self.specs}
 
     # ------------------------------------------------------------------ LoRA gradients of one linear
+    def _dmod_ln(self, x: torch.Tensor, dxn: torch.Tensor, off_scale: int, off_shift: int) -> None:
+        """xn = LN(x) (1 + scale) + shift:  d_scale += sum_rows dxn * LN(x),  d_shift += sum_rows dxn."""
+        self._tmp2.zero_()
+        ops.normout_backward(x, dxn, self._tmp2.view(1, 2, self.D), x.shape[0])
+        self.dmod[off_scale:off_scale + self.D] += self._tmp2[0]
+        self.dmod[off_shift:off_shift + self.D] += self._tmp2[1]
+
+    # ------------------------------------------------------------------ timestep embedder with its LoRA pair (host-sized math)
+    def _keep_scale(self, sp: LoraSpec, rows: int, cols: int) -> Optional[torch.Tensor]:
+        if self.p_drop <= 0:
+            return None
+        ones = torch.ones(rows, cols, dtype=torch.bfloat16, device=self.dev)
+        keep = ops.lora_dropout(ones, self.p_drop, self._site_seed(sp), 0, mode=1) > 0
+        return keep.float() / (1.0 - self.p_drop)
+
+    def temb_forward(self, sigma: torch.Tensor) -> torch.Tensor:
+        """timestep_embedder(sincos(1000 sigma)) [B, D] fp32 with the LoRA branches B A dropout(.) on both linears
+        (diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) -> Linear -> SiLU -> Linear).  These are
+        [B<=4, 256..D] products: done with torch on the device, the intermediates are kept for ``temb_backward``."""
+        sp1, sp2 = self._spec('temb.t.l1'), self._spec('temb.t.l2')
+        t = sigma.to(self.dev, torch.float32).reshape(-1) * 1000.0
+        freqs = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32, device=self.dev) / 128.0)
+        ang = t[:, None] * freqs[None]
+        s = torch.cat([ang.cos(), ang.sin()], dim=1)                                   # [B, 256], cos first
+        W1, W2 = self.base['temb.t.l1'].float(), self.base['temb.t.l2'].float()
+        b1, b2 = self.packed['temb.t.l1.bias'].float(), self.packed['temb.t.l2.bias'].float()
+        A1, B1, A2, B2 = (self.a16[sp1.name].float(), self.b16[sp1.name].float(), self.a16[sp2.name].float(), self.b16[sp2.name].float())
+        k1, k2 = self._keep_scale(sp1, s.shape[0], 256), self._keep_scale(sp2, s.shape[0], self.D)
+        sd = s if k1 is None else s * k1
+        u = s @ W1.t() + b1 + (sd @ A1.t()) @ B1.t()
+        h = torch.nn.functional.silu(u)
+        hd = h if k2 is None else h * k2
+        y = h @ W2.t() + b2 + (hd @ A2.t()) @ B2.t()
+        self._temb_cache = (sd, u, hd, k2, W2, A1, B1, A2, B2)
+        return y.contiguous()
+
+    def temb_backward(self, dtemb: torch.Tensor, grads: torch.Tensor) -> None:
+        """dtemb [B, D] = d loss / d timestep-embedding output; accumulates dA, dB of both linears into ``grads``."""
+        sp1, sp2 = self._spec('temb.t.l1'), self._spec('temb.t.l2')
+        sd, u, hd, k2, W2, A1, B1, A2, B2 = self._temb_cache
+        dT2 = dtemb @ B2                                                               # [B, r]
+        self.B(sp2, grads).add_(dtemb.t() @ (hd @ A2.t()))
+        self.A(sp2, grads).add_(dT2.t() @ hd)
+        dh = dtemb @ W2 + (dT2 @ A2) * (1.0 if k2 is None else k2)
+        sg = torch.sigmoid(u)
+        du = dh * (sg * (1 + u * (1 - sg)))
+        self.B(sp1, grads).add_(du.t() @ (sd @ A1.t()))
+        self.A(sp1, grads).add_((du @ B1).t() @ sd)
+
     def _site_seed(self, sp: LoraSpec) -> int:
         return (self.seed * 0x9E3779B1 + (sp.off_a * 2654435761 % (1 << 32))) & 0xffffffff
 
@@ -211,15 +267,21 @@ class LoraTrunk:
         Xo = torch.empty(S, D, **bf) if fwd_only else None
         for s, rows, _ in self._streams(T, S):
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-            ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], epilogue='gate_res', gate=mv[(s, 2)],
-                       residual=X[rows], out=X1[rows])
+            if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
+                y1 = self.ybuf[2 * i, self.row0:self.row0 + S][rows]
+                ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], out=y1)
+                ops.gate_residual(y1, mv[(s, 2)], X[rows], out=X1[rows])
+            else:
+                ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], epilogue='gate_res', gate=mv[(s, 2)],
+                           residual=X[rows], out=X1[rows])
             ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
             ops.linear(Xn2[rows], pk[p + s + '_mlp1.weight'], pk[p + s + '_mlp1.bias'], out=Pre[rows],
                        pre=self._corr(sp1, Xn2[rows], rows.start))
             ops.gelu(Pre[rows], out=Hh[rows])
             if fwd_only:
-                ops.linear(Hh[rows], pk[p + s + '_mlp2.weight'], pk[p + s + '_mlp2.bias'], epilogue='gate_res', gate=mv[(s, 5)],
-                           residual=X1[rows], out=Xo[rows], pre=self._corr(sp2, Hh[rows], rows.start))
+                y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows]
+                ops.linear(Hh[rows], pk[p + s + '_mlp2.weight'], pk[p + s + '_mlp2.bias'], out=y2, pre=self._corr(sp2, Hh[rows], rows.start))
+                ops.gate_residual(y2, mv[(s, 5)], X1[rows], out=Xo[rows])
         if fwd_only:
             return Xo
         # ---- backward ----
@@ -236,6 +298,11 @@ class LoraTrunk:
             dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
             self._dx_extra(sp1, dT1, dXn2, rows.start)
             ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
+            if self.dmod is not None:      # d(shift3, scale4, gate5, gate2) of this stream
+                so = m0 + (0 if s == 'img' else 6) * D
+                ops.coldot(dXo[rows], self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows], self.dmod[so + 5 * D:so + 6 * D])
+                self._dmod_ln(X1[rows], dXn2, so + 4 * D, so + 3 * D)
+                ops.coldot(dX1[rows], self.ybuf[2 * i, self.row0:self.row0 + S][rows], self.dmod[so + 2 * D:so + 3 * D])
             dYo = ops.add_scale(dX1[rows], gate=mv[(s, 2)])
             ops.linear(dYo, self.wt[p + s + '_out'], out=dO[rows])
         dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
@@ -247,6 +314,9 @@ class LoraTrunk:
         for s, rows, _ in self._streams(T, S):
             dXn1 = ops.linear(dQKVp[rows], self.wt[p + s + '_qkv'])
             ops.ln_modulate_backward(X[rows], dXn1, mv[(s, 1)], dres=dX1[rows], out=dX[rows])
+            if self.dmod is not None:
+                so = m0 + (0 if s == 'img' else 6) * D
+                self._dmod_ln(X[rows], dXn1, so + D, so)
         return dX
 
     def _single_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: Optional[torch.Tensor], grads,
@@ -276,8 +346,9 @@ class LoraTrunk:
         lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
         ops.gelu(Mp, out=G[:, D:])
         if fwd_only:
-            return ops.linear(G, pk[p + 'out.weight'], pk[p + 'out.bias'], epilogue='gate_res', gate=gt, residual=X,
-                              pre=self._corr(sp_out, G, 0))
+            y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S]
+            ops.linear(G, pk[p + 'out.weight'], pk[p + 'out.bias'], out=y, pre=self._corr(sp_out, G, 0))
+            return ops.gate_residual(y, gt, X)
         # ---- backward ----
         dY = ops.add_scale(dXo, gate=gt)
         dT_out = self._lora_grad(sp_out, G, dY, grads) if sp_out is not None else None
@@ -292,6 +363,9 @@ class LoraTrunk:
         self._rope(Qp, dFp[:, 2 * D:3 * D], qkn[0], qkn[0], cos, sin, S, T, dy=dQ)
         dXn = ops.linear(dFp, self.wt[p + 'fused'])
         self._dx_extra(sp_mlp, dT_mlp, dXn, 0)
+        if self.dmod is not None:          # d(shift, scale, gate) of the single-stream AdaLN
+            ops.coldot(dXo, self.ybuf[2 * self.nd + i, self.row0:self.row0 + S], self.dmod[m0 + 2 * D:m0 + 3 * D])
+            self._dmod_ln(X, dXn, m0 + D, m0)
         return ops.ln_modulate_backward(X, dXn, sc, dres=dXo)
 
     def _spec(self, key: str) -> Optional[LoraSpec]:
@@ -307,6 +381,8 @@ class LoraTrunk:
         self.row0 = b * S
         mod = mod_all[b]
         cos, sin = self.eng.rope_tables(hp, wp, T)
+        if self.ybuf is None or self.ybuf.shape[1] != x_tokens.shape[0]:
+            self.ybuf = torch.empty(2 * self.nd + self.ns, x_tokens.shape[0], self.D, dtype=torch.bfloat16, device=self.dev)
         X = x_tokens[b * S:(b + 1) * S]
         for i in range(self.nd):
             ckpt[i, b * S:(b + 1) * S].copy_(X)
@@ -318,13 +394,15 @@ class LoraTrunk:
 
     # ------------------------------------------------------------------ whole-trunk backward of one sample
     def backward_sample(self, ckpt: torch.Tensor, b: int, mod_all: torch.Tensor, x_final_img: torch.Tensor,
-                        dxn_img: torch.Tensor, T: int, N: int, hp: int, wp: int, grads: torch.Tensor) -> None:
+                        dxn_img: torch.Tensor, T: int, N: int, hp: int, wp: int, grads: torch.Tensor,
+                        dmod_out: Optional[torch.Tensor] = None) -> None:
         """ckpt [nblocks, B*S, D] block inputs of the last student forward; mod_all [B, n_mod]; x_final_img [N, D] the
         image tokens entering norm_out; dxn_img [N, D] the gradient at the velocity head's input.  Accumulates the
         LoRA gradients of sample b into ``grads``."""
         D, S = self.D, T + N
         mod = mod_all[b]
         self.row0 = b * S
+        self.dmod = dmod_out            # [n_mod] fp32 of this sample (zeroed by the caller), or None: no modulation gradients
         cos, sin = self.eng.rope_tables(hp, wp, T)
         fin = (self.nd * 12 + self.ns * 3) * D
         dX = torch.zeros(S, D, dtype=torch.bfloat16, device=self.dev)

@@ -187,6 +187,15 @@ int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, 
 /* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn) */
 int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
                          int32_t D, int32_t rows_per_batch, void* stream);
+/* Modulation gradients of the blocks (needed by the timestep-embedder LoRA pair, configs/flux/arcflux_2nfe_k16.py:46-47):
+ * out_accum[c] += sum_r a[r,c] b[r,c] (d_gate = sum_tokens dX_out * branch output);  out = res + gate[c] * y (gated residual kept
+ * apart from the GEMM so that y can be stored);  out_accum[b,k] += sum_n x[b,n] W[n,k] (d silu(temb) through the stacked
+ * modulation matrix W [n_mod, D], read once; B <= 4) */
+int afx_coldot_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* out_accum, int32_t rows, int32_t cols, void* stream);
+int afx_gate_residual_bf16(const void* y, int64_t ldy, const float* gate, const void* res, int64_t ldr, void* out, int64_t ldo,
+                           int64_t rows, int32_t cols, void* stream);
+int afx_gemv_t_bf16(const float* x, int64_t ldx, const void* W, int64_t ldw, float* out_accum, int32_t B, int64_t N, int32_t K,
+                    void* stream);
 /* dW_accum[J,Kd] += sum_b dmod[b,J] x[b,Kd]   (norm_out.linear weight gradient, B <= 8) */
 int afx_outer_accum(const float* dmod, const float* x, float* dW_accum, int32_t B, int32_t J, int32_t Kd, void* stream);
 /* Staged forward for the training student with LoRA input dropout (lakonlab .../arcflux.py:294-302 lora_dropout): stage 1 runs
@@ -197,6 +206,10 @@ int afx_mmdit_forward_stage(afx_ctx* ctx, const void* x, const void* ctx_emb, co
                             const float* rope_cos, const float* rope_sin, int32_t B, int32_t N, int32_t T, void* means, void* logw,
                             void* logg, int32_t stage, void* stream);
 int afx_mmdit_import_tokens(afx_ctx* ctx, const void* src, int32_t batch, int32_t n_img, int32_t n_txt, void* stream);
+/* Timestep-embedding override: when set (device pointer to [B, D] f32, NULL to clear) the next forwards use it in place of
+ * timestep_embedder(sincos(1000 t)); the guidance / pooled-text embeddings are still added.  The training student computes it
+ * host-side with the LoRA pair on the two tiny linears (and their input dropout). */
+int afx_set_temb_override(afx_ctx* ctx, const float* temb_t);
 
 /* Copy an activation of the LAST afx_mmdit_forward out of the workspace: "head_in" [B*N,D] bf16,
  * "x_final" [B*N,D] bf16, "silu_temb" [B,D] f32, "mod_final" [B,2D] f32 (scale|shift of norm_out),

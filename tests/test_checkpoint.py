@@ -46,8 +46,9 @@ def test_state_dict_names_follow_the_reference_layout():
     exported = CK.export_adapter_state({CK.EMA_PREFIX + k: v for k, v in sd.items()}, ema=True)
     assert 'transformer_blocks.1.ff.net.0.proj.lora_A.weight' in exported and not any('default' in k for k in exported)
     back2 = torch.zeros(n)
-    extra = CK.state_to_flat(dict(exported, **{'time_text_embed.timestep_embedder.linear_1.lora_A.weight': torch.zeros(8, 256)}), back2, lay)
-    assert extra == ['time_text_embed.timestep_embedder.linear_1.lora_A.weight']
+    extra = CK.state_to_flat(dict(exported, **{'time_text_embed.guidance_embedder.linear_1.lora_A.weight': torch.zeros(8, 256)}), back2, lay)
+    assert extra == ['time_text_embed.guidance_embedder.linear_1.lora_A.weight']
+    assert 'time_text_embed.timestep_embedder.linear_2.lora_B.weight' in exported            # arcflux_2nfe_k16.py:46-47
     mask = torch.ones(n, dtype=torch.bool)
     hw = mask[:lay.offsets[1]].view(lay.head_n, lay.D)
     hw[1148:] = False

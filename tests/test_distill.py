@@ -211,7 +211,7 @@ def test_lora_trunk_backward_matches_cpu_autograd():
         ea, eb = rel_l2(ga, ra), rel_l2(gb, rb)
         worst = max(worst, ea, eb)
         assert ea < 8e-2 and eb < 8e-2, (sp.name, ea, eb)
-    assert len(tr.specs) == len(lora_targets('flux', 1, 1, 256)) == 6
+    assert len(tr.specs) == len(lora_targets('flux', 1, 1, 256)) == 8        # 6 block linears + the timestep-embedder pair
     # the step changed the adapters and re-merged the student's weights
     sp = tr.specs[0]
     assert (tr.A(sp).cpu() - AB[sp.name][0]).abs().max().item() > 0
@@ -243,7 +243,7 @@ def test_qwen_distill_step_with_true_cfg_teacher():
                        teacher_guidance_scale=4.0)
     dist = ArcFlowDistiller('qwen', dict(num_double=2, heads=2, joint_dim=192), w, dc)
     tr = dist.trunk
-    assert len(tr.specs) == 6                       # 2 x img_mlp pairs + 1 x txt_mlp pair
+    assert len(tr.specs) == 8                       # 2 x img_mlp pairs + 1 x txt_mlp pair + the timestep-embedder pair
     AB = {}
     for sp in tr.specs:
         tr.B(sp).copy_((torch.randn(sp.out_f, r, generator=g) * 0.02).cuda())
@@ -360,9 +360,13 @@ def test_lora_dropout_train_step_matches_cpu_autograd():
         ws = dict(wt)
         tr.seed = seeds[step]
         for sp in tr.specs:
-            ks = ops.lora_dropout(torch.ones(B * S, sp.in_f, dtype=torch.bfloat16, device='cuda'), pdrop, tr._site_seed(sp), 0, mode=1)
-            ks = (ks.float().cpu().view(B, S, sp.in_f) > 0).float() / (1 - pdrop)
-            if 'ff_context' in sp.name:
+            rows = B if 'time_text_embed' in sp.name else B * S        # the embedder's rows are the samples
+            ks = ops.lora_dropout(torch.ones(rows, sp.in_f, dtype=torch.bfloat16, device='cuda'), pdrop, tr._site_seed(sp), 0, mode=1)
+            ks = (ks.float().cpu() > 0).float() / (1 - pdrop)
+            ks = ks if rows == B else ks.view(B, S, sp.in_f)
+            if 'time_text_embed' in sp.name:
+                pass
+            elif 'ff_context' in sp.name:
                 ks = ks[:, :T]
             elif 'transformer_blocks' in sp.name and 'single' not in sp.name:
                 ks = ks[:, T:]
