@@ -72,7 +72,7 @@ def flat_to_state(flat: torch.Tensor, lay: TrainableLayout, peft_names: bool = F
 
 def state_to_flat(sd: Dict[str, torch.Tensor], flat: torch.Tensor, lay: TrainableLayout, strict: bool = True) -> List[str]:
     """Copy a (reference- or export-named) trainable state dict into the flat buffer.  Returns the keys of ``sd`` that
-    this engine does not train (e.g. the timestep-embedder LoRA pair); a missing trainable raises when ``strict``."""
+    this engine does not train (adapters on other modules); a missing trainable raises when ``strict``."""
     norm = {k.replace('.lora_A.default.', '.lora_A.').replace('.lora_B.default.', '.lora_B.'): v for k, v in sd.items()}
     dst = flat_to_state(flat, lay, peft_names=False)
     missing = [k for k in dst if k not in norm]
