@@ -261,16 +261,24 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   atomicAdd(out + c, acc);
 }
 
-// out[c] += sum_r a[r, c] * b[r, c]: gradient of an AdaLN gate, d_gate = sum_tokens dX_out * branch_output
+// out[c] += sum_r a[r, c] * b[r, c]: gradient of an AdaLN gate, d_gate = sum_tokens dX_out * branch_output.
+// One 16-byte column chunk per thread, a slab of rows per block.
 __global__ __launch_bounds__(256) void coldot_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb,
                                                      float* __restrict__ out, int R, int C, int rows_per_block) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  if (c >= (C >> 3)) return;
   const int r0 = blockIdx.y * rows_per_block;
   const int r1 = min(R, r0 + rows_per_block);
-  float acc = 0.f;
-  for (int r = r0; r < r1; ++r) acc += bf16_to_f32(a[(int64_t)r * lda + c]) * bf16_to_f32(b[(int64_t)r * ldb + c]);
-  atomicAdd(out + c, acc);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float x[8], y[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(a + (int64_t)r * lda + c * 8), x);
+    unpack8(*reinterpret_cast<const u32x4_t*>(b + (int64_t)r * ldb + c * 8), y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += x[e] * y[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) atomicAdd(out + c * 8 + e, acc[e]);
 }
 
 // out[r, c] = res[r, c] + gate[c] * y[r, c]   (the gated residual, kept apart from the GEMM when y itself is needed later)
@@ -333,15 +341,15 @@ __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restri
   const int lane = threadIdx.x & 63;
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row0 = wv * rows_per_wave;
-  if (row0 >= rows) return;
+  const bool active = row0 < rows;
   const int nchunk = D >> 3;
-  const int b = row0 / rows_per_batch;            // rows_per_wave divides rows_per_batch
+  const int b = active ? row0 / rows_per_batch : 0;   // rows_per_wave divides rows_per_batch
   float ds[8][8], dh[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ds[i][e] = dh[i][e] = 0.f;
-  for (int row = row0; row < min(rows, row0 + rows_per_wave); ++row) {
+  for (int row = row0; active && row < min(rows, row0 + rows_per_wave); ++row) {
     float v[8][8];
     float s = 0.f;
 #pragma unroll
@@ -381,17 +389,28 @@ __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restri
       }
     }
   }
+  // combine the 4 waves of the block in LDS (they almost always belong to one batch entry): one global atomic set per block
+  extern __shared__ float red[];                 // [2][D]
+  __shared__ int b_blk;
+  if (threadIdx.x == 0) b_blk = b;               // wave 0 of a launched block always has rows
+  for (int j = threadIdx.x; j < 2 * D; j += 256) red[j] = 0.f;
+  __syncthreads();
+  if (active) {
+    float* dst0 = b == b_blk ? red : dmod + (int64_t)b * 2 * D;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const int c = lane + i * 64;
-    if (c < nchunk) {
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(dmod + ((int64_t)b * 2 + 0) * D + c * 8 + e, ds[i][e]);
-        atomicAdd(dmod + ((int64_t)b * 2 + 1) * D + c * 8 + e, dh[i][e]);
+        for (int e = 0; e < 8; ++e) {
+          atomicAdd(dst0 + c * 8 + e, ds[i][e]);
+          atomicAdd(dst0 + D + c * 8 + e, dh[i][e]);
+        }
       }
     }
   }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * D; j += 256) atomicAdd(dmod + (int64_t)b_blk * 2 * D + j, red[j]);
 }
 
 // dW[j, k] += sum_b dmod[b, j] * x[b, k]   (rank-B update of the norm_out.linear weight, B <= 8)
@@ -564,9 +583,9 @@ int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, 
 }
 
 int afx_coldot_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, float* out_accum, int32_t rows, int32_t cols, void* stream) {
-  if (!a || !b || !out_accum || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_coldot_bf16");
-  const int rpb = 256;
-  hipLaunchKernelGGL(coldot_kernel, dim3((cols + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
+  if (!a || !b || !out_accum || rows < 1 || cols < 8 || cols % 8 || lda % 8 || ldb % 8) return fail(AFX_E_INVALID, "bad argument to afx_coldot_bf16");
+  const int rpb = 32;
+  hipLaunchKernelGGL(coldot_kernel, dim3(((cols >> 3) + 255) / 256, (rows + rpb - 1) / rpb), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)a, lda, (const bf16_t*)b, ldb, out_accum, rows, cols, rpb);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
@@ -596,10 +615,10 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
                          int32_t D, int32_t rows_per_batch, void* stream) {
   if (!x || !dxn || !dmod_accum || rows < 1 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1 || rows % rows_per_batch)
     return fail(AFX_E_INVALID, "bad argument to afx_normout_backward");
-  int rpw = 16;
+  int rpw = rows_per_batch >= 2048 ? 32 : 16;
   while (rows_per_batch % rpw) rpw >>= 1;
   const int waves = rows / rpw;
-  hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+  hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dxn, ldd, dmod_accum, rows, D, rows_per_batch, rpw);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
