@@ -6,7 +6,8 @@
 // v_mfma_f32_32x32x16_bf16 (-12 %: the 2-deep accumulator chains stall), 2 phases of 32 MFMAs per K-tile (+3 % on
 // cache-resident operands but -7 % in the real forward, where the halved DMA lead time meets HBM latency), LDS reads
 // levelled 8/4/8/4 over the phases (0 %), one barrier per K-tile with every wave interleaving its own ds_reads / DMA with
-// its MFMAs (-21 %: the vmcnt(0) in front of the barrier drains the DMA queue).
+// its MFMAs (-21 %: the vmcnt(0) in front of the barrier drains the DMA queue), k-quarter phases of 8 independent
+// v_mfma_f32_32x32x16_bf16 with 32-byte-row DMA pieces (-36 %: 4x the L2 requests per byte).
 // Cycle budget of one 256x256 tile, K = 3072 (tools/gemm_trace.hip, s_memtime): prologue 3.2 k, main loop 118 k
 // (2464 per K-tile; 2048 = 128 MFMAs x 16 cycles is the floor), epilogue 7.9 k.
 // Structure (wave64, 8 waves = 2(M) x 4(N), 256x256x64 tile, one work-group per CU):
