@@ -193,3 +193,32 @@ def test_flux_encode_prompt_with_hip_encoders():
         rp, re = clip(input_ids=ids).pooler_output, t5(input_ids=ids2).last_hidden_state
     assert pe.shape == (2, 128, 128) and pooled.shape == (2, 64)
     assert _rel(pe[0], re[0]) < 2e-2 and _rel(pooled[1], rp[0]) < 2e-2
+
+
+def test_prompt_cache_round_trip_and_online_cond(tmp_path):
+    """tools/cache_prompts.py path: prompts -> HIP encoders -> cache files -> PromptEmbedCache -> collate == online cond."""
+    from transformers import CLIPTextConfig, CLIPTextModel, T5Config, T5EncoderModel
+    from arcflow_amd.pipelines import ArcFluxPipeline
+    from arcflow_amd.text_encoders import CLIPTextEncoder, T5Encoder
+    from arcflow_amd.train import data as DATA
+    from arcflow_amd.train.prompts import PromptEncoder, write_cache
+    torch.manual_seed(5)
+    t5 = _bf16_weights(T5EncoderModel(T5Config(vocab_size=300, d_model=128, d_kv=64, d_ff=256, num_layers=1, num_heads=2,
+                                               feed_forward_proj='gated-gelu', dropout_rate=0.0)).eval())
+    clip = _bf16_weights(CLIPTextModel(CLIPTextConfig(vocab_size=300, hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=1,
+                                                      max_position_embeddings=77, eos_token_id=2, bos_token_id=298, pad_token_id=299)).eval())
+    pipe = ArcFluxPipeline()
+    pipe.tokenizer, pipe.tokenizer_2 = _Tok(300, pad_id=299, eos_id=299, bos_id=298), _Tok(300, pad_id=0, eos_id=1)
+    pipe.text_encoder = CLIPTextEncoder(clip.state_dict(), num_layers=1, num_heads=1, eos_token_id=2)
+    pipe.text_encoder_2 = T5Encoder(t5.state_dict(), num_layers=1, num_heads=2, d_kv=64)
+    enc = PromptEncoder('flux', pipe, max_sequence_length=64)
+    prompts = ['a fox', 'two red cubes on a table', 'sunset']
+    names = write_cache(enc, prompts, str(tmp_path / 'cache'), latent_size=(16, 16, 16), batch=2, compress=False)
+    assert names == ['00000000', '00000001', '00000002'] and (tmp_path / 'cache.jsonl').exists()
+    ds = DATA.PromptEmbedCache(str(tmp_path / 'cache'), pad_seq_len=64)
+    assert len(ds) == 3 and ds[1]['name'] == prompts[1]
+    batch = DATA.collate([ds[0], ds[1]], device='cuda')
+    online = enc.cond(prompts[:2], 8, 8)
+    assert (batch['hp'], batch['wp']) == (8, 8)
+    assert _rel(batch['prompt_embeds'], online['prompt_embeds'].cpu()) < 4e-3          # fp16 storage of bf16 values
+    assert _rel(batch['pooled'], online['pooled'].cpu()) < 4e-3

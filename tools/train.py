@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument('--transformer-dir', help='local diffusers transformer directory of the teacher')
     ap.add_argument('--synthetic', action='store_true', help='random-init weights and prompt embeddings')
     ap.add_argument('--data-dir', help='prompt-embedding cache directory')
+    ap.add_argument('--prompts', help='text file, one prompt per line: encode on the fly with the HIP text encoders (needs --snapshot)')
+    ap.add_argument('--snapshot', help='local FLUX.1-dev / Qwen-Image snapshot (text_encoder*/, tokenizer*/) for --prompts')
     ap.add_argument('--latent-tokens', type=int, nargs=2, default=[64, 64], help='synthetic data: packed latent grid (64 64 = 1024^2)')
     ap.add_argument('--export', help='write the EMA adapter (diffusers layout) here when done')
     return ap.parse_args()
@@ -117,6 +119,21 @@ def main():
                     yield data.collate([ds[j] for j in idx[i:i + B]], device=dev)
                 epoch += 1
         loader = batches()
+    elif args.prompts:          # text encoder inside the training process (the uncommented text_encoder of _ddp_train.py)
+        if not args.snapshot:
+            raise SystemExit('--prompts needs --snapshot')
+        from arcflow_amd.train.prompts import PromptEncoder
+        enc = PromptEncoder.from_snapshot(family, args.snapshot)
+        with open(args.prompts, encoding='utf-8') as f:
+            lines = [l.rstrip('\n') for l in f if l.strip()]
+        neg = [' '] * B if dc.teacher_guidance_scale > 1.0 else None
+
+        def prompt_batches():
+            i = rank * B + dist_.iteration * B * world
+            while True:
+                yield enc.cond([lines[(i + j) % len(lines)] for j in range(B)], args.latent_tokens[0], args.latent_tokens[1], neg)
+                i += B * world
+        loader = prompt_batches()
     else:
         T = 512 if family == 'flux' else 128
         synth = dict(prompt_embeds=(torch.randn(B, T, eng['joint_dim'], device=dev, generator=rng) * 0.1).bfloat16(), hp=args.latent_tokens[0], wp=args.latent_tokens[1])
