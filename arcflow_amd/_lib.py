@@ -13,6 +13,7 @@ from .build import lib_path
 
 AFX_DT_BF16 = 1
 AFX_DT_F32 = 2
+AFX_DT_FP8 = 3
 
 EXPORTS = [
     'afx_last_error', 'afx_version', 'afx_create', 'afx_destroy', 'afx_bind_weight', 'afx_finalize',
@@ -24,9 +25,9 @@ EXPORTS = [
     'afx_conv3x3_bf16', 'afx_groupnorm_nhwc', 'afx_upsample2x_nhwc', 'afx_interior_nhwc', 'afx_softmax_rows_f32',
     'afx_latent_to_nhwc', 'afx_nhwc_to_image', 'afx_latent_to_nhwc_affine', 'afx_rmsnorm_nhwc',
     'afx_embed_rows_bf16', 'afx_norm_rows_bf16', 'afx_act_mul_bf16', 'afx_rope_half_bf16', 'afx_attention_ext_ws_bytes',
-    'afx_attention_ext_bf16', 'afx_linear_bf16_splitk', 'afx_finish_f32_bf16', 'afx_linear_splitk_chunks',
+    'afx_attention_ext_bf16', 'afx_linear_bf16_splitk', 'afx_finish_f32_bf16', 'afx_linear_splitk_chunks', 'afx_quant_rows_fp8', 'afx_linear_fp8',
     'afx_linear_bf16_pre', 'afx_lora_dropout_bf16', 'afx_mmdit_forward_stage', 'afx_mmdit_import_tokens',
-    'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override',
+    'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override', 'afx_set_fp8_linear',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
     'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward',
     'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
@@ -103,6 +104,8 @@ def load() -> C.CDLL:
     lib.afx_rope_half_bf16.argtypes = [vp, i64, vp, vp, i32, i32, i32, vp]
     lib.afx_linear_bf16_splitk.argtypes = [vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, vp]
     lib.afx_finish_f32_bf16.argtypes = [vp, i32, vp, i64, vp, i64, i64, i32, vp]
+    lib.afx_quant_rows_fp8.argtypes = [vp, i64, vp, i64, vp, i32, i32, vp]
+    lib.afx_linear_fp8.argtypes = [vp, i64, vp, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, i32, vp, i64, vp]
     lib.afx_linear_splitk_chunks.argtypes = [i32, i32, i32, i32]
     lib.afx_linear_bf16_pre.argtypes = [vp, i64, vp, i64, vp, vp, i64, i32, i32, i32, i32, i32, vp, i64, i32, vp, i64, vp, i64, vp]
     lib.afx_lora_dropout_bf16.argtypes = [vp, i64, vp, i64, i64, i32, i64, f32, C.c_uint32, i32, vp]
@@ -112,6 +115,7 @@ def load() -> C.CDLL:
     lib.afx_gate_residual_bf16.argtypes = [vp, i64, vp, vp, i64, vp, i64, i64, i32, vp]
     lib.afx_gemv_t_bf16.argtypes = [vp, i64, vp, i64, vp, i32, i64, i32, vp]
     lib.afx_set_temb_override.argtypes = [vp, vp]
+    lib.afx_set_fp8_linear.argtypes = [vp, i32]
     lib.afx_linear_splitk_chunks.restype = i32
     lib.afx_attention_ext_ws_bytes.argtypes = [i32, i32, i32, i32]
     lib.afx_attention_ext_ws_bytes.restype = i64

@@ -57,6 +57,7 @@ struct afx_ctx {
   int64_t n_mod = 0;       // rows of the stacked modulation linear
   int head_n = 0;          // padded head width
   uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
+  bool fp8 = false;            // block linears on the fp8 MFMA (afx_set_fp8_linear)
   const float* temb_override = nullptr;   // optional [B, D] f32 replacing timestep_embedder(t) (training student with its LoRA pair)
   // optional per-launch-class timing (HIP events on the forward's stream)
   bool prof_on = false;
@@ -74,6 +75,11 @@ const uint16_t* W16(const afx_ctx* c, const std::string& n) {
 const float* W32(const afx_ctx* c, const std::string& n) {
   auto it = c->w.find(n);
   return it == c->w.end() ? nullptr : (const float*)it->second.ptr;
+}
+
+const void* WQ(const afx_ctx* c, const std::string& n) {
+  auto it = c->w.find(n);
+  return it == c->w.end() ? nullptr : it->second.ptr;
 }
 
 int need(const afx_ctx* c, const std::string& n, int dtype, std::vector<int64_t> shape) {
@@ -110,6 +116,8 @@ struct ModLayout {
 struct Workspace {
   uint16_t *X, *Xn, *F, *Vt, *head;
   float *sincos, *tmp, *temb, *semb, *mod, *pooled;
+  uint8_t* q8;     // fp8 mode: the quantised A operand of the GEMM about to run [R, <= 5D]
+  float* qs;       //           its per-row scales [R]
   int64_t total;
 };
 
@@ -133,6 +141,12 @@ Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
   w.semb = (float*)take((int64_t)B * D * 4);
   w.pooled = (float*)take((int64_t)B * (c->d.pooled_dim > 0 ? c->d.pooled_dim : 8) * 4);
   w.mod = (float*)take((int64_t)B * c->n_mod * 4);
+  w.q8 = nullptr;
+  w.qs = nullptr;
+  if (c->fp8) {
+    w.q8 = (uint8_t*)take(R * 5 * D);
+    w.qs = (float*)take(R * 4);
+  }
   w.total = off;
   return w;
 }
@@ -197,7 +211,7 @@ int afx_destroy(afx_ctx* ctx) {
 int afx_bind_weight(afx_ctx* ctx, const char* name, const void* dptr, int32_t dtype, int32_t ndim,
                     const int64_t* shape) {
   if (!ctx || !name || !dptr || ndim < 1 || ndim > 4 || !shape) return fail(AFX_E_INVALID, "bad bind_weight argument");
-  if (dtype != AFX_DT_BF16 && dtype != AFX_DT_F32) return fail(AFX_E_INVALID, "bad dtype for '%s'", name);
+  if (dtype != AFX_DT_BF16 && dtype != AFX_DT_F32 && dtype != AFX_DT_FP8) return fail(AFX_E_INVALID, "bad dtype for '%s'", name);
   Weight w;
   w.ptr = dptr;
   w.dtype = dtype;
@@ -351,6 +365,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const std::string& pre, const char* suffix,
                          uint16_t* C, int64_t ldc, int Nout, int epi, int blk, int gate_chunk) -> int {
     GemmBatch gb{};
+    if (c->fp8) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
     for (int b = 0; b < B; ++b)
       for (int s = 0; s < 2; ++s) {   // 0 image rows, 1 text rows
         GemmProblem& p = gb.p[gb.nprob++];
@@ -359,6 +374,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         const std::string wn = pre + (s == 0 ? "img_" : "txt_") + suffix;
         p.A = A + row0 * lda; p.lda = lda;
         p.W = W16(c, wn + ".weight"); p.ldw = K; p.bias = W16(c, wn + ".bias");
+        if (c->fp8) {
+          p.A = (const uint16_t*)(ws.q8 + row0 * K); p.lda = K;
+          p.W = (const uint16_t*)WQ(c, wn + ".weight_q"); p.fp8 = 1; p.a_scale = ws.qs + row0; p.w_scale = W32(c, wn + ".wscale");
+        }
         p.C = C + row0 * ldc; p.ldc = ldc;
         p.M = (s == 0 ? N : T); p.N = Nout; p.K = K;
         p.epi = epi; p.gelu_col0 = 0;
@@ -414,6 +433,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     f = GemmProblem{};
     f.A = ws.Xn; f.lda = D; f.W = W16(c, p + "fused.weight"); f.ldw = D; f.bias = W16(c, p + "fused.bias");
     f.C = ws.F; f.ldc = 7 * D; f.M = (int)R; f.N = (int)(7 * D); f.K = (int)D; f.epi = EPI_GELU; f.gelu_col0 = (int)(3 * D);
+    if (c->fp8) {
+      HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));
+      f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)WQ(c, p + "fused.weight_q"); f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = W32(c, p + "fused.wscale");
+    }
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
     HIP_TRY(launch_qk_norm_rope(ws.F, 7 * D, qkn + 128, qkn + 128, rope_cos, rope_sin, B, S, T, H, st));                 // k
     HIP_TRY(launch_qk_norm_rope(ws.F + 2 * D, 7 * D, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));                     // q
@@ -426,6 +449,11 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     o.A = ws.F + 2 * D; o.lda = 7 * D; o.W = W16(c, p + "out.weight"); o.ldw = 5 * D; o.bias = W16(c, p + "out.bias");
     o.C = ws.X; o.ldc = D; o.M = (int)R; o.N = (int)D; o.K = (int)(5 * D); o.epi = EPI_GATE_RES;
     o.gate = ws.mod + ml.sgl(i, 2); o.ldg = ldm; o.rows_per_batch = S; o.res = ws.X; o.ldr = D;
+    if (c->fp8) {
+      HIP_TRY(launch_quant_rows_fp8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.qs, (int)R, (int)(5 * D), st));
+      o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)WQ(c, p + "out.weight_q"); o.fp8 = 1; o.a_scale = ws.qs;
+      o.w_scale = W32(c, p + "out.wscale");
+    }
     { ProfScope ps_(c, st, 0, gemm_flops(go)); HIP_TRY(launch_gemm(go, st)); }
   }
 
@@ -451,6 +479,29 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   if (d.head_mode == 0)
     HIP_TRY(launch_head_split(ws.head, c->head_n, (uint16_t*)means, (uint16_t*)logw, (uint16_t*)logg, (int64_t)B * N,
                               d.num_gaussians, d.in_channels, d.logweights_channels, st));
+  return AFX_OK;
+}
+
+int afx_set_fp8_linear(afx_ctx* c, int32_t on) {
+  if (!c) return fail(AFX_E_INVALID, "null ctx");
+  if (on) {
+    const int64_t D = c->D;
+    int r;
+    auto chk = [&](const std::string& n, int64_t out_f, int64_t in_f) -> int {
+      if ((r = need(c, n + ".weight_q", AFX_DT_FP8, {out_f, in_f})) != AFX_OK) return r;
+      return need(c, n + ".wscale", AFX_DT_F32, {out_f});
+    };
+    for (int i = 0; i < c->d.num_double; ++i)
+      for (const char* s : {"img_", "txt_"}) {
+        const std::string p = "d" + std::to_string(i) + "." + s;
+        if ((r = chk(p + "qkv", 3 * D, D)) || (r = chk(p + "out", D, D)) || (r = chk(p + "mlp1", 4 * D, D)) || (r = chk(p + "mlp2", D, 4 * D))) return r;
+      }
+    for (int i = 0; i < c->d.num_single; ++i) {
+      const std::string p = "s" + std::to_string(i) + ".";
+      if ((r = chk(p + "fused", 7 * D, D)) || (r = chk(p + "out", D, 5 * D))) return r;
+    }
+  }
+  c->fp8 = on != 0;
   return AFX_OK;
 }
 

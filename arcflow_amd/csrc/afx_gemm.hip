@@ -132,6 +132,7 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
 // store are 16 bytes per lane (64 contiguous bytes per row and instruction), no LDS round trip, no barrier.
 AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
   const bool first_chunk = chunk == 0;
+  float wsc[2][8];            // fp8: per-output-channel weight scales of this lane's 2 x 8 columns
   int gcol[2];
   bool col_ok[2];
   float bias[2][8];
@@ -144,6 +145,14 @@ AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int ro
     if (P.bias != nullptr && col_ok[jp] && first_chunk) {
       const u32x4_t bw = *reinterpret_cast<const u32x4_t*>(P.bias + gcol[jp]);
       unpack8(bw, bias[jp]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) wsc[jp][e] = 1.f;
+    if (P.fp8 && col_ok[jp]) {
+      const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(P.w_scale + gcol[jp]);
+      const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(P.w_scale + gcol[jp] + 4);
+      wsc[jp][0] = s0[0]; wsc[jp][1] = s0[1]; wsc[jp][2] = s0[2]; wsc[jp][3] = s0[3];
+      wsc[jp][4] = s1[0]; wsc[jp][5] = s1[1]; wsc[jp][6] = s1[2]; wsc[jp][7] = s1[3];
     }
   }
 #pragma unroll
@@ -167,6 +176,11 @@ AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int ro
         v[4 + e] = __uint_as_float(sw[1]);
       }
       if (!row_ok || !col_ok[jp]) continue;
+      if (P.fp8) {
+        const float as = P.a_scale[grow];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= as * wsc[jp][e];
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] += bias[jp][e];
       if (P.pre != nullptr) {
@@ -350,9 +364,16 @@ __device__ unsigned int g_gemm_trace[2][8][32];
 #define AFX_TRC(i)
 #endif
 
-AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int64_t kbyte, char* slot, int wave) {
-  const char* s0 = reinterpret_cast<const char*>(p0) + kbyte;
-  const char* s1 = reinterpret_cast<const char*>(p1) + kbyte;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+
+AFX_DEV i32x8_t cat8(bf16x8_t lo, bf16x8_t hi) {      // two 16-byte fragments -> the 32-byte operand of the K = 128 fp8 MFMA
+  const u32x4_t a = __builtin_bit_cast(u32x4_t, lo), b = __builtin_bit_cast(u32x4_t, hi);
+  return (i32x8_t){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+}
+
+AFX_DEV void stage_half(const char* p0, const char* p1, int64_t kbyte, char* slot, int wave) {
+  const char* s0 = p0 + kbyte;
+  const char* s1 = p1 + kbyte;
   __builtin_amdgcn_global_load_lds((gbl_void_t*)s0, (lds_void_t*)(slot + (wave * 64) * 16), 16, 0, 0);
   __builtin_amdgcn_global_load_lds((gbl_void_t*)s1, (lds_void_t*)(slot + (GEMM_THREADS + wave * 64) * 16), 16, 0, 0);
 }
@@ -360,7 +381,12 @@ AFX_DEV void stage_half(const bf16_t* p0, const bf16_t* p1, int64_t kbyte, char*
 #define AFX_WAIT_VM8() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
 #define AFX_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const GemmBatch batch) {
+// FP8 = true: operands are OCP e4m3 bytes.  A 128-byte LDS row is then 128 k-values and one v_mfma_scale_f32_16x16x128_f8f6f4
+// (unit block scales; 2x the bf16 rate) covers the whole K-tile of a 16x16 output tile: the DMA / LDS / swizzle / phase code is
+// byte-for-byte the bf16 one, a phase is 8 MFMAs instead of 16.  The contraction order inside the instruction is free as
+// long as both operands agree, so lane (row, fq) simply feeds the two 16-byte chunks fq and 4 + fq it already reads.
+template <bool FP8>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -388,7 +414,8 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   const int tm = first_m + in_grp % gsz;
   const int tn = in_grp / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
-  int t0 = 0, nk = P.K / BK;
+  constexpr int ES = FP8 ? 1 : 2;       // bytes per operand element
+  int t0 = 0, nk = P.K * ES / (BK * 2);
   if (P.split_k > 1) {
     const int per = (nk + P.split_k - 1) / P.split_k;
     t0 = chunk * per;
@@ -402,7 +429,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
 #endif
 
   // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
-  const bf16_t* src[4][2];     // [X0, X1, Y0, Y1][chunk i]
+  const char* src[4][2];       // [X0, X1, Y0, Y1][chunk i]
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int p = i * GEMM_THREADS + tid;
@@ -412,10 +439,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
     for (int h = 0; h < 2; ++h) {
       int ar = m0 + (lr >> 6) * 128 + h * 64 + (lr & 63);
       ar = ar < P.M ? ar : P.M - 1;
-      src[h][i] = P.A + (int64_t)ar * P.lda + c * 8;
+      src[h][i] = reinterpret_cast<const char*>(P.A) + (int64_t)ar * P.lda * ES + c * 16;
       int br = n0 + (lr >> 5) * 64 + h * 32 + (lr & 31);
       br = br < P.N ? br : P.N - 1;
-      src[2 + h][i] = P.W + (int64_t)br * P.ldw + c * 8;
+      src[2 + h][i] = reinterpret_cast<const char*>(P.W) + (int64_t)br * P.ldw * ES + c * 16;
     }
   }
   // slot(buffer b, half h) = smem + (b*4 + h) * HALF_BYTES with h: 0 X0, 1 X1, 2 Y0, 3 Y1
@@ -455,11 +482,18 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel_v2(const Gem
   bf16x8_t af[2][4], b0[2][2], b1[2][2];    // [kk][tile]
 
 #define AFX_MFMA_QUAD(MH, NH, BF)                                                                   \
-  _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                  \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                     \
-    acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                      \
-        BF[kk][j], af[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);
+  if constexpr (FP8) {                                                                              \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+      acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(           \
+          cat8(BF[0][j], BF[1][j]), cat8(af[0][i], af[1][i]), acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f); \
+  } else {                                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                   \
+      acc[(MH) * 4 + i][(NH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                    \
+          BF[kk][j], af[kk][i], acc[(MH) * 4 + i][(NH) * 2 + j], 0, 0, 0);                          \
+  }
 
 #define AFX_PHASE_TAIL(MH, NH, BF, TI)                                                              \
   __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -551,7 +585,10 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel_v2),
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v2<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    if (r != hipSuccess) return r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v2<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
   }
@@ -562,10 +599,14 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   if (conv) use = 2;                                 // the implicit-conv addressing lives in the 8-phase kernel
   for (int i = 0; i < batch.nprob; ++i)
     if (batch.p[i].out_f32 == 3) use = 2;            // ... and so do split-K and the atomic epilogue
-  if (use == 1)
+  bool fp8 = false;
+  for (int i = 0; i < batch.nprob; ++i) fp8 = fp8 || batch.p[i].fp8 != 0;     // a launch is all-bf16 or all-fp8
+  if (fp8)
+    hipLaunchKernelGGL(gemm_kernel_v2<true>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+  else if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else
-    hipLaunchKernelGGL(gemm_bf16_kernel_v2, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+    hipLaunchKernelGGL(gemm_kernel_v2<false>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   return hipGetLastError();
 }
 

@@ -24,6 +24,9 @@ struct GemmProblem {
   int32_t split_k;      // > 1 (out_f32 == 3 only): the K range is cut into split_k chunks, one work-group per (tile, chunk);
   int64_t split_stride; //   chunk c stores its partial tile at C + c * split_stride floats (summed by a finishing pass)
   int32_t conv_cin_tiles, conv_wp, conv_hp;   // > 0: implicit 3x3 conv on a padded [conv_hp][conv_wp] NHWC grid, K = 9 * 64 * conv_cin_tiles
+  int32_t fp8;          // 1: A and W hold OCP e4m3 bytes (lda/ldw/K in elements = bytes, K % 128 == 0); the product is scaled by
+  const float* a_scale; //    a_scale[m] * w_scale[n] (per-row activation scale, per-output-channel weight scale) before the epilogue
+  const float* w_scale;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 
@@ -54,6 +57,9 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
                                      const float* lse, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk,
                                      uint16_t* dv, int64_t lddv, void* ws, int B, int H, int S, hipStream_t stream);
 inline int64_t attn_spad(int S) { return ((int64_t)S + 63) / 64 * 64; }
+
+// row-wise OCP e4m3 quantisation (afx_text.hip): q = round(x / scale[r]), scale[r] = absmax(row) / 448
+hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int K, hipStream_t stream);
 
 // ---- element-wise / reductions -----------------------------------------------------------------
 hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,

@@ -123,6 +123,41 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
   *reinterpret_cast<u32x4_t*>(p + half) = pack8(ob);
 }
 
+// Row-wise fp8 quantisation (OCP e4m3): scale[r] = absmax(row) / 448, q = round(x / scale[r]).  One wave per row, K <= 16384.
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
+                                                             float* __restrict__ scale, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  const int nch = K >> 3;
+  float amax = 0.f;
+  for (int ch = lane; ch < nch; ch += 64) {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  uint8_t* qr = q + (int64_t)row * ldq;
+  for (int ch = lane; ch < nch; ch += 64) {
+    float v[8];
+    unpack8(*reinterpret_cast<const u32x4_t*>(xr + ch * 8), v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = __builtin_amdgcn_fmed3f(v[e] * inv, 448.0f, -448.0f);
+    int w0 = 0, w1 = 0;
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], w0, false);
+    w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], w0, true);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], w1, false);
+    w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], w1, true);
+    *reinterpret_cast<u32x2_t*>(qr + ch * 8) = (u32x2_t){(uint32_t)w0, (uint32_t)w1};
+  }
+}
+
 // out (bf16) = sum of the split-K partial slabs (f32, [nslab][M][N]) [+ res (bf16)]
 __global__ __launch_bounds__(256) void finish_f32_kernel(const float* __restrict__ src, int nslab, const bf16_t* __restrict__ res,
                                                          int64_t ldr, bf16_t* __restrict__ out, int64_t ldo, int64_t M, int N) {
@@ -145,6 +180,11 @@ __global__ __launch_bounds__(256) void finish_f32_kernel(const float* __restrict
     for (int e = 0; e < 8; ++e) v[e] += r[e];
   }
   *reinterpret_cast<u32x4_t*>(out + m * ldo + c * 8) = pack8(v);
+}
+
+hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int K, hipStream_t stream) {
+  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
+  return hipGetLastError();
 }
 
 }  // namespace afx
@@ -189,6 +229,31 @@ int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* si
   hipLaunchKernelGGL(rope_half_kernel, dim3(tblocks((int64_t)S * H * (head_dim >> 4))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x,
                      ldx, cos_t, sin_t, S, H, head_dim);
   HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int32_t rows, int32_t K, void* stream) {
+  if (!x || !q || !scale || rows < 1 || K % 8 || ldx % 8 || ldq % 8) return fail(AFX_E_INVALID, "bad argument to afx_quant_rows_fp8");
+  HIP_TRY(launch_quant_rows_fp8((const uint16_t*)x, ldx, (uint8_t*)q, ldq, scale, rows, K, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_linear_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale, const void* bias,
+                   void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
+                   int32_t rows_per_batch, const void* res, int64_t ldr, void* stream) {
+  if (!Aq || !Wq || !C || !a_scale || !w_scale) return fail(AFX_E_INVALID, "null argument to afx_linear_fp8");
+  if (M < 0 || N < 0 || K <= 0 || K % 128 || N % 8 || lda % 16 || ldw % 16 || ldc % 8 || epi < 0 || epi > 2)
+    return fail(AFX_E_INVALID, "afx_linear_fp8: need K%%128==0, N%%8==0, lda/ldw%%16==0, ldc%%8==0");
+  if (epi == EPI_GATE_RES && (!res || ldr % 8 || (gate && rows_per_batch < 1))) return fail(AFX_E_INVALID, "gated residual epilogue needs res");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)Aq; p.lda = lda; p.W = (const uint16_t*)Wq; p.ldw = ldw; p.bias = (const uint16_t*)bias;
+  p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
+  p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
+  p.fp8 = 1; p.a_scale = a_scale; p.w_scale = w_scale;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;
 }
 

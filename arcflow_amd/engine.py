@@ -94,7 +94,7 @@ class MMDiTEngine:
     def bind_packed(self, packed: Dict[str, torch.Tensor]) -> None:
         for name, t in packed.items():
             assert t.is_contiguous() and t.device.type == 'cuda', name
-            dt = {torch.bfloat16: _lib.AFX_DT_BF16, torch.float32: _lib.AFX_DT_F32}[t.dtype]
+            dt = {torch.bfloat16: _lib.AFX_DT_BF16, torch.float32: _lib.AFX_DT_F32, torch.uint8: _lib.AFX_DT_FP8}[t.dtype]
             shape = (C.c_int64 * t.dim())(*t.shape)
             _lib.check(self.lib.afx_bind_weight(self._ctx, name.encode(), _ptr(t), dt, t.dim(), shape))
         self._weights.update(packed)         # keep the storage alive
@@ -194,6 +194,26 @@ class MMDiTEngine:
         return ArcFlowModelOutput(means, logw, logg)
 
     __call__ = forward
+
+    def enable_fp8(self, on: bool = True) -> None:
+        """fp8 linear mode (BASELINE.json configs[4] "fp8 MFMA fwd"): quantise every block linear's weight row-wise to OCP
+        e4m3 (kept next to the bf16 copy) and run those GEMMs on the 2x-rate fp8 MFMA with per-token activation scales.
+        Embedders, modulation, head and attention stay bf16.  A reduced-precision OPTION: never the default, never the bench."""
+        from . import ops
+        if on:
+            names = []
+            for i in range(self.num_double):
+                names += [f'd{i}.{s}_{n}' for s in ('img', 'txt') for n in ('qkv', 'out', 'mlp1', 'mlp2')]
+            names += [f's{i}.{n}' for i in range(self.num_single) for n in ('fused', 'out')]
+            extra = {}
+            for n in names:
+                if n + '.weight_q' not in self._weights:
+                    q, sc = ops.quant_rows_fp8(self._weights[n + '.weight'])
+                    extra[n + '.weight_q'], extra[n + '.wscale'] = q, sc
+            if extra:
+                self.bind_packed(extra)
+        _lib.check(self.lib.afx_set_fp8_linear(self._ctx, int(on)))
+        self._ws, self._ws_key = None, (0, 0, 0)          # the workspace grows by the quantised-operand buffer
 
     def set_temb_override(self, temb_t: Optional[torch.Tensor]) -> None:
         """[B, D] fp32 replacing timestep_embedder(t) in the next forwards (None clears); the caller keeps it alive."""

@@ -264,6 +264,36 @@ def linear_f32out(a, w, out=None, accumulate: bool = False):
     return out
 
 
+def quant_rows_fp8(x: torch.Tensor):
+    """bf16 [M,K] -> (q uint8 [M,K] OCP e4m3, scale fp32 [M]) with q = round(x / scale[r]), scale = absmax(row) / 448."""
+    lib = _lib.load()
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    scale = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.check(lib.afx_quant_rows_fp8(_p(x), x.stride(0), _p(q), K, _p(scale), M, K, _s()))
+    return q, scale
+
+
+def linear_fp8(aq, a_scale, wq, w_scale, bias=None, epilogue: str = 'none', gelu_col0: int = 0, gate=None, residual=None,
+               rows_per_batch: int = 0, out=None):
+    """bf16 out = epi(a_scale[m] w_scale[n] (aq @ wq.T) + bias) on the 2x-rate fp8 MFMA; aq [M,K], wq [N,K] uint8 (e4m3)."""
+    lib = _lib.load()
+    M, K = aq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=aq.device)
+    epi = {'none': 0, 'gelu': 1, 'gate_res': 2}[epilogue]
+    if gate is not None:
+        gate = _cuda(gate, torch.float32)
+        if gate.dim() == 1:
+            gate = gate[None]
+    rpb = rows_per_batch if rows_per_batch > 0 else max(M, 1)
+    _lib.check(lib.afx_linear_fp8(_p(aq), aq.stride(0), _p(a_scale), _p(wq), wq.stride(0), _p(w_scale), _p(bias), _p(out), out.stride(0),
+                                  M, N, K, epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb, _p(residual),
+                                  0 if residual is None else residual.stride(0), _s()))
+    return out
+
+
 def linear_splitk(a, w, bias=None, residual=None, out=None, split_k: int = 0):
     """bf16 out = a @ w.T (+ bias) (+ residual) for few-row operands: split-K GEMM into per-chunk fp32 partial slabs, then one
     summing / converting pass.  Fills the chip when M x N alone gives only a handful of 256x256 tiles."""

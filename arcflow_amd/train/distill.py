@@ -59,6 +59,7 @@ class DistillConfig:
     ema_start_iter: int = 100
     lora_rank: int = 0                    # 0: train heads + norm_out only; 256 in the reference configs
     lora_dropout: float = 0.0             # peft lora_dropout on the adapters' input (0.05 in the reference configs)
+    teacher_fp8: bool = False             # BASELINE.json configs[4]: frozen teacher forwards on the fp8 MFMA (student + grads stay bf16)
 
 
 def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
@@ -94,6 +95,8 @@ class ArcFlowDistiller:
         t_packed = dict(packed)
         t_packed['head.weight'], t_packed['head.bias'] = th_w, th_b
         self.teacher.bind_packed(t_packed)
+        if cfg.teacher_fp8:
+            self.teacher.enable_fp8()
         D = self.student.dim
         self.D, self.K, self.C, self.L = D, K, C, L
         self.head_n = packed['head.weight'].shape[0]

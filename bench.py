@@ -123,6 +123,7 @@ def main():
     ap.add_argument('--model', default='flux', choices=['flux', 'qwen'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--fp8', action='store_true', help='OPTIONAL reduced-precision mode: block linears on the fp8 MFMA (not the headline: the line says dtype fp8)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -143,6 +144,8 @@ def main():
     from arcflow_amd.schedule import FlowMatchEulerDiscreteScheduler, retrieve_raw_timesteps
 
     eng, (x0, t, ctx, pooled, guidance, hp, wp) = build_flux_engine(args.model, dev, seed=rank)
+    if args.fp8:
+        eng.enable_fp8()
     raw, counts, _ = retrieve_raw_timesteps(2, 128, 1.0)
     sch = FlowMatchEulerDiscreteScheduler(shift=3.2)
     ts = sch.set_timesteps(sigmas=raw)
@@ -190,7 +193,7 @@ def main():
                       f'architecture, denoiser + ArcFlow integrator)',
             'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16', 'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt '
+            'dtype': 'fp8 e4m3 block linears (row-wise scales) + bf16 attention / embedders / head: REDUCED PRECISION, not the headline' if args.fp8 else 'bf16', 'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt '
                                      'embeddings, seeded noise latents)',
             'config': {'workload': 'ArcFlow-FLUX-12B 2-NFE inference, 1024x1024, bs=1 per GPU' if args.model == 'flux'
                        else 'ArcFlow-Qwen-Image-20B 2-NFE inference, 1024x1024, bs=1 per GPU, T=128',
@@ -201,7 +204,7 @@ def main():
         if prof and gemm_n:
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
-                'bound': 'mfma', 'kernel': 'afx::gemm_bf16_kernel_v2', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
+                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else 'afx::gemm_kernel_v2<false>', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
                 'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': _traffic(args.model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,

@@ -37,6 +37,7 @@ extern "C" {
 
 #define AFX_DT_BF16 1
 #define AFX_DT_F32 2
+#define AFX_DT_FP8 3   /* OCP e4m3 bytes (quantised weights of the fp8 linear mode) */
 
 typedef struct afx_ctx afx_ctx;
 
@@ -206,6 +207,11 @@ int afx_mmdit_forward_stage(afx_ctx* ctx, const void* x, const void* ctx_emb, co
                             const float* rope_cos, const float* rope_sin, int32_t B, int32_t N, int32_t T, void* means, void* logw,
                             void* logg, int32_t stage, void* stream);
 int afx_mmdit_import_tokens(afx_ctx* ctx, const void* src, int32_t batch, int32_t n_img, int32_t n_txt, void* stream);
+/* fp8 linear mode (BASELINE.json configs[4] "fp8 MFMA fwd"): every block linear (qkv / out / mlp of the double blocks, fused
+ * projection and proj_out of the single blocks) runs on the fp8 MFMA with row-wise scales: activations are quantised per
+ * token right before the GEMM, weights come pre-quantised as "<linear>.weight_q" (AFX_DT_FP8 [out, in]) + "<linear>.wscale"
+ * (f32 [out]) next to the bf16 ones.  Embedders, modulation, head and attention stay bf16.  Set before afx_workspace_bytes. */
+int afx_set_fp8_linear(afx_ctx* ctx, int32_t on);
 /* Timestep-embedding override: when set (device pointer to [B, D] f32, NULL to clear) the next forwards use it in place of
  * timestep_embedder(sincos(1000 t)); the guidance / pooled-text embeddings are still added.  The training student computes it
  * host-side with the LoRA pair on the two tiny linears (and their input dropout). */
@@ -285,6 +291,13 @@ int afx_act_mul_bf16(const void* x, int64_t ldx, void* out, int64_t ldo, int64_t
 /* rotate-half RoPE in place on H heads side by side in a row; cos/sin [S, head_dim / 2] f32 */
 int afx_rope_half_bf16(void* x, int64_t ldx, const float* cos_t, const float* sin_t, int32_t S, int32_t H, int32_t head_dim,
                        void* stream);
+/* fp8 (OCP e4m3) linear on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE.json configs[4]): row-wise
+ * quantisation q = round(x / scale[r]), scale[r] = absmax(row) / 448, for activations (per token) and weights (per output
+ * channel); C = epi(a_scale[m] w_scale[n] (Aq . Wq^T) + bias), bf16 out, same epilogues as afx_linear_bf16.  K % 128 == 0. */
+int afx_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* scale, int32_t rows, int32_t K, void* stream);
+int afx_linear_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale, const void* bias,
+                   void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
+                   int32_t rows_per_batch, const void* res, int64_t ldr, void* stream);
 /* Split-K GEMM for few-row operands (M <= 1-2 tiles: the prompt encoders): the K range is cut into chunks, chunk c stores
  * its partial A . W^T (+ bias on chunk 0) into the f32 slab partials[c][M][N]; afx_finish_f32_bf16 sums the slabs into bf16
  * (+ residual).  afx_linear_splitk_chunks = number of slabs for (M, N, K, split_k); split_k 0: chosen to fill the chip. */

@@ -81,3 +81,38 @@ def test_engine_errors_are_loud():
     with pytest.raises(_lib.ArcflowHipError):      # nothing bound yet
         eng(torch.zeros(1, 4, 64).cuda(), torch.ones(1).cuda(), torch.zeros(1, 3, 128).cuda(),
             torch.zeros(1, 64).cuda(), torch.ones(1).cuda(), 2, 2)
+
+
+@pytest.mark.parametrize('family', ['flux', 'qwen'])
+def test_fp8_linear_mode_tracks_bf16(family):
+    """BASELINE.json configs[4] "fp8 MFMA fwd": the same engine with every block linear on the fp8 MFMA (row-wise e4m3
+    scales) stays within fp8 quantisation error of the bf16 forward; the teacher head likewise."""
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    g = torch.Generator().manual_seed(21)
+    hp = wp = 8
+    T = 24
+    if family == 'flux':
+        cfg = D.FluxCfg(num_layers=2, num_single_layers=2, heads=2, joint_dim=128, pooled_dim=64)
+        w = D.make_flux_weights(cfg, seed=5)
+        kw = dict(num_double=2, num_single=2, heads=2, joint_dim=128, pooled_dim=64)
+        pooled, gd = (torch.randn(1, 64, generator=g) * 0.5).bfloat16().cuda(), torch.full((1,), 3.5).cuda()
+    else:
+        cfg = D.QwenCfg(num_layers=3, heads=2, joint_dim=192)
+        w = D.make_qwen_weights(cfg, seed=5)
+        kw = dict(num_double=3, heads=2, joint_dim=192)
+        pooled = gd = None
+    x = torch.randn(1, hp * wp, 64, generator=g).bfloat16().cuda()
+    ctx = (torch.randn(1, T, kw['joint_dim'], generator=g) * 0.5).bfloat16().cuda()
+    t = torch.tensor([0.6]).cuda()
+    outs = []
+    for fp8 in (False, True):
+        eng = MMDiTEngine(family, kw['num_double'], kw.get('num_single', 0), heads=2, joint_dim=kw['joint_dim'], pooled_dim=kw.get('pooled_dim', 768))
+        eng.load_state_dict(w)
+        if fp8:
+            eng.enable_fp8()
+        outs.append(eng(x, t, ctx, pooled, gd, hp, wp))
+    for k in ('means', 'logweights', 'loggammas'):
+        a, b = outs[0][k].float(), outs[1][k].float()
+        rel = ((a - b).norm() / a.norm()).item()
+        assert 0 < rel < 8e-2, (k, rel)          # different (fp8) but close

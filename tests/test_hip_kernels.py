@@ -256,3 +256,31 @@ def test_linear_splitk_matches_plain_gemm(M, N, K, split):
     got = ops.linear_splitk(a, w, b, r, split_k=split)
     ref = a.float() @ w.float().t() + b.float() + r.float()
     assert ((got.float() - ref).norm() / ref.norm()).item() < 4e-3
+
+
+@pytest.mark.gpu
+def test_fp8_quant_and_linear():
+    """Row-wise e4m3 quantisation (vs torch.float8_e4m3fn) and the fp8 MFMA linear with every epilogue."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 300, 520, 1024
+    a = (torch.randn(M, K, generator=g) * 2.0).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    aq, asc = ops.quant_rows_fp8(a)
+    wq, wsc = ops.quant_rows_fp8(w)
+    # quantiser: scale = absmax / 448, codes = RNE cast of x / scale (saturating) -- the same as torch's e4m3fn cast
+    assert torch.allclose(asc, a.float().abs().amax(1) / 448.0, rtol=1e-6)
+    ref_codes = (a.float() / asc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (aq != ref_codes).float().mean().item() < 1e-3          # ties on the bf16 -> fp32 product may differ in the last bit
+    ad = aq.view(torch.float8_e4m3fn).float() * asc[:, None]
+    wd = wq.view(torch.float8_e4m3fn).float() * wsc[:, None]
+    exact = ad @ wd.t()                                             # what the fp8 GEMM must reproduce exactly (fp32 accumulate)
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    gate = torch.randn(N, generator=g).cuda()
+    rel = lambda x, y: ((x.float() - y).norm() / y.norm()).item()   # noqa: E731
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc, b), exact + b.float()) < 4e-3
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc, b, epilogue='gelu'), torch.nn.functional.gelu(exact + b.float(), approximate='tanh')) < 5e-3
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc, b, epilogue='gate_res', gate=gate, residual=r), r.float() + gate * (exact + b.float())) < 4e-3
+    # and the quantisation error itself against the bf16 product stays at the e4m3 level
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc), a.float() @ w.float().t()) < 6e-2

@@ -39,6 +39,22 @@ def gemm():
         print(f'M={M:5d} N={N:5d} K={K:5d}  {dt*1e6:9.1f} us  {2*M*N*K/dt/1e12:7.1f} TF   (torch/hipBLASLt {2*M*N*K/ref/1e12:7.1f} TF)')
 
 
+def gemm8():
+    print('--- fp8 (e4m3, row-wise scales) linear vs the bf16 kernel')
+    for M, N, K in [(4608, 9216, 3072), (4608, 21504, 3072), (4608, 3072, 15360), (4608, 12288, 3072), (8192, 8192, 8192)]:
+        a = torch.randn(M, K, device='cuda').bfloat16()
+        w = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()
+        out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        aq, asc = ops.quant_rows_fp8(a)
+        wq, wsc = ops.quant_rows_fp8(w)
+        d8 = timeit(lambda: ops.linear_fp8(aq, asc, wq, wsc, out=out))
+        dq = timeit(lambda: ops.quant_rows_fp8(a))
+        d16 = timeit(lambda: ops.linear(a, w, out=out))
+        ref = a.float() @ w.float().t()
+        err = ((ops.linear_fp8(aq, asc, wq, wsc).float() - ref).norm() / ref.norm()).item()
+        print(f'M={M:5d} N={N:5d} K={K:5d}  fp8 {d8*1e6:8.1f} us {2*M*N*K/d8/1e12:7.1f} TF | quant(A) {dq*1e6:6.1f} us | bf16 {d16*1e6:8.1f} us {2*M*N*K/d16/1e12:7.1f} TF | rel err {err:.2e}')
+
+
 def attn():
     print('--- joint attention, d=128')
     for B, S, H in [(1, 4608, 24), (1, 4224, 24), (1, 1024, 24)]:

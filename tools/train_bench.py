@@ -24,6 +24,7 @@ def main():
     ap.add_argument('--model', default='flux')
     ap.add_argument('--lora-rank', type=int, default=256)
     ap.add_argument('--lora-dropout', type=float, default=0.05, help='peft lora_dropout of the reference configs')
+    ap.add_argument('--teacher-fp8', action='store_true', help='BASELINE configs[4]: teacher forwards on the fp8 MFMA')
     args = ap.parse_args()
     rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -46,8 +47,8 @@ def main():
     packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
     packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
     # configs/qwen/arcqwen_2nfe_k16.py: true-CFG teacher (scale 4.0, negative prompt), decay 1000, batch 2 per GPU
-    dc = DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout) if flux else \
-        DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout, teacher_guidance_scale=4.0, num_decay_iters=1000)
+    dc = DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout, teacher_fp8=args.teacher_fp8) if flux else \
+        DistillConfig(lora_rank=args.lora_rank, lora_dropout=args.lora_dropout, teacher_guidance_scale=4.0, num_decay_iters=1000, teacher_fp8=args.teacher_fp8)
     eng = dict(num_double=nd, num_single=ns) if flux else dict(num_double=nd, joint_dim=joint)
     dist_ = ArcFlowDistiller(args.model, eng, None, dc, device=dev, packed=packed)
     B = args.batch
