@@ -72,14 +72,19 @@ def qwen_sd(L=28, D=3584, F=18944, H=28, Hkv=4, V=152064):
     return sd
 
 
-t5 = T5Encoder(t5_sd())
-ids = torch.randint(0, 32000, (1, 512))
-print(f'T5 v1.1 XXL encoder, 512 tokens:        {timeit(lambda: t5(ids)):7.2f} ms')
-del t5
-clip = CLIPTextEncoder(clip_sd(), eos_token_id=2)
-ids = torch.randint(0, 49000, (1, 77))
-print(f'CLIP ViT-L/14 text model, 77 tokens:    {timeit(lambda: clip(ids)):7.2f} ms')
-del clip
-qw = Qwen25TextEncoder(qwen_sd())
-ids = torch.randint(0, 150000, (1, 162))
-print(f'Qwen2.5-VL-7B language model, 162 tok:  {timeit(lambda: qw(ids)):7.2f} ms')
+def main():
+    t5 = T5Encoder(t5_sd())
+    ids = torch.randint(0, 32000, (1, 512))
+    print(f'T5 v1.1 XXL encoder, 512 tokens:        {timeit(lambda: t5(ids)):7.2f} ms')
+    del t5
+    clip = CLIPTextEncoder(clip_sd(), eos_token_id=2)
+    ids = torch.randint(0, 49000, (1, 77))
+    print(f'CLIP ViT-L/14 text model, 77 tokens:    {timeit(lambda: clip(ids)):7.2f} ms')
+    del clip
+    qw = Qwen25TextEncoder(qwen_sd())
+    ids = torch.randint(0, 150000, (1, 162))
+    print(f'Qwen2.5-VL-7B language model, 162 tok:  {timeit(lambda: qw(ids)):7.2f} ms')
+
+
+if __name__ == '__main__':
+    main()
