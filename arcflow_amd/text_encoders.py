@@ -40,6 +40,7 @@ class _Base:
         self.dev = torch.device(device)
         self.w: Dict[str, torch.Tensor] = {}
         self.use_graphs = True
+        self.max_graphs = 8
         self._graphs: Dict[int, tuple] = {}
 
     def _run(self, ids: torch.Tensor) -> torch.Tensor:
@@ -58,7 +59,11 @@ class _Base:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 static_out = self._forward(static_ids)
+            while len(self._graphs) >= self.max_graphs:      # prompt lengths vary: keep the most recent few (each graph owns
+                self._graphs.pop(next(iter(self._graphs)))   # its activation pool)
             self._graphs[S] = (g, static_ids, static_out)
+        else:
+            self._graphs[S] = self._graphs.pop(S)            # most recently used last
         g, static_ids, static_out = self._graphs[S]
         static_ids.copy_(ids)
         g.replay()
