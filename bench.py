@@ -204,8 +204,8 @@ def main():
         if prof and gemm_n:
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
-                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else 'afx::gemm_kernel_v2<false>', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF,
-                'unit': 'TFLOP/s', 'frac': ach / MFMA_BF16_PEAK_TF, 'traffic': _traffic(args.model),
+                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else 'afx::gemm_kernel_v2<false>', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1),
+                'unit': 'TFLOP/s', 'frac': ach / (MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1)), 'traffic': None if args.fp8 else _traffic(args.model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,
                 'share_of_step_time': gemm_ms * 1e-3 / dt,
