@@ -19,6 +19,8 @@
 // The kernel is a template <head dim, EXT>.  <128, false> is the MMDiT product path above.  EXT = true adds what the
 // text encoders need (afx_text.hip): a runtime softmax scale, causal masking with tile skipping, an additive
 // relative-position bias table (T5), grouped KV heads (Qwen2.5), and head dim 64 (T5, CLIP).
+#include <hip/hip_ext.h>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -313,8 +315,12 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
   const int nq = (S + QB - 1) / QB;
   const int heads_per_xcd = (H + 7) / 8;
   dim3 grid(8 * heads_per_xcd * nq * B);
-  hipLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad,
-                     nq, B, lse, AttnExt{});
+  if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, launch_timer().start, launch_timer().stop,
+                          0, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B, lse, AttnExt{});
+  else
+    hipLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad,
+                       nq, B, lse, AttnExt{});
   return hipGetLastError();
 }
 

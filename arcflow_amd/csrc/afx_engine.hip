@@ -151,7 +151,8 @@ Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
   return w;
 }
 
-// RAII-free scoped timer: records an event pair around one launch when profiling is enabled.
+// Scoped timer of ONE launch when profiling is enabled: hands an event pair to the launcher, which attaches it to the kernel
+// dispatch itself (hipExtLaunchKernelGGL: kernel begin / end timestamps, no extra queue packets).
 struct ProfScope {
   afx_ctx* c; hipStream_t st; afx_ctx::ProfRec* r = nullptr;
   ProfScope(afx_ctx* c_, hipStream_t st_, int klass, double flops) : c(c_), st(st_) {
@@ -163,9 +164,10 @@ struct ProfScope {
     }
     r = &c->prof_pool[c->prof_used++];
     r->klass = klass; r->flops = flops;
-    (void)hipEventRecord(r->a, st);
+    launch_timer().start = r->a;
+    launch_timer().stop = r->b;
   }
-  ~ProfScope() { if (r) (void)hipEventRecord(r->b, st); }
+  ~ProfScope() { launch_timer() = LaunchTimer{}; }
 };
 
 double gemm_flops(const GemmBatch& gb) {

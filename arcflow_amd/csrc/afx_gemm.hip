@@ -24,6 +24,8 @@
 //     grid is remapped so every XCD owns a contiguous run of tiles (private-L2 reuse of A/W panels).
 #include <cstdlib>
 
+#include <hip/hip_ext.h>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -564,6 +566,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
 #endif
 }
 
+LaunchTimer& launch_timer() {
+  static thread_local LaunchTimer t;
+  return t;
+}
+
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   int total = 0;
   for (int i = 0; i < batch.nprob; ++i) {
@@ -601,10 +608,16 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (batch.p[i].out_f32 == 3) use = 2;            // ... and so do split-K and the atomic epilogue
   bool fp8 = false;
   for (int i = 0; i < batch.nprob; ++i) fp8 = fp8 || batch.p[i].fp8 != 0;     // a launch is all-bf16 or all-fp8
-  if (fp8)
+  if (fp8 && launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL(gemm_kernel_v2<true>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, launch_timer().start,
+                          launch_timer().stop, 0, batch);
+  else if (fp8)
     hipLaunchKernelGGL(gemm_kernel_v2<true>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   else if (use == 1)
     hipLaunchKernelGGL(gemm_bf16_kernel, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
+  else if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL(gemm_kernel_v2<false>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, launch_timer().start,
+                          launch_timer().stop, 0, batch);
   else
     hipLaunchKernelGGL(gemm_kernel_v2<false>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, batch);
   return hipGetLastError();

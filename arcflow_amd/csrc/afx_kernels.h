@@ -39,6 +39,12 @@ struct GemmBatch {
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
 
+// Optional per-launch timing without extra queue packets: when both are non-null, the NEXT launch_gemm / launch_attention issues
+// its kernel with hipExtLaunchKernelGGL(start, stop), which stamps the kernel's own begin / end on the events (the engine's
+// ProfScope sets and clears them; a plain hipEventRecord pair costs a barrier packet each: ~2 % of the forward).
+struct LaunchTimer { hipEvent_t start = nullptr, stop = nullptr; };
+LaunchTimer& launch_timer();
+
 // ---- attention ------------------------------------------------------------------------------
 // vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)
 hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
