@@ -91,9 +91,16 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
 // ------------------------------------------------------------------------------------------------
 // In-place per-head RMSNorm(128, weight) + interleaved-pair RoPE.  16 lanes x 8 elements = one
 // (token, head); the 4 rotation pairs of a lane stay inside its own 16-byte chunk.
+// blockIdx.y selects one of up to two tensors handled by the same launch (k and q of a block: same rows, different column
+// range and norm weights).
+struct QkRopeArgs { bf16_t* x[2]; const float* w_txt[2]; const float* w_img[2]; };
+
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(
-    bf16_t* __restrict__ x, int64_t ldx, const float* __restrict__ w_txt, const float* __restrict__ w_img,
-    const float* __restrict__ cos_t, const float* __restrict__ sin_t, int S, int n_txt, int H, int64_t total) {
+    const QkRopeArgs a, int64_t ldx, const float* __restrict__ cos_t, const float* __restrict__ sin_t, int S, int n_txt, int H,
+    int64_t total) {
+  bf16_t* __restrict__ x = a.x[blockIdx.y];
+  const float* __restrict__ w_txt = a.w_txt[blockIdx.y];
+  const float* __restrict__ w_img = a.w_img[blockIdx.y];
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;     // (row, head, chunk)
   if (g >= total) return;                                         // total % 16 == 0: whole groups exit together
   const int c = (int)(g & 15);
@@ -132,8 +139,24 @@ hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, con
                                hipStream_t stream) {
   const int64_t total = (int64_t)B * S * H * 16;
   if (total == 0) return hipSuccess;
-  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, ldx,
-                     w_txt, w_img, cos_t, sin_t, S, n_txt, H, total);
+  QkRopeArgs a{};
+  a.x[0] = x; a.w_txt[0] = w_txt; a.w_img[0] = w_img;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 255) / 256), 1), dim3(256), 0, stream, a, ldx, cos_t, sin_t, S,
+                     n_txt, H, total);
+  return hipGetLastError();
+}
+
+// k and q of one block in a single launch
+hipError_t launch_qk_norm_rope2(uint16_t* xk, uint16_t* xq, int64_t ldx, const float* wk_txt, const float* wk_img, const float* wq_txt,
+                                const float* wq_img, const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
+                                hipStream_t stream) {
+  const int64_t total = (int64_t)B * S * H * 16;
+  if (total == 0) return hipSuccess;
+  QkRopeArgs a{};
+  a.x[0] = xk; a.w_txt[0] = wk_txt; a.w_img[0] = wk_img;
+  a.x[1] = xq; a.w_txt[1] = wq_txt; a.w_img[1] = wq_img;
+  hipLaunchKernelGGL(qk_norm_rope_kernel, dim3((unsigned)((total + 255) / 256), 2), dim3(256), 0, stream, a, ldx, cos_t, sin_t, S,
+                     n_txt, H, total);
   return hipGetLastError();
 }
 

@@ -412,8 +412,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     if ((rc = stream_norm(i, 0, 1))) return rc;
     if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "qkv", QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
-    HIP_TRY(launch_qk_norm_rope(QKV, 3 * D, qkn + 3 * 128, qkn + 1 * 128, rope_cos, rope_sin, B, S, T, H, st));            // k
-    HIP_TRY(launch_qk_norm_rope(QKV + 2 * D, 3 * D, qkn + 2 * 128, qkn + 0 * 128, rope_cos, rope_sin, B, S, T, H, st));    // q
+    HIP_TRY(launch_qk_norm_rope2(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn + 0 * 128, rope_cos,
+                                 rope_sin, B, S, T, H, st));                                                                // k and q
     HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
     if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, p, "out", ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
@@ -440,8 +440,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)WQ(c, p + "fused.weight_q"); f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = W32(c, p + "fused.wscale");
     }
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
-    HIP_TRY(launch_qk_norm_rope(ws.F, 7 * D, qkn + 128, qkn + 128, rope_cos, rope_sin, B, S, T, H, st));                 // k
-    HIP_TRY(launch_qk_norm_rope(ws.F + 2 * D, 7 * D, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));                     // q
+    HIP_TRY(launch_qk_norm_rope2(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));   // k and q
     HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st)); }
     GemmBatch go{};

@@ -74,6 +74,9 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
 hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, const float* w_img,
                                const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
                                hipStream_t stream);
+hipError_t launch_qk_norm_rope2(uint16_t* xk, uint16_t* xq, int64_t ldx, const float* wk_txt, const float* wk_img, const float* wq_txt,
+                                const float* wq_img, const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
+                                hipStream_t stream);
 hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
                        int K, int act, int accumulate, hipStream_t stream, int64_t ldy = 0);
 hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream);
