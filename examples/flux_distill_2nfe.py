@@ -1,6 +1,6 @@
 # Minimal training config in the reference's config-file format (SURVEY.md appendix C lists the hyper-parameters of
 # configs/flux/arcflux_2nfe_k16.py + _ddp_train.py); tools/train.py also accepts the reference's own files unchanged.
-name = 'arcflux_2nfe_k16'
+name = 'flux_distill_2nfe'
 
 model = dict(
     diffusion=dict(
