@@ -144,27 +144,41 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   // K / V^T tiles go HBM -> LDS by LDS-DMA (16 B per lane, lane-linear destination), double
   // buffered; the XOR swizzle is applied to the per-lane SOURCE chunk and undone by the readers.
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // Per-lane byte offsets of the DT pieces of a K tile and a V^T tile relative to UNIFORM per-tile base pointers (SGPR base +
+  // 32-bit VGPR offset: one v_add per DMA instead of 64-bit address arithmetic -- that arithmetic was a quarter of the loop's
+  // VALU work).  K rows are KROW bytes: 256-byte rows swizzle chunk ^ (row & 15), 128-byte rows chunk ^ ((row >> 1) & 7).
+  constexpr int KCPR = HD / 8;                       // 16-byte chunks per K row
+  const int r0 = tid / KCPR, cp = tid % KCPR;        // K: row r0 + (256 / KCPR) i, physical chunk cp
+  const int kswz = (HD == 128 ? (cp ^ (r0 & 15)) : (cp ^ ((r0 >> 1) & 7))) << 3;
+  const int d0 = tid >> 3, vp = tid & 7;             // V^T: row d0 + 32 i, physical chunk vp
+  const int vswz = (vp ^ ((d0 >> 1) & 7)) << 3;
+  uint32_t koff[DT], voff[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i) {
+    koff[i] = (uint32_t)(((int64_t)(r0 + (256 / KCPR) * i) * ldk + kswz) * 2);
+    voff[i] = (uint32_t)(((int64_t)(d0 + 32 * i) * S_pad + vswz) * 2);
+  }
+  const bool ragged = S_pad != S;
   auto stage_tile = [&](int t, int buf) {
     const int kv0 = t * KVB;
     char* kd = smem + buf * STAGE_BYTES;
     char* vd = kd + KVB * HD * 2;
-    // keep the per-lane source addresses a short recomputation (opaque seed) instead of 8 live 64-bit
-    // induction pointers: those 16 VGPRs are what pushed the loop into scratch spills.
-    int seed = tid;
-    asm volatile("" : "+v"(seed));
-    // K rows are KROW bytes: 256-byte rows swizzle chunk ^ (row & 15), 128-byte rows chunk ^ ((row >> 1) & 7)
-    constexpr int KCPR = HD / 8;                     // chunks per K row
-    const int r0 = seed / KCPR, cp = seed % KCPR;    // K: row r0 + (256 / KCPR) i, physical chunk cp
-    const int kswz = (HD == 128 ? (cp ^ (r0 & 15)) : (cp ^ ((r0 >> 1) & 7))) << 3;
-    const int d0 = seed >> 3, vp = seed & 7;         // V^T: row d0 + 32 i, physical chunk vp
-    const int vswz = (vp ^ ((d0 >> 1) & 7)) << 3;
+    const char* kt = reinterpret_cast<const char*>(kbase) + (int64_t)kv0 * ldk * 2;     // uniform
+    const char* vt_ = reinterpret_cast<const char*>(vbase) + (int64_t)kv0 * 2;
+    if (ragged && t == ntiles - 1) {                 // keys past the end: clamp the row (never read unmasked)
 #pragma unroll
-    for (int i = 0; i < DT; ++i) {                   // DT = KVB * KCPR / 256 = HD / 32 pieces of each tile per thread
-      const int kr = min(kv0 + r0 + (256 / KCPR) * i, S - 1);
-      const bf16_t* ksrc = kbase + (int64_t)kr * ldk + kswz;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
-      const bf16_t* vsrc = vbase + (int64_t)(d0 + 32 * i) * S_pad + kv0 + vswz;
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)vsrc, (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      for (int i = 0; i < DT; ++i) {
+        const int kr = min(kv0 + r0 + (256 / KCPR) * i, S - 1);
+        const bf16_t* ksrc = kbase + (int64_t)kr * ldk + kswz;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DT; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(kt + koff[i]), (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      }
     }
   };
 
@@ -220,7 +234,8 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     }
     __builtin_amdgcn_sched_barrier(0);
     // ---- D ---- mask keys past the end of the sequence (last tile only)
-    if (t == ntiles - 1 && S_pad != S) {
+    if (t == ntiles - 1 && ragged) {
+      asm volatile("" ::: "memory");       // keep this a wave-uniform BRANCH: as selects it costs 31 v_cndmask on every tile
       const int kv0 = t * KVB;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
