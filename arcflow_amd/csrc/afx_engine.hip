@@ -582,8 +582,11 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
 }
 
 int afx_mmdit_import_tokens(afx_ctx* c, const void* src, int32_t batch, int32_t n_img, int32_t n_txt, void* stream) {
-  if (!c || !src || !c->ws) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_import_tokens");
+  if (!c || !src || !c->ws || batch < 1 || n_img < 1 || n_txt < 0) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_import_tokens");
   Workspace ws = carve(c, c->ws, batch, n_img, n_txt);
+  if (ws.total > c->ws_bytes)
+    return fail(AFX_E_WORKSPACE, "afx_mmdit_import_tokens: shape (%d, %d, %d) needs %lld workspace bytes, have %lld", batch, n_img, n_txt,
+                (long long)ws.total, (long long)c->ws_bytes);
   HIP_TRY(hipMemcpyAsync(ws.X, src, (size_t)batch * (n_img + n_txt) * c->D * 2, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return AFX_OK;
 }
@@ -618,8 +621,12 @@ int afx_linear_bf16_splitk(const void* A, int64_t lda, const void* W, int64_t ld
 }
 
 int afx_mmdit_export(afx_ctx* c, const char* what, void* dst, int32_t batch, int32_t n_img, int32_t n_txt, void* stream) {
-  if (!c || !what || !dst || !c->ws) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_export");
+  if (!c || !what || !dst || !c->ws || batch < 1 || n_img < 1 || n_txt < 0) return fail(AFX_E_INVALID, "bad argument to afx_mmdit_export");
   Workspace ws = carve(c, c->ws, batch, n_img, n_txt);
+  // the layout is a function of the shape: a shape the bound workspace was not sized for would read past it / from another layout
+  if (ws.total > c->ws_bytes)
+    return fail(AFX_E_WORKSPACE, "afx_mmdit_export: shape (%d, %d, %d) needs %lld workspace bytes, have %lld", batch, n_img, n_txt,
+                (long long)ws.total, (long long)c->ws_bytes);
   const int64_t D = c->D;
   ModLayout ml{D, c->d.num_double, c->d.num_single};
   hipStream_t st = (hipStream_t)stream;

@@ -8,15 +8,17 @@ Per iteration and student step (nfe = 2):
         teacher forward at (x_a, t_a), predicted mean velocity of the FULL policy over [t_b - window, t_a],
         teacher Euler roll to t_b }, MSE x 30 x 0.5 x segment size, roll to the segment end
     backward of the policy math -> head logits -> {velocity heads, norm_out.linear}  (fp32 gradients)
-then: gradient all-reduce (RCCL, launched per student step so it overlaps the next one), global-norm clip (50 from
+then: gradient all-reduce (RCCL, one exchange per iteration, launched slice by slice while the last backward runs), global-norm clip (50 from
 iteration 100, non-finite -> skip), AdamW (loggamma rows lr x 0.1, linear warm-up), Karras EMA of the trainables.
 
 Every tensor op on [B,N,*] data is a HIP kernel from libarcflow_hip (arcflow_amd.ops); torch supplies device memory,
 the RNG draws and the tiny [B]-sized schedule arithmetic.
 
-Scope of THIS round: the trainable set is {proj_out_means, proj_out_logweights, proj_out_loggamma, norm_out} of the
-reference's ``freeze_exclude`` (configs/flux/arcflux_2nfe_k16.py:20-25); the LoRA adapters (the fifth entry) need the
-trunk backward and arrive with it -- see DESIGN.md section 6.
+Trainable set = the reference's ``freeze_exclude`` (configs/flux/arcflux_2nfe_k16.py:20-25): the three velocity heads,
+norm_out and (``lora_rank`` > 0) the rank-r LoRA adapters incl. the timestep-embedder pair, all in ONE flat fp32 buffer;
+both student steps accumulate into ONE gradient buffer whose slices are all-reduced once each (train/reducer.py).
+Batches above 4 samples per GPU run as micro-batches of <= 4 (the engine's grouped launches hold 4 samples; the
+reference micro-batches the same way, ``grad_accum_batch_size``, configs/flux/_ddp_train.py:14).
 """
 from __future__ import annotations
 
@@ -45,7 +47,8 @@ class DistillConfig:
     shift: float = 3.2
     eps: float = 1e-4
     loss_scale: float = 30.0
-    guidance: float = 3.5                 # distilled guidance fed to student and teacher (FLUX)
+    guidance: float = 3.5                 # distilled guidance fed to the student (FLUX; distilled_guidance_scale)
+    teacher_guidance: Optional[float] = None   # teacher_distilled_guidance_scale (arcflux_2nfe_k16.py:94); None = same as the student's
     teacher_guidance_scale: float = 1.0   # > 1: true CFG with negative prompt embeds (Qwen: 4.0)
     lr: float = 1e-4
     betas: tuple = (0.9, 0.95)
@@ -116,7 +119,8 @@ class ArcFlowDistiller:
         self.exp_avg = torch.zeros_like(self.params)
         self.exp_avg_sq = torch.zeros_like(self.params)
         self.ema = self.params.clone()
-        self.grads = [torch.zeros_like(self.params) for _ in range(cfg.nfe)]   # one buffer per student step
+        self.grad = torch.zeros_like(self.params)      # ONE buffer: both student steps accumulate into it
+        self.grads = [self.grad]                       # (kept for callers that index the summed gradient as grads[0])
         # bf16 working copies the engine reads
         self.w_head = packed['head.weight']
         self.b_head = packed['head.bias']
@@ -165,21 +169,27 @@ class ArcFlowDistiller:
 
     def dropout_seed(self, step_id: int) -> int:
         """Seed of the LoRA dropout masks of one student step: differs per iteration, step and rank (train.py --diff_seed)."""
-        return (self.iteration * 7919 + step_id * 104729 + self.reducer.rank * 15485863 + 12345) & 0x7fffffff
+        return (self.iteration * 7919 + step_id * 104729 + self.reducer.rank * 15485863 + getattr(self, '_chunk', 0) * 32452843 + 12345) & 0x7fffffff
 
     def _student(self, x, sigma, cond):
         return self.student(x.to(torch.bfloat16), sigma, cond['prompt_embeds'], cond.get('pooled'),
                             self._guid(x.shape[0]), cond['hp'], cond['wp'])
 
-    def _guid(self, B):
+    def _guid(self, B, teacher: bool = False):
         if self.family != 'flux' or not self.student.guidance_embeds:
             return None
-        return torch.full((B,), self.cfg.guidance, device=self.device)
+        g = self.cfg.guidance
+        if teacher and self.cfg.teacher_guidance is not None:
+            g = self.cfg.teacher_guidance
+        return torch.full((B,), g, device=self.device)
 
     def _teacher_u(self, x, sigma, cond):
         """Teacher velocity (GaussianFlow.forward_u, gaussian_flow.py:224-254): optional true CFG on a 2B batch."""
         xb = x.to(torch.bfloat16)
-        g = self._guid(x.shape[0])
+        g = self._guid(x.shape[0], teacher=True)
+        if self.cfg.teacher_guidance_scale != 1.0 and 'negative_prompt_embeds' not in cond:
+            raise ValueError('teacher_guidance_scale > 1 (true CFG) needs cond["negative_prompt_embeds"] '
+                             '(reference: negative_prompt_embeds_path, lakonlab/datasets/image_prompts.py:158-163)')
         pos = self.teacher(xb, sigma, cond['prompt_embeds'], cond.get('pooled'), g, cond['hp'], cond['wp']).float()
         if self.cfg.teacher_guidance_scale == 1.0:
             return pos
@@ -187,10 +197,17 @@ class ArcFlowDistiller:
         return ops.cfg_combine(pos, neg, self.cfg.teacher_guidance_scale)
 
     # ------------------------------------------------------------------ one student segment
-    def _segment(self, step_id: int, x_src, raw_src, cond, teacher_ratio: float, segment: float, rng, draws=None):
-        """piid_segment_momentum + the head backward of this student step.  Returns (x_dst, raw_dst)."""
+    def _segment(self, step_id: int, x_src, raw_src, cond, teacher_ratio: float, segment: float, rng, draws=None,
+                 batch_total: Optional[int] = None, final: bool = False):
+        """piid_segment_momentum + the head backward of this student step.  Returns (x_dst, raw_dst).
+        batch_total: samples of the whole per-GPU batch (the loss is a mean over it; x_src may be a micro-batch of it).
+        final: this is the last gradient-producing call of the iteration -> finished slices of the flat gradient buffer
+        are handed to the reducer as the last sample's backward leaves them."""
         c = self.cfg
         B, N, ch = x_src.shape
+        if B > 4:
+            raise ValueError('a micro-batch holds at most 4 samples (train_step splits larger batches)')
+        batch_total = B if batch_total is None else batch_total
         dev = self.device
         K, pp = self.K, self.L
         sigma_src = warp(raw_src, c.shift)
@@ -259,7 +276,7 @@ class ArcFlowDistiller:
         d_means = torch.zeros(B, N, K, ch, dtype=torch.float32, device=dev)
         d_logw = torch.zeros(B, N, K, pp, dtype=torch.float32, device=dev)
         d_logg = torch.zeros(B, N, K - 1, pp, dtype=torch.float32, device=dev)
-        coef = c.loss_scale / (n * B * N * ch) * segment          # mean over the 4B stacked states x segment weight
+        coef = c.loss_scale / (n * batch_total * N * ch) * segment          # mean over the 4B stacked states x segment weight
         x, raw, sigma = x_src, raw_src, sigma_src
         one = torch.ones(B, device=dev)
         for i in range(n):
@@ -288,7 +305,7 @@ class ArcFlowDistiller:
         x_dst = ops.arcflow_step_dropout(x, means, logw, logg, sigma_src, sigma, warp(raw_dst, c.shift), drop, c.eps)
 
         # ---- backward: head logits -> head weights / bias, norm_out modulation -> norm_out.linear ---------------
-        gbuf = self.grads[step_id]
+        gbuf = self.grad
         dy = ops.head_grad(d_means, d_logw, d_logg, logw, self.head_n)                 # [M, head_n] bf16
         M = B * N
         Mp = (M + 63) // 64 * 64
@@ -305,15 +322,35 @@ class ArcFlowDistiller:
         if self.trunk is not None:                          # LoRA adapters: per-sample recompute + backward of every block
             dmod_all = torch.zeros(B, self.student.n_mod, dtype=torch.float32, device=dev)
             for b in range(B):
+                done = self._launch_block_slice if (final and b == B - 1) else None
                 self.trunk.backward_sample(self._ckpt, b, mod_all, xf[b * N:(b + 1) * N], dxn[b * N:(b + 1) * N], T, N,
-                                           cond['hp'], cond['wp'], gbuf, dmod_out=dmod_all[b])
+                                           cond['hp'], cond['wp'], gbuf, dmod_out=dmod_all[b], on_block_done=done)
             # timestep-embedder LoRA pair: d silu(temb) = W_mod^T d mod (all blocks) + W_norm_out^T d mod_final, then SiLU'
             dsemb = torch.zeros(B, self.D, dtype=torch.float32, device=dev)
             ops.gemv_t(dmod_all, self.student._weights['mod.weight'], dsemb)
-            dsemb += dflat @ self._view(self.params, 2).view(2 * self.D, self.D)
+            ops.gemv_t(dflat, self.w_no, dsemb)                 # the bf16 working copy the forward multiplied with
             sg = torch.sigmoid(temb_sum)
             self.trunk.temb_backward(dsemb * (sg * (1 + temb_sum * (1 - sg))), gbuf)
         return x_dst, raw_dst
+
+    # ------------------------------------------------------------------ gradient exchange, slice by slice
+    def _launch_block_slice(self, block: int) -> None:
+        """Called by the trunk when ``block``'s backward of the iteration's LAST sample is done: its adapters' gradients are
+        final -> start their all-reduce now (it overlaps the remaining blocks' backward)."""
+        a, b = self.trunk.block_slice(block)
+        self.reducer.launch(self.grad[a:b])
+        self._launched.append((a, b))
+
+    def _launch_rest(self) -> None:
+        """Everything not exchanged yet (heads, norm_out, the timestep-embedder pair; the whole buffer without a trunk)."""
+        pos = 0
+        for a, b in sorted(self._launched):
+            if a > pos:
+                self.reducer.launch(self.grad[pos:a])
+            pos = max(pos, b)
+        if pos < self.grad.numel():
+            self.reducer.launch(self.grad[pos:])
+        self._launched = []
 
     # ------------------------------------------------------------------ one iteration
     def lr_at(self, it: int) -> float:
@@ -331,20 +368,29 @@ class ArcFlowDistiller:
         N = cond['hp'] * cond['wp']
         it = self.iteration
         teacher_ratio = 1 - min(it, c.num_decay_iters) / c.num_decay_iters if c.num_decay_iters > 0 else 0.0
-        for gbuf in self.grads:
-            gbuf.zero_()
+        self.grad.zero_()
         self._loss_acc.zero_()
-        x = x_init if x_init is not None else torch.randn(batch, N, self.C, device=self.device, generator=rng)
-        raw = torch.ones(batch, device=self.device)
+        self._launched = []
+        x_all = x_init if x_init is not None else torch.randn(batch, N, self.C, device=self.device, generator=rng)
         base = 1.0 / (c.nfe - 1 + max(c.timestep_ratio, c.eps))
-        for step_id in range(c.nfe):
-            seg = base * max(c.timestep_ratio, c.eps) if step_id == c.nfe - 1 else base
-            x, raw = self._segment(step_id, x, raw, cond, teacher_ratio, seg, rng, None if draws is None else draws[step_id])
-            self.reducer.launch(self.grads[step_id])          # overlaps the next student step
+        chunks = [(a, min(a + 4, batch)) for a in range(0, batch, 4)]      # micro-batches of <= 4 samples
+        outs = []
+        for ci, (a, b) in enumerate(chunks):
+            self._chunk = ci                                   # part of the LoRA-dropout seed: micro-batches draw different masks
+            x = x_all[a:b]
+            raw = torch.ones(b - a, device=self.device)
+            cc = cond if len(chunks) == 1 else {k: (v[a:b] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == batch else v)
+                                                for k, v in cond.items()}
+            for step_id in range(c.nfe):
+                seg = base * max(c.timestep_ratio, c.eps) if step_id == c.nfe - 1 else base
+                dr = None if draws is None else tuple(d[a:b] for d in draws[step_id])
+                x, raw = self._segment(step_id, x, raw, cc, teacher_ratio, seg, rng, dr, batch_total=batch,
+                                       final=(ci == len(chunks) - 1 and step_id == c.nfe - 1))
+            outs.append(x)
+        x = outs[0] if len(outs) == 1 else torch.cat(outs)
+        self._launch_rest()                                    # heads / norm_out / embedder pair (or everything)
         inv_world = self.reducer.finish()
-        g = self.grads[0]
-        for other in self.grads[1:]:
-            g.add_(other)                                      # flat buffer sum (plumbing-sized: 22 M floats)
+        g = self.grad
         self._norm_acc.zero_()
         ops.sumsq(g, self._norm_acc)
         grad_norm = float(self._norm_acc.sqrt()) * inv_world   # the step's one host sync
@@ -376,4 +422,5 @@ class ArcFlowDistiller:
             ops.ema_lerp(self.ema, self.params, min((1 - 1 / t) ** (c.ema_gamma + 1), 1.0))
         self.iteration += 1
         self.last_x = x
-        return dict(loss=loss, grad_norm=grad_norm, lr=lr, teacher_ratio=teacher_ratio, skipped=skipped)
+        return dict(loss=loss, grad_norm=grad_norm, lr=lr, teacher_ratio=teacher_ratio, skipped=skipped,
+                    allreduce_exposed_ms=self.reducer.exposed_ms())

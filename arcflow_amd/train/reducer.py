@@ -1,16 +1,19 @@
 """Data-parallel gradient exchange of the distillation step.
 
 The reference wraps only the trainable `diffusion` sub-module in torch DDP (lakonlab/parallel/ddp_wrapper.py:9-26)
-and lets its bucketed NCCL all-reduce overlap the single backward (lakonlab/models/base_diffusion.py:59-60).  Here the
-trainable set lives in flat fp32 buffers, so the exchange is one large all-reduce per student step issued
-asynchronously on the process group's stream (RCCL over xGMI on MI355X: few, large messages -- a 7-link
-point-to-point fabric is per-link bound) while the next student step computes; the buffers are
-averaged and summed when the optimizer needs them.  torch.distributed is plumbing here (backend "nccl" == RCCL on
-ROCm; "gloo" in the CPU tests).
+and lets its bucketed NCCL all-reduce overlap the single backward (lakonlab/models/base_diffusion.py:59-60): ONE
+exchange of the trainable set per iteration.  Here the trainable set lives in one flat fp32 buffer that both student
+steps accumulate into, and the exchange is the same volume as the reference's: every slice of the buffer is
+all-reduced exactly once per iteration, launched asynchronously the moment it is final -- block by block in reverse
+while the LAST sample of the LAST student step is still back-propagating -- so only the tail (block 0 + heads) is
+exposed.  Slices are whole blocks (tens of MB): few, large messages, which is what a 7-link point-to-point xGMI fabric
+wants (per-link bound), not DDP's 25 MB buckets.  torch.distributed is plumbing here (backend "nccl"
+== RCCL on ROCm; "gloo" in the CPU tests and in the 2-ranks-on-one-GPU equivalence test, where device buffers are staged
+through the host because RCCL refuses two ranks on one device).
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List, Optional, Tuple
 
 import torch
 
@@ -22,25 +25,60 @@ class GradReducer:
         self.group = process_group
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
         self.rank = self.dist.get_rank(process_group) if self.dist else 0
+        self.backend = self.dist.get_backend(process_group) if self.dist else None
         self._pending: List = []
+        self._staged: List[Tuple[torch.Tensor, torch.Tensor]] = []
+        self.bytes_launched = 0          # per iteration (reset by finish): the tests check "every byte exactly once"
+        self.last_exposed_ms = 0.0       # time the compute stream waited in the last finish() (device tensors, RCCL)
 
     def launch(self, flat_grad: torch.Tensor) -> None:
-        """Start the SUM all-reduce of one flat gradient buffer (returns immediately)."""
+        """Start the SUM all-reduce of one contiguous slice of the flat gradient buffer (returns immediately)."""
+        if flat_grad.numel() == 0:
+            return
+        self.bytes_launched += flat_grad.numel() * flat_grad.element_size()
         if self.dist is None or self.world == 1:
+            return
+        assert flat_grad.is_contiguous()
+        if flat_grad.is_cuda and self.backend == 'gloo':      # 2 ranks on one GPU (tests): stage through the host
+            host = flat_grad.detach().to('cpu', copy=True)
+            self._pending.append(self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._staged.append((flat_grad, host))
             return
         self._pending.append(self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self) -> float:
         """Wait for every outstanding exchange; returns the factor (1/world) that turns the sums into means
         (folded into the optimizer's grad_scale instead of a separate pass over the buffer)."""
+        ev = None
+        if self._pending and not self._staged and torch.cuda.is_available() and self.backend == 'nccl':
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         for h in self._pending:
-            h.wait()
+            h.wait()                      # RCCL: the current stream waits for the collective, the host does not
+        if ev is not None:
+            ev[1].record()
+            self._ev = ev
+        for dst, host in self._staged:
+            dst.copy_(host)
         self._pending.clear()
+        self._staged.clear()
+        self.bytes_launched = 0
         return 1.0 / self.world
+
+    def exposed_ms(self) -> float:
+        """Milliseconds the compute stream spent blocked on the collectives of the last finish() (syncs the events)."""
+        ev = getattr(self, '_ev', None)
+        if ev is None:
+            return 0.0
+        ev[1].synchronize()
+        self.last_exposed_ms = ev[0].elapsed_time(ev[1])
+        self._ev = None
+        return self.last_exposed_ms
 
     def all_reduce_max(self, value: float, device) -> float:
         if self.dist is None or self.world == 1:
             return value
-        t = torch.tensor([value], dtype=torch.float32, device=device)
+        dev = 'cpu' if self.backend == 'gloo' else device
+        t = torch.tensor([value], dtype=torch.float32, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX, group=self.group)
         return float(t)

@@ -11,9 +11,11 @@ Design for MI355X:
     dgrad GEMMs on pre-transposed weights, flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
   * LoRA gradients per adapted linear  y = x W'^T:   t = x A^T,  dT = dy B,  dB += dy^T t,  dA += dT^T x
     (rank-r skinny GEMMs on the MFMA kernel, fp32 accumulate-into output).
-Scope notes: LoRA dropout (0.05 in the reference config) is not applied (merged-weight forward); the
-timestep-embedder LoRA pair (2.4 M of ~650 M trainables) is not trained yet -- it needs the modulation gradients
-of every block.  Both are listed in DESIGN.md.
+  * LoRA input dropout (0.05 in the reference config): the merged-weight product gets the correction B A (x . delta),
+    delta = keep/(1-p) - 1, from a counter-hash mask regenerated wherever it is needed (forward, recompute, backward).
+  * The timestep-embedder LoRA pair is trained too: its gradient is the sum of EVERY block's AdaLN modulation gradients
+    (d_shift / d_scale / d_gate, accumulated per sample into a [n_mod] vector during the block backwards) pulled back
+    through the stacked modulation matrix; the two [B <= 4]-row linears run on the gemv kernels.
 """
 from __future__ import annotations
 
@@ -148,6 +150,15 @@ class LoraTrunk:
                            out=w[rows])                          # W' = W + B A  (fp32 accumulate, one rounding)
             self.wt[key] = ops.transpose(w)
 
+    def block_slice(self, block: int) -> Tuple[int, int]:
+        """[a, b) of the flat parameter / gradient buffer holding the adapters of transformer block ``block``
+        (0 .. nd-1 double, nd .. nd+ns-1 single); the layout is block-major, so the range is contiguous."""
+        pre = f'd{block}.' if block < self.nd else f's{block - self.nd}.'
+        sps = [sp for sp in self.specs if sp.packed_key.startswith(pre)]
+        if not sps:
+            return (0, 0)
+        return (min(sp.off_a for sp in sps), max(sp.off_b + sp.out_f * self.r for sp in sps))
+
     def merged_state(self) -> Dict[str, torch.Tensor]:
         return {sp.name: self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f] for sp in self.specs}
 
@@ -169,37 +180,48 @@ class LoraTrunk:
 
     def temb_forward(self, sigma: torch.Tensor) -> torch.Tensor:
         """timestep_embedder(sincos(1000 sigma)) [B, D] fp32 with the LoRA branches B A dropout(.) on both linears
-        (diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) -> Linear -> SiLU -> Linear).  These are
-        [B<=4, 256..D] products: done with torch on the device, the intermediates are kept for ``temb_backward``."""
+        (diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) -> Linear -> SiLU -> Linear).  The
+        [B<=4]-row products run on the weight-streaming gemv kernel; the intermediates are kept for ``temb_backward``."""
         sp1, sp2 = self._spec('temb.t.l1'), self._spec('temb.t.l2')
         t = sigma.to(self.dev, torch.float32).reshape(-1) * 1000.0
         freqs = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32, device=self.dev) / 128.0)
         ang = t[:, None] * freqs[None]
         s = torch.cat([ang.cos(), ang.sin()], dim=1)                                   # [B, 256], cos first
-        W1, W2 = self.base['temb.t.l1'].float(), self.base['temb.t.l2'].float()
-        b1, b2 = self.packed['temb.t.l1.bias'].float(), self.packed['temb.t.l2.bias'].float()
-        A1, B1, A2, B2 = (self.a16[sp1.name].float(), self.b16[sp1.name].float(), self.a16[sp2.name].float(), self.b16[sp2.name].float())
+        W1, W2 = self.base['temb.t.l1'], self.base['temb.t.l2']                      # frozen bf16 [out, in]
+        b1, b2 = self.packed['temb.t.l1.bias'], self.packed['temb.t.l2.bias']
         k1, k2 = self._keep_scale(sp1, s.shape[0], 256), self._keep_scale(sp2, s.shape[0], self.D)
-        sd = s if k1 is None else s * k1
-        u = s @ W1.t() + b1 + (sd @ A1.t()) @ B1.t()
+        sd = (s if k1 is None else s * k1).contiguous()
+        t1 = ops.gemv(sd, self.a16[sp1.name])                                          # [B, r]  = dropout(s) A1^T
+        u = ops.gemv(s.contiguous(), W1, b1)
+        ops.gemv(t1, self.b16[sp1.name], out=u, accumulate=True)                       # + (.) B1^T
         h = torch.nn.functional.silu(u)
-        hd = h if k2 is None else h * k2
-        y = h @ W2.t() + b2 + (hd @ A2.t()) @ B2.t()
-        self._temb_cache = (sd, u, hd, k2, W2, A1, B1, A2, B2)
+        hd = (h if k2 is None else h * k2).contiguous()
+        t2 = ops.gemv(hd, self.a16[sp2.name])
+        y = ops.gemv(h.contiguous(), W2, b2)
+        ops.gemv(t2, self.b16[sp2.name], out=y, accumulate=True)
+        self._temb_cache = (sd, u, hd, k2, t1, t2)
         return y.contiguous()
 
     def temb_backward(self, dtemb: torch.Tensor, grads: torch.Tensor) -> None:
-        """dtemb [B, D] = d loss / d timestep-embedding output; accumulates dA, dB of both linears into ``grads``."""
+        """dtemb [B, D] = d loss / d timestep-embedding output; accumulates dA, dB of both linears into ``grads``
+        (gemv / transposed gemv / rank-B outer-product kernels: no torch matmul on the path)."""
         sp1, sp2 = self._spec('temb.t.l1'), self._spec('temb.t.l2')
-        sd, u, hd, k2, W2, A1, B1, A2, B2 = self._temb_cache
-        dT2 = dtemb @ B2                                                               # [B, r]
-        self.B(sp2, grads).add_(dtemb.t() @ (hd @ A2.t()))
-        self.A(sp2, grads).add_(dT2.t() @ hd)
-        dh = dtemb @ W2 + (dT2 @ A2) * (1.0 if k2 is None else k2)
+        sd, u, hd, k2, t1, t2 = self._temb_cache
+        dtemb = dtemb.contiguous()
+        B = dtemb.shape[0]
+        dT2 = ops.gemv(dtemb, self.bt16[sp2.name])                                     # [B, r] = dtemb B2
+        ops.outer_accum(dtemb, t2, self.B(sp2, grads))                                 # dB2 += dtemb^T (hd A2^T)
+        ops.outer_accum(dT2, hd, self.A(sp2, grads))                                   # dA2 += dT2^T hd
+        dh = torch.zeros(B, self.D, dtype=torch.float32, device=self.dev)
+        ops.gemv_t(dtemb, self.base['temb.t.l2'], dh)                                  # dtemb W2
+        dl = torch.zeros(B, self.D, dtype=torch.float32, device=self.dev)
+        ops.gemv_t(dT2, self.a16[sp2.name], dl)                                        # (dT2 A2) . keep_scale
+        dh += dl if k2 is None else dl * k2
         sg = torch.sigmoid(u)
-        du = dh * (sg * (1 + u * (1 - sg)))
-        self.B(sp1, grads).add_(du.t() @ (sd @ A1.t()))
-        self.A(sp1, grads).add_((du @ B1).t() @ sd)
+        du = (dh * (sg * (1 + u * (1 - sg)))).contiguous()
+        ops.outer_accum(du, t1, self.B(sp1, grads))                                    # dB1 += du^T (sd A1^T)
+        dT1 = ops.gemv(du, self.bt16[sp1.name])                                        # [B, r] = du B1
+        ops.outer_accum(dT1, sd, self.A(sp1, grads))                                   # dA1 += dT1^T sd
 
     def _site_seed(self, sp: LoraSpec) -> int:
         return (self.seed * 0x9E3779B1 + (sp.off_a * 2654435761 % (1 << 32))) & 0xffffffff
@@ -395,10 +417,11 @@ class LoraTrunk:
     # ------------------------------------------------------------------ whole-trunk backward of one sample
     def backward_sample(self, ckpt: torch.Tensor, b: int, mod_all: torch.Tensor, x_final_img: torch.Tensor,
                         dxn_img: torch.Tensor, T: int, N: int, hp: int, wp: int, grads: torch.Tensor,
-                        dmod_out: Optional[torch.Tensor] = None) -> None:
+                        dmod_out: Optional[torch.Tensor] = None, on_block_done=None) -> None:
         """ckpt [nblocks, B*S, D] block inputs of the last student forward; mod_all [B, n_mod]; x_final_img [N, D] the
         image tokens entering norm_out; dxn_img [N, D] the gradient at the velocity head's input.  Accumulates the
-        LoRA gradients of sample b into ``grads``."""
+        LoRA gradients of sample b into ``grads``.  on_block_done(block): called after each block's backward (the distiller
+        starts the all-reduce of that block's gradient slice when this is the iteration's last sample)."""
         D, S = self.D, T + N
         mod = mod_all[b]
         self.row0 = b * S
@@ -410,6 +433,10 @@ class LoraTrunk:
         for i in reversed(range(self.ns)):
             X = ckpt[self.nd + i, b * S:(b + 1) * S]
             dX = self._single_block(i, X, mod, cos, sin, T, dX, grads)
+            if on_block_done is not None:
+                on_block_done(self.nd + i)
         for i in reversed(range(self.nd)):
             X = ckpt[i, b * S:(b + 1) * S]
             dX = self._double_block(i, X, mod, cos, sin, T, dX, grads)
+            if on_block_done is not None:
+                on_block_done(i)

@@ -8,7 +8,13 @@ lakonlab/pipelines/arcflux_pipeline.py:457-510.  Text encoders and the VAE are o
  and outside the timed region; prompt embeddings are synthetic, weights are random-init of
 the exact architecture (no network for checkpoints).
 
-    python bench.py --gpus N --steps K --warmup W        (torchrun launches N ranks for N > 1)
+    python bench.py --gpus N --steps K --warmup W [--model flux|qwen] [--train]
+
+N > 1: one replica per GPU.  Launched under torchrun (RANK / WORLD_SIZE in the environment) the script is one rank; launched
+bare (`python bench.py --gpus N`) it re-executes itself under `python -m torch.distributed.run --nproc-per-node N` and
+fails loudly when the box has fewer than N GPUs -- the line never reports n_gpus 1 for an N-GPU request.
+--train times the distillation iteration instead (BASELINE.json configs[3] / [4]: FLUX 4 samples/GPU, Qwen 2 samples/GPU
+with the true-CFG teacher; data parallel, the adapter-gradient all-reduce over RCCL is inside the timed region).
 
 Prints ONE JSON line (rank 0) with the `roofline` object of the dominant kernel (the bf16 MFMA GEMM,
 timed live with HIP events on the launch stream) and a `cpu_baseline` object (the fp32 CPU oracle's
@@ -115,16 +121,139 @@ def _traffic(model):
         return None
 
 
-def main():
+def train_main(args, rank, world, dev, dist):
+    """--train: one step = one distillation iteration (lakonlab/models/diffusions/arcflow.py:338-426 + the optimizer / EMA shell)
+    on the per-GPU batch of the reference config; data parallel over the ranks (samples are independent: weak scaling), the
+    single adapter-gradient all-reduce (RCCL) is inside the timed region and its exposed part is reported."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from arcflow_amd.weights import random_packed
+    flux = args.model == 'flux'
+    D = 3072
+    nd, ns, joint, T = (19, 38, 4096, 512) if flux else (60, 0, 3584, 128)
+    B = args.batch or (4 if flux else 2)
+    packed = random_packed(args.model, nd, ns, dev, joint_dim=joint, seed=0)
+    g = torch.Generator(device=dev).manual_seed(1)
+    packed['teacher_head.weight'] = (torch.randn(64, D, generator=g, device=dev) * 0.02).bfloat16()
+    packed['teacher_head.bias'] = torch.zeros(64, device=dev, dtype=torch.bfloat16)
+    packed['norm_out.weight'] = packed['mod.weight'][-2 * D:].clone()
+    packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
+    # configs/flux/arcflux_2nfe_k16.py / configs/qwen/arcqwen_2nfe_k16.py: rank-256 LoRA, lora_dropout 0.05; Qwen: true-CFG
+    # teacher (scale 4.0, negative prompt), decay 1000
+    kw = dict(lora_rank=256, lora_dropout=0.05, teacher_fp8=args.teacher_fp8)
+    dc = DistillConfig(**kw) if flux else DistillConfig(teacher_guidance_scale=4.0, num_decay_iters=1000, **kw)
+    eng = dict(num_double=nd, num_single=ns) if flux else dict(num_double=nd, joint_dim=joint)
+    ds = ArcFlowDistiller(args.model, eng, None, dc, device=dev, packed=packed)
+    cond = dict(prompt_embeds=(torch.randn(B, T, joint, device=dev, generator=g) * 0.1).bfloat16(), hp=64, wp=64)
+    if flux:
+        cond['pooled'] = (torch.randn(B, 768, device=dev, generator=g) * 0.1).bfloat16()
+    else:
+        cond['negative_prompt_embeds'] = (torch.randn(B, T, joint, device=dev, generator=g) * 0.1).bfloat16()
+    rng = torch.Generator(device=dev).manual_seed(100 + rank)        # per-rank draws (train.py --diff_seed)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        info = ds.train_step(cond, B, rng=rng)
+    barrier()
+    t0 = time.perf_counter()
+    exposed = 0.0
+    for _ in range(args.steps):
+        info = ds.train_step(cond, B, rng=rng)
+        exposed += info['allreduce_exposed_ms']
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank == 0:
+        fwd_equiv = 16 if flux else 24          # SURVEY 3.3: student 2 + teacher 8 (x2 with true CFG) + recompute 2 + backward ~4
+        per_fwd = FLOPS_PER_FORWARD if flux else 70.6e12
+        sps = world * B * args.steps / dt
+        ach = B * args.steps * fwd_equiv * per_fwd / dt / 1e12           # per GPU
+        peak = MFMA_BF16_PEAK_TF
+        line = {
+            'metric': f'distillation samples/sec ({"ArcFlow-FLUX-12B" if flux else "ArcFlow-Qwen-Image-20B"} architecture, data-free '
+                      f'trajectory matching, 2 student steps x 4 teacher states, LoRA r=256 + heads + norm_out trainable)',
+            'value': sps, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16 student + gradients, fp8 e4m3 frozen-teacher linears (configs[4])' if args.teacher_fp8 else 'bf16 (fp32 master weights / gradients / AdamW moments)',
+            'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt embeddings, data-free noise latents)',
+            'config': {'workload': ('ArcFlow-FLUX distillation training (train_flux.sh), LoRA adapters' if flux else
+                                    'ArcFlow-Qwen-20B distillation training (train_qwen.sh), true-CFG teacher'),
+                       'samples_per_gpu': B, 'global_batch': world * B, 'image_tokens': N_IMG, 'text_tokens': T,
+                       'trainable_params': int(ds.params.numel()), 'lora_dropout': 0.05,
+                       'parallelism': f'dp{world}: batch sharded over ranks, one flat-gradient all-reduce per iteration (RCCL), '
+                                      f'sliced per block and overlapped with the last backward'},
+            'roofline': {'bound': 'mfma', 'kernel': 'whole iteration (denoiser forward-equivalents, SURVEY 3.3)', 'achieved': ach,
+                         'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                         'forward_equivalents_per_sample': fwd_equiv},
+            'allreduce_exposed_ms_per_step': exposed / args.steps,
+            'allreduce_bytes_per_step': int(ds.params.numel()) * 4 if world > 1 else 0,
+            'max_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30, 'last_step': info,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 5; 2 with --train)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 2; 1 with --train)')
     ap.add_argument('--model', default='flux', choices=['flux', 'qwen'])
+    ap.add_argument('--train', action='store_true', help='time the distillation iteration (configs[3] flux / configs[4] qwen) instead of inference')
+    ap.add_argument('--batch', type=int, default=None, help='--train: samples per GPU (default: 4 flux, 2 qwen, the reference configs)')
+    ap.add_argument('--teacher-fp8', action='store_true', help='--train: frozen teacher forwards on the fp8 MFMA (configs[4]); the line says so in dtype')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
     ap.add_argument('--fp8', action='store_true', help='OPTIONAL reduced-precision mode: block linears on the fp8 MFMA (not the headline: the line says dtype fp8)')
-    args = ap.parse_args()
+    ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launch (default: derived from the pid)')
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 2 if args.train else 5
+    if args.warmup is None:
+        args.warmup = 1 if args.train else 2
+    return args
+
+
+def launcher_cmd(args, argv, environ=None, device_count=None):
+    """The command `python bench.py --gpus N` re-executes itself with when it is NOT already a torchrun rank, or None when
+    this process should run the bench itself.  Raises when the request cannot be honoured (never a silent n_gpus=1)."""
+    environ = os.environ if environ is None else environ
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' in environ:                      # already one rank of a torchrun launch
+        world = int(environ['WORLD_SIZE'])
+        if world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus}')
+        return None
+    if args.gpus == 1:
+        return None
+    if device_count is None:
+        device_count = torch.cuda.device_count()
+    if device_count < args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} requested but this box exposes {device_count} GPU(s)')
+    port = args.master_port or (29500 + os.getpid() % 2000)
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__), *argv]
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    cmd = launcher_cmd(args, argv)
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        raise SystemExit(subprocess.call(cmd, env=env))
 
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -139,6 +268,8 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = f'cuda:{local_rank if world > 1 else 0}'
+    if args.train:
+        return train_main(args, rank, world, dev, dist)
 
     from arcflow_amd import ops
     from arcflow_amd.schedule import FlowMatchEulerDiscreteScheduler, retrieve_raw_timesteps

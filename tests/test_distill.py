@@ -118,13 +118,17 @@ def _dp_worker(rank, world, port, tmp):
     red = GradReducer()
     assert red.world == world
     g = torch.Generator().manual_seed(100 + rank)
-    bufs = [torch.randn(1000, generator=g), torch.randn(1000, generator=g)]
-    local = [b.clone() for b in bufs]
-    for b in bufs:
-        red.launch(b)                     # async, one exchange per student step
+    buf = torch.randn(5000, generator=g)                # ONE flat gradient buffer, exchanged in slices as they become final
+    local = buf.clone()
+    slices = [(3000, 4200), (1800, 3000), (700, 1800)]  # "blocks" in reverse, the way the last backward releases them
+    for a, b in slices:
+        red.launch(buf[a:b])
+    red.launch(buf[:700])                               # the rest: heads ...
+    red.launch(buf[4200:])                              # ... and the embedder pair
+    assert red.bytes_launched == buf.numel() * 4        # every byte exactly once per iteration
     scale = red.finish()
-    assert scale == 1.0 / world
-    torch.save(dict(local=local, reduced=bufs, mx=red.all_reduce_max(float(rank + 1), 'cpu')), os.path.join(tmp, f'r{rank}.pt'))
+    assert scale == 1.0 / world and red.bytes_launched == 0
+    torch.save(dict(local=local, reduced=buf, mx=red.all_reduce_max(float(rank + 1), 'cpu')), os.path.join(tmp, f'r{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -134,12 +138,130 @@ def test_grad_reducer_gloo_world2(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f'r{i}.pt')) for i in range(2))
-    for i in range(2):
-        expect = r0['local'][i] + r1['local'][i]
-        assert torch.allclose(r0['reduced'][i], expect) and torch.allclose(r1['reduced'][i], expect)
+    expect = r0['local'] + r1['local']
+    assert torch.allclose(r0['reduced'], expect) and torch.allclose(r1['reduced'], expect)
     assert r0['mx'] == 2.0 and r1['mx'] == 2.0
     red_single = __import__('arcflow_amd.train.reducer', fromlist=['GradReducer']).GradReducer()
     assert red_single.world == 1 and red_single.finish() == 1.0
+
+
+def test_block_slices_cover_the_lora_region_once():
+    """The per-block gradient slices the distiller hands to the reducer are contiguous, disjoint, block-major, and together
+    with 'the rest' cover the flat buffer exactly once (pure index arithmetic: no GPU)."""
+    from arcflow_amd.train.trunk import lora_targets
+    for family, nd, ns in (('flux', 3, 5), ('qwen', 4, 0)):
+        D, r, base = 256, 16, 1000
+        off, spans = base, {}
+        for name, key, row0, out_f, in_f in lora_targets(family, nd, ns, D):
+            n = r * in_f + out_f * r
+            blk = key.split('.')[0]
+            a, b = spans.get(blk, (off, off))
+            assert b == off or blk not in spans, 'a block\'s adapters must be contiguous in the flat buffer'
+            spans[blk] = (min(a, off), off + n)
+            off += n
+        blocks = [f'd{i}' for i in range(nd)] + [f's{i}' for i in range(ns)]
+        pos = base
+        for blk in blocks:
+            a, b = spans[blk]
+            assert a == pos and b > a
+            pos = b
+        assert spans['temb'][0] == pos and spans['temb'][1] == off      # the embedder pair closes the buffer
+
+
+def _dp_train_worker(rank, world, port, tmp):
+    """Rank ``rank`` of a 2-process data-parallel step: sample ``rank`` of the 2-sample batch, both ranks on cuda:0
+    (gloo; the reducer stages device buffers through the host because RCCL refuses two ranks on one device)."""
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from arcflow_amd.train import ArcFlowDistiller
+    st = torch.load(os.path.join(tmp, 'setup.pt'), weights_only=False)
+    dd = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), st['w'], st['dc'])
+    assert dd.reducer.world == world and dd.reducer.rank == rank
+    for sp in dd.trunk.specs:
+        dd.trunk.B(sp).copy_(st['B'][sp.name].cuda())
+    dd.trunk.refresh()
+    dd.iteration = 1
+    sl = slice(rank, rank + 1)
+    cond = dict(prompt_embeds=st['pe'][sl].cuda(), pooled=st['pooled'][sl].cuda(), hp=8, wp=8)
+    draws = [tuple(d[sl] for d in step) for step in st['draws']]
+    info = dd.train_step(cond, 1, x_init=st['x0'][sl].cuda(), draws=draws)
+    torch.cuda.synchronize()
+    torch.save(dict(grad=dd.grad.cpu(), params=dd.params.cpu(), info=info), os.path.join(tmp, f'dp{rank}.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_train_step_equals_single_process_batch(tmp_path):
+    """Reference semantics (ddp_wrapper.py:19-25, base_diffusion.py:59-60): the batch is sharded over the ranks, gradients
+    are averaged.  Two processes with one sample each (fixed draws) must reproduce the single-process 2-sample iteration:
+    same exchanged gradient (x 1/world), same parameters after AdamW."""
+    import torch.multiprocessing as mp
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    cfg, w = _setup()
+    B, hp, wp, T, r = 2, 8, 8, 64, 32
+    g = torch.Generator().manual_seed(15)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, hp * wp, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r)
+    single = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+    Bm = {sp.name: (torch.randn(sp.out_f, r, generator=g) * 0.02) for sp in single.trunk.specs}
+    for sp in single.trunk.specs:
+        single.trunk.B(sp).copy_(Bm[sp.name].cuda())
+    single.trunk.refresh()
+    single.iteration = 1
+    info = single.train_step(dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp), B, x_init=x0.cuda(), draws=draws)
+    torch.cuda.synchronize()
+    torch.save(dict(w=w, dc=dc, B=Bm, pe=pe, pooled=pooled, x0=x0, draws=draws), os.path.join(tmp_path, 'setup.pt'))
+    port = 29500 + (os.getpid() + 7) % 2000
+    mp.spawn(_dp_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(tmp_path, f'dp{i}.pt'), weights_only=False) for i in range(2))
+    assert torch.equal(r0['grad'], r1['grad']) and torch.equal(r0['params'], r1['params'])      # ranks stay in lock-step
+    ref_g, ref_p = single.grad.cpu(), single.params.cpu()
+    got_g = r0['grad'] * 0.5                                    # the exchanged SUM x 1/world
+    rel = ((got_g - ref_g).norm() / ref_g.norm()).item()
+    assert rel < 1e-4, rel
+    assert ref_g.abs().max().item() > 0
+    assert ((r0['params'] - ref_p).abs().max() / ref_p.abs().max()).item() < 1e-5
+    assert abs(r0['info']['grad_norm'] - info['grad_norm']) < 1e-3 * info['grad_norm']
+    # the loss is each rank's local mean: their average is the single-process loss
+    assert abs(0.5 * (r0['info']['loss'] + r1['info']['loss']) - info['loss']) < 1e-3 * abs(info['loss'])
+
+
+@pytest.mark.gpu
+def test_micro_batched_step_equals_one_batch():
+    """more than 4 samples per GPU run as micro-batches of <= 4 and must give the gradient of the whole
+    batch (mean over ALL samples), not of the last chunk."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    cfg, w = _setup()
+    B, hp, wp, T = 6, 8, 8, 12
+    g = torch.Generator().manual_seed(33)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16().cuda()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16().cuda()
+    x0 = torch.randn(B, hp * wp, 64, generator=g).cuda()
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0)
+    eng = dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64)
+    big = ArcFlowDistiller('flux', eng, w, dc)
+    big.iteration = 1
+    info = big.train_step(dict(prompt_embeds=pe, pooled=pooled, hp=hp, wp=wp), B, x_init=x0, draws=draws)
+    # reference: the same six samples as two independent 3-sample steps, gradients combined as (3 g_a + 3 g_b) / 6
+    acc, loss = torch.zeros_like(big.grad), 0.0
+    for a, b in ((0, 3), (3, 6)):
+        d = ArcFlowDistiller('flux', eng, w, dc)
+        d.iteration = 1
+        i2 = d.train_step(dict(prompt_embeds=pe[a:b], pooled=pooled[a:b], hp=hp, wp=wp), b - a, x_init=x0[a:b],
+                          draws=[tuple(t[a:b] for t in step) for step in draws])
+        acc += d.grad * 0.5
+        loss += 0.5 * i2['loss']
+    rel = ((big.grad - acc).norm() / acc.norm()).item()
+    assert rel < 2e-3, rel          # chunk boundaries differ (4+2 vs 3+3): bf16 GEMM tiles see different row groupings
+    assert abs(info['loss'] - loss) < 1e-3 * abs(loss)
+    assert big.last_x.shape == (B, hp * wp, 64)
 
 
 @pytest.mark.gpu

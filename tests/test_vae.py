@@ -151,3 +151,58 @@ def test_qwen_pipeline_decodes_images_end_to_end():
     ref = V.decode(vw, z)
     assert img.shape == (1, 3, 64, 64)
     assert ((img.float().cpu() - ref).norm() / ref.norm()).item() < 3e-2
+
+
+# ------------------------------------------------------------------------------------------ released sizes, 1024^2
+def _on_device(w):
+    return {k: v.cuda() for k, v in w.items()}
+
+
+def test_flux_decoder_1024sq_released_width_vs_oracle_on_device():
+    """The released AutoencoderKL decoder width (128/256/512/512, 32 groups) at 1024 x 1024: the 128-channel full-resolution
+    stage (half-filled 256-wide GEMM tiles) and conv_out (3 channels) that the 64-pixel tests never reach.  The fp32 oracle
+    (oracle/vae_ref.py, torch ops) is evaluated on the device here -- on the host it would need minutes."""
+    from arcflow_amd.vae import AutoencoderKLDecoder
+    from oracle import arcflow_ref as R
+    from oracle import vae_ref as V
+    chans = (128, 256, 512, 512)
+    w = V.make_decoder_weights(chans, seed=5)
+    g = torch.Generator().manual_seed(6)
+    hp = wp = 64
+    tok = torch.randn(1, hp * wp, 64, generator=g)
+    dec = AutoencoderKLDecoder(w, chans, norm_num_groups=32)
+    img = dec.decode_packed(tok.cuda(), hp, wp)
+    z = R.unpack_latents(tok, hp, wp) / 0.3611 + 0.1159
+    with torch.no_grad():
+        ref = V.decode(_on_device(w), z.bfloat16().float().cuda(), chans, groups=32)
+    assert img.shape == ref.shape == (1, 3, 1024, 1024)
+    assert torch.isfinite(img.float()).all()
+    rel = ((img.float() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-2, rel
+    # no stripe / tile of the image is off on its own (a mis-addressed tile hides inside a global norm)
+    d = (img.float() - ref).reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
+    r = ref.reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
+    assert (d / r).max().item() < 6e-2, (d / r).max().item()
+
+
+def test_qwen_decoder_1024sq_released_width_vs_oracle_on_device():
+    from arcflow_amd.vae import AutoencoderKLQwenImageDecoder
+    from oracle import arcflow_ref as R
+    from oracle import vae_qwen_ref as V
+    w = V.make_decoder_weights(dim=96, seed=7)
+    g = torch.Generator().manual_seed(8)
+    mean = (torch.randn(16, generator=g) * 0.3).tolist()
+    std = (1.0 + 0.5 * torch.rand(16, generator=g)).tolist()
+    hp = wp = 64
+    tok = torch.randn(1, hp * wp, 64, generator=g)
+    dec = AutoencoderKLQwenImageDecoder(w, mean, std)
+    img = dec.decode_packed(tok.cuda(), hp, wp)
+    z = R.unpack_latents(tok, hp, wp) * torch.tensor(std).view(1, 16, 1, 1) + torch.tensor(mean).view(1, 16, 1, 1)
+    with torch.no_grad():
+        ref = V.decode(_on_device(w), z.cuda())
+    assert img.shape == ref.shape == (1, 3, 1024, 1024)
+    rel = ((img.float() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-2, rel
+    d = (img.float() - ref).reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
+    r = ref.reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
+    assert (d / r).max().item() < 6e-2, (d / r).max().item()
