@@ -11,10 +11,12 @@ namespace afx {
 // One wave per row, D <= 4096, D % 8 == 0; each lane owns chunks lane, lane+64, ... of 8 elements.
 constexpr int NM_MAX_CHUNKS = 8;
 
+// Joint mode (scale_txt != nullptr): the rows are the joint [text n_txt | image] token matrix of rows_per_batch = S rows per
+// sample and the two streams of a double block carry different modulation vectors -- one launch instead of one per stream.
 __global__ __launch_bounds__(256) void norm_modulate_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int rows, int D,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ldmod, int rows_per_batch,
-    int rms) {
+    int rms, const float* __restrict__ scale_txt, const float* __restrict__ shift_txt, int n_txt) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -54,6 +56,10 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
     rstd = rsqrtf(q / (float)D + 1e-6f);
   }
   const int64_t moff = rms ? 0 : (int64_t)(row / rows_per_batch) * ldmod;
+  if (scale_txt != nullptr && row % rows_per_batch < n_txt) {      // wave-uniform: one wave = one row
+    scale = scale_txt;
+    shift = shift_txt;
+  }
   bf16_t* orow = out + (int64_t)row * ldo;
 #pragma unroll
   for (int i = 0; i < NM_MAX_CHUNKS; ++i) {
@@ -84,7 +90,20 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
   if (rows <= 0) return hipSuccess;
   if (D > NM_MAX_CHUNKS * 512 || (D & 7)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows,
-                     D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, rms);
+                     D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, rms, (const float*)nullptr,
+                     (const float*)nullptr, 0);
+  return hipGetLastError();
+}
+
+// LN + modulate of a whole joint token matrix [B][text T | image N] in ONE launch: image rows use (scale, shift), text rows
+// (scale_txt, shift_txt); sample b's vectors sit at + b * ldmod.
+hipError_t launch_norm_modulate_joint(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
+                                      const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
+                                      int n_txt, hipStream_t stream) {
+  if (rows <= 0) return hipSuccess;
+  if (D > NM_MAX_CHUNKS * 512 || (D & 7) || S <= 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, scale, shift, ldmod,
+                     S, 0, scale_txt, shift_txt, n_txt);
   return hipGetLastError();
 }
 
@@ -368,6 +387,117 @@ __global__ __launch_bounds__(256) void arcflow_step_kernel(
   }
 }
 
+
+// Fast path for the shipped mixture shape (K = 16 components, ch = C p^2 = 64 packed channels, pp = p^2 = 4 sub-pixels: FLUX and
+// Qwen-Image alike).  The step is  x_out[c] = x[c] - sum_k coef[k][c % 4] * mean[k][c]  with
+//     coef[k][q] = softmax_k(logw[.][q]) * exp(gamma_k d_past) * d_step * phi(gamma_k d_step)        (k = 0: d = phi = 1)
+// -- K * pp = 64 coefficients per token, i.e. exactly ONE per lane: every transcendental of the token is evaluated once
+// (the generic kernel below evaluates each of them in all 16 lanes that share a sub-pixel), the softmax over K is a 4-step
+// xor-shuffle over the lanes of one sub-pixel, and the token's 1024 means arrive as two 16-byte loads per lane.  Lane l then
+// owns 8 channels of components l/8 and 8 + l/8; a 3-step reduce-scatter (4 + 2 + 1 exchanges) over the 8 lanes that share
+// l % 8 leaves every lane with ONE fully summed channel, so x is read and written as one coalesced 256-byte row per token.
+// TPW tokens per wave with all of their loads issued up front (2 x 2.8 KB in flight per wave): HBM streaming, not latency.
+template <typename MixT> struct Mix8;
+template <> struct Mix8<bf16_t> {
+  AFX_DEV static void load(const bf16_t* p, float (&f)[8]) { unpack8(*reinterpret_cast<const u32x4_t*>(p), f); }
+};
+template <> struct Mix8<float> {
+  AFX_DEV static void load(const float* p, float (&f)[8]) {
+    const f32x4_t a = *reinterpret_cast<const f32x4_t*>(p), b = *reinterpret_cast<const f32x4_t*>(p + 4);
+    f[0] = a[0]; f[1] = a[1]; f[2] = a[2]; f[3] = a[3]; f[4] = b[0]; f[5] = b[1]; f[6] = b[2]; f[7] = b[3];
+  }
+};
+
+template <typename MixT, int TPW>
+__global__ __launch_bounds__(256) void arcflow_step_k16_kernel(
+    const float* __restrict__ x_in, const MixT* __restrict__ means, const MixT* __restrict__ logw,
+    const MixT* __restrict__ logg, float s_src0, float s_start0, float s_end0, const float* __restrict__ sigma_vec, float eps,
+    float* __restrict__ x_out, int64_t tokens, int n_tok, int velocity_only, const uint8_t* __restrict__ drop) {
+  constexpr int K = 16, CH = 64, PP = 4;
+  const int lane = threadIdx.x & 63;
+  const int64_t tok0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * TPW;
+  if (tok0 >= tokens) return;
+  const int k = lane >> 2;                       // this lane's coefficient: component k, sub-pixel lane & 3
+  float mA[TPW][8], mB[TPW][8], lw[TPW], lg[TPW], xv[TPW];
+  // ---- every load of the wave's tokens first -------------------------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int64_t tok = tok0 + t < tokens ? tok0 + t : tokens - 1;      // wave-uniform clamp (the tail token is not stored)
+    const MixT* mt = means + tok * (int64_t)(K * CH);
+    Mix8<MixT>::load(mt + lane * 8, mA[t]);                             // component lane/8,      channels (lane%8)*8 ..
+    Mix8<MixT>::load(mt + (64 + lane) * 8, mB[t]);                      // component 8 + lane/8
+    lw[t] = mix_load<MixT>(logw + tok * (K * PP), lane);
+    lg[t] = k > 0 ? mix_load<MixT>(logg + tok * ((K - 1) * PP), lane - PP) : 0.f;
+  }
+  const int e3 = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);   // channel (inside the lane's 8) left after the reduce-scatter
+  const int cfin = (lane & 7) * 8 + e3;
+  if (!velocity_only) {
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) xv[t] = x_in[(tok0 + t < tokens ? tok0 + t : tokens - 1) * CH + cfin];
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int64_t tok = tok0 + t;
+    if (tok >= tokens) break;                    // wave-uniform
+    const int64_t bidx = tok / n_tok;
+    float s_src = s_src0, s_start = s_start0, s_end = s_end0;
+    if (sigma_vec != nullptr) {
+      s_src = sigma_vec[3 * bidx];
+      s_start = sigma_vec[3 * bidx + 1];
+      s_end = sigma_vec[3 * bidx + 2];
+    }
+    const float d_past = s_src - s_start, d_step = s_start - s_end;
+    float l = lw[t];
+    if (drop != nullptr && drop[bidx * K + k]) l = -INFINITY;           // GM dropout: component k of sample b removed
+    // softmax over the 16 components of this sub-pixel: lanes q, q+4, ..., q+60
+    float mx = l;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float ex = expf(l - mx);
+    float den = ex;
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) den += __shfl_xor(den, o, 64);
+    float coef = ex / den;
+    if (k > 0) {
+      const float g = lg[t];
+      coef *= expf(g * d_past);
+      if (!velocity_only) {
+        const float z = g * d_step;
+        const float zs = (z < 0.f ? -1.0f : 1.0f) * fmaxf(fabsf(z), eps);
+        coef *= d_step * (expm1f(zs) / zs);
+      }
+    } else if (!velocity_only) {
+      coef *= d_step;                             // k = 0: straight-line component (d = phi = 1)
+    }
+    // the 4 coefficients (sub-pixels) of this lane's two components
+    float cA[4], cB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cA[q] = __shfl(coef, (lane >> 3) * 4 + q, 64);
+      cB[q] = __shfl(coef, (8 + (lane >> 3)) * 4 + q, 64);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = cA[e & 3] * mA[t][e] + cB[e & 3] * mB[t][e];
+    // reduce-scatter over the 8 lanes sharing lane % 8 (xor 32, 16, 8): 4 + 2 + 1 exchanges
+    const bool h5 = (lane & 32) != 0, h4 = (lane & 16) != 0, h3 = (lane & 8) != 0;
+    float w4[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float keep = h5 ? v[4 + i] : v[i], send = h5 ? v[i] : v[4 + i];
+      w4[i] = keep + __shfl_xor(send, 32, 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float keep = h4 ? w4[2 + i] : w4[i], send = h4 ? w4[i] : w4[2 + i];
+      w2[i] = keep + __shfl_xor(send, 16, 64);
+    }
+    const float keep = h3 ? w2[1] : w2[0], send = h3 ? w2[0] : w2[1];
+    const float acc = keep + __shfl_xor(send, 8, 64);
+    x_out[tok * CH + cfin] = velocity_only ? acc : (xv[t] - acc);
+  }
+}
+
 hipError_t launch_arcflow_step(const float* x_in, const void* means, const void* logw, const void* logg,
                                int mix_bf16, float s_src, float s_start, float s_end,
                                const float* sigma_vec, float eps, float* x_out, int B, int n_tok, int K,
@@ -375,6 +505,17 @@ hipError_t launch_arcflow_step(const float* x_in, const void* means, const void*
   if (K < 1 || K > ARC_MAXK || pp < 1 || ch < 1) return hipErrorInvalidValue;
   const int64_t tokens = (int64_t)B * n_tok;
   if (tokens == 0) return hipSuccess;
+  if (K == 16 && ch == 64 && pp == 4) {             // the shipped mixture shape: one coefficient per lane (see above)
+    constexpr int TPW = 2;
+    dim3 g2((unsigned)((tokens + 4 * TPW - 1) / (4 * TPW)));
+    if (mix_bf16)
+      hipLaunchKernelGGL((arcflow_step_k16_kernel<bf16_t, TPW>), g2, dim3(256), 0, stream, x_in, (const bf16_t*)means, (const bf16_t*)logw,
+                         (const bf16_t*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out, tokens, n_tok, velocity_only, drop);
+    else
+      hipLaunchKernelGGL((arcflow_step_k16_kernel<float, TPW>), g2, dim3(256), 0, stream, x_in, (const float*)means, (const float*)logw,
+                         (const float*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out, tokens, n_tok, velocity_only, drop);
+    return hipGetLastError();
+  }
   dim3 grid((unsigned)((tokens + 3) / 4)), block(256);
   if (mix_bf16)
     hipLaunchKernelGGL(arcflow_step_kernel<bf16_t>, grid, block, 0, stream, x_in, (const bf16_t*)means,

@@ -49,9 +49,14 @@ LaunchTimer& launch_timer();
 // vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)
 hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
                               hipStream_t stream);
+// qw_txt != nullptr: q is the RAW projection; RMSNorm(q) * w + RoPE are applied in the kernel's prologue (text rows: row % S < n_txt)
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream, float* lse = nullptr);
+                            hipStream_t stream, float* lse = nullptr, const float* qw_txt = nullptr, const float* qw_img = nullptr,
+                            const float* cos_t = nullptr, const float* sin_t = nullptr, int n_txt = 0);
+// K <- RoPE(RMSNorm(K) w) in place and V -> V^T (key-permuted) in one launch
+hipError_t launch_kv_prep(uint16_t* k, int64_t ldk, const float* wk_txt, const float* wk_img, const float* cos_t, const float* sin_t,
+                          int n_txt, const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S, hipStream_t stream);
 // text encoders: runtime scale, causal mask, additive bias table [H][2S-1] (pre-divided by scale), grouped KV heads, d 64|128
 hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
                                 uint16_t* vt_ws, uint16_t* o, int64_t ldo, int B, int H, int Hkv, int S, int head_dim, float scale,
@@ -71,6 +76,9 @@ hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int
 hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,
                                 int D, const float* scale, const float* shift, int64_t ldmod,
                                 int rows_per_batch, int rms, hipStream_t stream);
+hipError_t launch_norm_modulate_joint(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
+                                      const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
+                                      int n_txt, hipStream_t stream);
 hipError_t launch_qk_norm_rope(uint16_t* x, int64_t ldx, const float* w_txt, const float* w_img,
                                const float* cos_t, const float* sin_t, int B, int S, int n_txt, int H,
                                hipStream_t stream);

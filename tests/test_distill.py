@@ -201,7 +201,7 @@ def test_two_rank_train_step_equals_single_process_batch(tmp_path):
     import torch.multiprocessing as mp
     from arcflow_amd.train import ArcFlowDistiller, DistillConfig
     cfg, w = _setup()
-    B, hp, wp, T, r = 2, 8, 8, 64, 32
+    B, hp, wp, T, r = 2, 8, 8, 64, 64
     g = torch.Generator().manual_seed(15)
     pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
     pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
