@@ -19,6 +19,8 @@
 // The kernel is a template <head dim, EXT>.  <128, false> is the MMDiT product path above.  EXT = true adds what the
 // text encoders need (afx_text.hip): a runtime softmax scale, causal masking with tile skipping, an additive
 // relative-position bias table (T5), grouped KV heads (Qwen2.5), and head dim 64 (T5, CLIP).
+#include <cstdlib>
+
 #include <hip/hip_ext.h>
 
 #include "afx_common.h"
@@ -85,20 +87,27 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
 
 
 // ---------------------------------------------------------------------------------------------
-// K / V preparation of one attention call in ONE launch (the q side is fused into the attention prologue, see QFuse):
-//   blocks [0, nblk_k):  K <- RoPE(RMSNorm_128(K) * w) in place -- 16 lanes x 8 elements = one (token, head), the 4 rotation
-//                        pairs of a lane stay inside its own 16-byte chunk (same math as qk_norm_rope_kernel);
-//   blocks [nblk_k, ..): V^T tiles as v_transpose_kernel<128>.
-__global__ __launch_bounds__(256) void kv_prep_kernel(bf16_t* __restrict__ k, int64_t ldk, const float* __restrict__ w_txt,
-                                                      const float* __restrict__ w_img, const float* __restrict__ cos_t,
+// Operand preparation of one attention call in ONE launch (was three: k/q RMSNorm+RoPE, V transpose):
+//   blocks [0, 2 nblk_k):  X <- RoPE(RMSNorm_128(X) * w) in place for X = K (first nblk_k blocks) and X = Q -- 16 lanes x 8
+//                          elements = one (token, head), the 4 rotation pairs of a lane stay inside its own 16-byte chunk;
+//   blocks [2 nblk_k, ..): V^T tiles as v_transpose_kernel<128>.
+// Measured and dropped: the q part inside the attention prologue (QFuse, r02c): +23 us per attention launch (prologue VALU +
+// 64 KB of cos/sin per work-group in front of the first MFMA, 1.69 rounds deep) against the 11 us it saves here.
+struct PrepX { bf16_t* x[2]; const float* w_txt[2]; const float* w_img[2]; };
+
+__global__ __launch_bounds__(256) void kv_prep_kernel(const PrepX px, int64_t ldk, const float* __restrict__ cos_t,
                                                       const float* __restrict__ sin_t, int n_txt, const bf16_t* __restrict__ v,
                                                       int64_t ldv, bf16_t* __restrict__ vt, int B, int H, int S, int S_pad,
                                                       int nblk_k) {
   constexpr int HD = 128;
   __shared__ bf16_t tile[KVB][HD + 2];
   const int tid = threadIdx.x;
-  if ((int)blockIdx.x < nblk_k) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + tid;            // (row, head, chunk)
+  if ((int)blockIdx.x < 2 * nblk_k) {
+    const int which = (int)blockIdx.x >= nblk_k;
+    bf16_t* __restrict__ k = px.x[which];
+    const float* __restrict__ w_txt = px.w_txt[which];
+    const float* __restrict__ w_img = px.w_img[which];
+    const int64_t g = (int64_t)((int)blockIdx.x - which * nblk_k) * 256 + tid;            // (row, head, chunk)
     const int64_t total = (int64_t)B * S * H * 16;
     if (g >= total) return;
     const int c = (int)(g & 15);
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(bf16_t* __restrict__ k, in
     *reinterpret_cast<u32x4_t*>(p) = pack8(r);
     return;
   }
-  const int vb = blockIdx.x - nblk_k;                              // (kv tile, head, batch)
+  const int vb = blockIdx.x - 2 * nblk_k;                          // (kv tile, head, batch)
   const int ntile = S_pad / KVB;
   const int kv0 = (vb % ntile) * KVB, h = (vb / ntile) % H, b = vb / (ntile * H);
   constexpr int CPR = HD / 8;
@@ -162,13 +171,17 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(bf16_t* __restrict__ k, in
   }
 }
 
-hipError_t launch_kv_prep(uint16_t* k, int64_t ldk, const float* wk_txt, const float* wk_img, const float* cos_t, const float* sin_t,
-                          int n_txt, const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S, hipStream_t stream) {
+hipError_t launch_kv_prep(uint16_t* k, uint16_t* q, int64_t ldk, const float* wk_txt, const float* wk_img, const float* wq_txt,
+                          const float* wq_img, const float* cos_t, const float* sin_t, int n_txt, const uint16_t* v, int64_t ldv,
+                          uint16_t* vt, int B, int H, int S, hipStream_t stream) {
   const int S_pad = (int)attn_spad(S);
   const int nblk_k = (int)(((int64_t)B * S * H * 16 + 255) / 256);
   const int nblk_v = (S_pad / KVB) * H * B;
-  hipLaunchKernelGGL(kv_prep_kernel, dim3(nblk_k + nblk_v), dim3(256), 0, stream, k, ldk, wk_txt, wk_img, cos_t, sin_t, n_txt, v, ldv,
-                     vt, B, H, S, S_pad, nblk_k);
+  PrepX px{};
+  px.x[0] = k; px.w_txt[0] = wk_txt; px.w_img[0] = wk_img;
+  px.x[1] = q; px.w_txt[1] = wq_txt; px.w_img[1] = wq_img;
+  hipLaunchKernelGGL(kv_prep_kernel, dim3(2 * nblk_k + nblk_v), dim3(256), 0, stream, px, ldk, cos_t, sin_t, n_txt, v, ldv, vt, B, H, S,
+                     S_pad, nblk_k);
   return hipGetLastError();
 }
 
@@ -180,22 +193,11 @@ struct AttnExt {            // EXT = true only
   int kv_group;             // query heads per KV head (1 = MHA)
 };
 
-// Q-side fusion (HD = 128, !EXT): when w_txt != nullptr the kernel reads the RAW q projection and applies
-// RMSNorm_128(q) * w followed by the interleaved-pair RoPE to its 128 query rows in the prologue (fp32 math, rounded to bf16
-// exactly where the separate qk_norm_rope pass rounded) -- the q slab is never rewritten in HBM.
-struct QFuse {
-  const float* w_txt;       // [128] RMSNorm weight of the text rows (row % S < n_txt), or nullptr: q is already normalised + rotated
-  const float* w_img;       // [128] ... of the image rows
-  const float* cos_t;       // [S][64]
-  const float* sin_t;
-  int n_txt;
-};
-
 template <int HD, bool EXT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
     const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B,
-    float* __restrict__ lse, const AttnExt ext, const QFuse qfuse) {
+    float* __restrict__ lse, const AttnExt ext) {
   constexpr int STAGE_BYTES = 2 * KVB * HD * 2;
   constexpr int KS = HD / 16;          // k-steps of the score product
   constexpr int DT = HD / 32;          // 32-row tiles of O^T
@@ -284,42 +286,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
 
   stage_tile(0, 0);
   if (ntiles > 1) stage_tile(1, 1);
-  if constexpr (HD == 128 && !EXT) {
-    if (qfuse.w_txt != nullptr) {        // RMSNorm + RoPE of this lane's half row (d = 16 s + 8 hi .. + 7); the other half sits in lane ^ 32
-      float ss = 0.f;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
-        float t8[8];
-        unpack8(__builtin_bit_cast(u32x4_t, qf[s]), t8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) ss += t8[e] * t8[e];
-      }
-      ss += __shfl_xor(ss, 32, 64);
-      const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-      const float* w = qrow < qfuse.n_txt ? qfuse.w_txt : qfuse.w_img;
-      const float* cr = qfuse.cos_t + (int64_t)qrow * 64 + hi * 4;
-      const float* sr = qfuse.sin_t + (int64_t)qrow * 64 + hi * 4;
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {        // one k-step at a time (sched_barrier): hoisting all 8 steps' loads costs 130 registers and spills
-        __builtin_amdgcn_sched_barrier(0);
-        float t8[8];
-        unpack8(__builtin_bit_cast(u32x4_t, qf[s]), t8);
-        const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(w + s * 16 + hi * 8), w1 = *reinterpret_cast<const f32x4_t*>(w + s * 16 + hi * 8 + 4);
-        const float wv[8] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3]};
-        const f32x4_t cs = *reinterpret_cast<const f32x4_t*>(cr + s * 8), sn = *reinterpret_cast<const f32x4_t*>(sr + s * 8);
-        float r[8];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float a = t8[2 * i] * rstd * wv[2 * i];
-          const float b2 = t8[2 * i + 1] * rstd * wv[2 * i + 1];
-          r[2 * i] = a * cs[i] - b2 * sn[i];
-          r[2 * i + 1] = a * sn[i] + b2 * cs[i];
-        }
-        qf[s] = __builtin_bit_cast(bf16x8_t, pack8(r));
-      }
-    }
-  }
-  __syncthreads();
+  AFX_SYNC_DMA();
   // Pin the Q fragments as landed HERE: otherwise their pending global loads reach the loop header and
   // hipcc's conservative merge turns the first in-loop wait into vmcnt(0).
 #pragma unroll
@@ -330,7 +297,10 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   //   B  16 MFMAs  S^T = K Q^T
   //   C  ds_read all 16 V^T fragments of tile t                  [latency hides under the softmax VALU]
   //   D  online softmax in registers -> P^T fragments
-  //   E  __syncthreads: tile t+1 landed (vmcnt 0), nobody reads buffer t&1 any more
+  //   E  explicit s_waitcnt vmcnt(0) + barrier: tile t+1 landed, nobody reads buffer t&1 any more (AFX_SYNC_DMA: the
+  //      compiler's own wait is NOT reliable here).  Measured alternatives (r02, S = 4608, H = 24): a second raw barrier +
+  //      counted vmcnt(8) so that a tile stays in flight across one barrier: 374-380 us vs 335 us for this form -- with two
+  //      independent work-groups per CU every extra barrier costs more in lost phase slack than the DMA wait it hides.
   //   F  LDS-DMA tile t+2 into buffer t&1                              [hides under G and the next B..D]
   //   G  16 MFMAs  O^T += V^T P^T
   bf16x8_t kf0[KS], kf1[KS], vf[DT][4];
@@ -428,7 +398,7 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     }
     l_run += psum;
     // ---- E ----
-    __syncthreads();
+    AFX_SYNC_DMA();
     // ---- F ----
     if (t + 2 < ntiles) stage_tile(t + 2, t & 1);
     // ---- G ----
@@ -460,19 +430,17 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
 
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream, float* lse, const float* qw_txt, const float* qw_img, const float* cos_t,
-                            const float* sin_t, int n_txt) {
-  const QFuse qfuse{qw_txt, qw_img, cos_t, sin_t, n_txt};
+                            hipStream_t stream, float* lse) {
   const int S_pad = (int)attn_spad(S);
   const int nq = (S + QB - 1) / QB;
   const int heads_per_xcd = (H + 7) / 8;
   dim3 grid(8 * heads_per_xcd * nq * B);
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, launch_timer().start, launch_timer().stop,
-                          0, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B, lse, AttnExt{}, qfuse);
+                          0, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq, B, lse, AttnExt{});
   else
     hipLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad,
-                       nq, B, lse, AttnExt{}, qfuse);
+                       nq, B, lse, AttnExt{});
   return hipGetLastError();
 }
 
@@ -487,11 +455,11 @@ hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* 
   if (head_dim == 128) {
     hipLaunchKernelGGL(v_transpose_kernel<128>, dim3(S_pad / KVB, Hkv, B), dim3(256), 0, stream, v, ldv, vt_ws, Hkv, S, S_pad);
     hipLaunchKernelGGL((attention_kernel<128, true>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt_ws, o, ldo, H, S, S_pad,
-                       nq, B, (float*)nullptr, ext, QFuse{});
+                       nq, B, (float*)nullptr, ext);
   } else {
     hipLaunchKernelGGL(v_transpose_kernel<64>, dim3(S_pad / KVB, Hkv, B), dim3(256), 0, stream, v, ldv, vt_ws, Hkv, S, S_pad);
     hipLaunchKernelGGL((attention_kernel<64, true>), grid, dim3(ATT_THREADS), 0, stream, q, ldq, k, ldk, vt_ws, o, ldo, H, S, S_pad,
-                       nq, B, (float*)nullptr, ext, QFuse{});
+                       nq, B, (float*)nullptr, ext);
   }
   return hipGetLastError();
 }

@@ -137,7 +137,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
     for (int r = 0; r < 16; ++r) acc[d][r] = 0.f;
 
   stage(0, 0);
-  __syncthreads();
+  AFX_SYNC_DMA();
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     asm volatile("" : "+v"(qf[s]));
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int d = 0; d < 4; ++d)
         acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(kts, d * 32 + ql, g * 2 + hi), dsf[g], acc[d], 0, 0, 0);
-    __syncthreads();
+    AFX_SYNC_DMA();
   }
   if (q_ok) {
     bf16_t* op = dq + ((int64_t)b * S + q0 + ql) * lddq + h * HD;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     for (int r = 0; r < 16; ++r) dva[d][r] = dka[d][r] = 0.f;
 
   stage(0, 0);
-  __syncthreads();
+  AFX_SYNC_DMA();
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     asm volatile("" : "+v"(kf[s]));
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
         }
       }
     }
-    __syncthreads();
+    AFX_SYNC_DMA();
   }
   if (k_ok) {
     bf16_t* kp_o = dk + ((int64_t)b * S + k0 + kl) * lddk + h * HD;

@@ -14,6 +14,17 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 
 #define AFX_DEV __device__ __forceinline__
 
+// Work-group barrier that ALSO retires this wave's LDS-DMA (global_load_lds) transfers.  A bare __syncthreads() is not enough:
+// hipcc only puts the s_waitcnt vmcnt(0) in front of the s_barrier when its own bookkeeping still sees the DMA as pending,
+// and after loop unswitching one copy of the attention main loop came out WITHOUT it (ROCm 7.2) -- a wave then read a K / V
+// tile whose last pieces were still in flight (found with tools/race_probe_attn.py: 5-20 % of the launches at S = 4608 had a
+// few 32-query slabs off by one tile's weight).  The explicit wait costs nothing where the compiler would have emitted it.
+#define AFX_SYNC_DMA()                                   \
+  do {                                                   \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     \
+    __syncthreads();                                     \
+  } while (0)
+
 AFX_DEV float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
 // fp32 -> bf16 on the gfx950 conversion unit (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN quieted --

@@ -47,10 +47,26 @@ inline int64_t align256(int64_t x) { return (x + 255) / 256 * 256; }
 
 }  // namespace
 
+// Weight pointers of one linear / one block, resolved once in afx_finalize (the launch plan does no string work)
+struct LinW {
+  const uint16_t* w = nullptr;    // bf16 [out, in]
+  const uint16_t* b = nullptr;    // bf16 [out]
+  const void* wq = nullptr;       // fp8 mode: e4m3 [out, in]
+  const float* wscale = nullptr;  //           per-output-channel scale [out]
+};
+struct DoubleW { LinW qkv[2], out[2], mlp1[2], mlp2[2]; const float* qkn = nullptr; };   // [0] image stream, [1] text stream
+struct SingleW { LinW fused, out; const float* qkn = nullptr; };
+
 struct afx_ctx {
   afx_model_desc d;
   std::unordered_map<std::string, Weight> w;
   bool finalized = false;
+  std::vector<DoubleW> dbl;
+  std::vector<SingleW> sgl;
+  // side stream for the weight-streaming modulation GEMV (HBM-bound, 6.5 GB for FLUX): it runs under the first blocks' MFMA work
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int mod_overlap = -1;          // -1: read AFX_MOD_OVERLAP on first use (default off)
   char* ws = nullptr;
   int64_t ws_bytes = 0;
   int D = 0;
@@ -114,6 +130,8 @@ struct ModLayout {
 };
 
 struct Workspace {
+  uint32_t* sk_flags;   // stream-K GEMM tail (afx_gemm.hip): 1024 flag words at offset 0 (zeroed by afx_set_workspace, re-armed by the kernel)
+  float* sk_slab;       //   + 256 fp32 accumulator slabs of one 256x256 tile each
   uint16_t *X, *Xn, *F, *Vt, *head;
   float *sincos, *tmp, *temb, *semb, *mod, *pooled;
   uint8_t* q8;     // fp8 mode: the quantised A operand of the GEMM about to run [R, <= 5D]
@@ -130,6 +148,8 @@ Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
     off += align256(bytes);
     return p;
   };
+  w.sk_flags = (uint32_t*)take(GEMM_SK_FLAG_BYTES);          // FIRST: its offset must not depend on the shape
+  w.sk_slab = (float*)take(GEMM_SK_SLAB_BYTES);
   w.X = (uint16_t*)take(R * D * 2);
   w.Xn = (uint16_t*)take(R * D * 2);
   w.F = (uint16_t*)take(R * 7 * D * 2);   // single: fused [k|v|q|mlp]; double: [QKV 3D] then [H 4D]
@@ -204,8 +224,12 @@ int afx_create(const afx_model_desc* desc, afx_ctx** out) {
 }
 
 int afx_destroy(afx_ctx* ctx) {
-  if (ctx)
+  if (ctx) {
     for (auto& r : ctx->prof_pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+  }
   delete ctx;
   return AFX_OK;
 }
@@ -263,6 +287,28 @@ int afx_finalize(afx_ctx* c) {
   NEED(need_linear(c, "head", c->head_n, D));
   if (c->w.count("mod_final.weight")) NEED(need_linear(c, "mod_final", 2 * D, D));
 #undef NEED
+  auto lin = [&](const std::string& n) {
+    LinW l;
+    l.w = W16(c, n + ".weight"); l.b = W16(c, n + ".bias");
+    l.wq = WQ(c, n + ".weight_q"); l.wscale = W32(c, n + ".wscale");
+    return l;
+  };
+  c->dbl.assign(d.num_double, DoubleW{});
+  for (int i = 0; i < d.num_double; ++i) {
+    const std::string p = "d" + std::to_string(i) + ".";
+    for (int s = 0; s < 2; ++s) {
+      const std::string q = p + (s == 0 ? "img_" : "txt_");
+      c->dbl[i].qkv[s] = lin(q + "qkv"); c->dbl[i].out[s] = lin(q + "out");
+      c->dbl[i].mlp1[s] = lin(q + "mlp1"); c->dbl[i].mlp2[s] = lin(q + "mlp2");
+    }
+    c->dbl[i].qkn = W32(c, p + "qknorm");
+  }
+  c->sgl.assign(d.num_single, SingleW{});
+  for (int i = 0; i < d.num_single; ++i) {
+    const std::string p = "s" + std::to_string(i) + ".";
+    c->sgl[i].fused = lin(p + "fused"); c->sgl[i].out = lin(p + "out");
+    c->sgl[i].qkn = W32(c, p + "qknorm");
+  }
   c->finalized = true;
   return AFX_OK;
 }
@@ -275,6 +321,8 @@ int64_t afx_workspace_bytes(const afx_ctx* ctx, int32_t batch, int32_t n_img, in
 int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes) {
   if (!ctx || !dptr || bytes <= 0) return fail(AFX_E_INVALID, "bad workspace");
   if (((uintptr_t)dptr & 255) != 0) return fail(AFX_E_INVALID, "workspace must be 256-byte aligned");
+  if (bytes < GEMM_SK_FLAG_BYTES) return fail(AFX_E_WORKSPACE, "workspace too small");
+  HIP_TRY(hipMemset(dptr, 0, GEMM_SK_FLAG_BYTES));          // stream-K hand-off flags start cleared (the kernel re-arms them)
   ctx->ws = (char*)dptr;
   ctx->ws_bytes = bytes;
   return AFX_OK;
@@ -308,6 +356,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   const int64_t R = (int64_t)B * S;
   ModLayout ml{D, d.num_double, d.num_single};
   const int64_t ldm = c->n_mod;
+  int overlap_join_block = -1;          // >= 0: the side-stream modulation GEMV must be joined in front of this block
 
   if (stage != 2) {
   // ---- conditioning: temb = t_mlp(sincos(1000 t)) [+ g_mlp(sincos(1000 g))] [+ p_mlp(pooled)] ------
@@ -329,11 +378,42 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.p.l2.weight"), W16(c, "temb.p.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 1, st));
   }
   HIP_TRY(launch_silu(ws.temb, ws.semb, (int64_t)B * D, st));
-  // every AdaLN modulation vector of the whole network in one weight-streaming pass
-  HIP_TRY(launch_gemv(ws.semb, W16(c, "mod.weight"), W16(c, "mod.bias"), ws.mod, B, (int)c->n_mod, (int)D, 0, 0, st));
+  // Every AdaLN modulation vector of the whole network in one weight-streaming pass over the stacked [n_mod, D] matrix
+  // (6.5 GB for FLUX: 1.3 ms of pure HBM streaming).  Only the first blocks' rows are needed right away: those run on the
+  // forward's stream; with AFX_MOD_OVERLAP=1 the rest streams on a side stream under the embedders' and first blocks' MFMA work
+  // and is joined in front of the first block that reads it (fork / join by events).  OFF by default: measured 140.2 vs 139.5 ms
+  // per image (r02c) -- the GEMMs lose more to the shared HBM / issue slots than the 1.3 ms the stream hides.
+  if (c->mod_overlap < 0) {
+    const char* e = getenv("AFX_MOD_OVERLAP");
+    c->mod_overlap = (e && e[0] == '1') ? 1 : 0;     // opt-in: measured -0.5 % on FLUX (r02c: the stream steals HBM + issue slots from the GEMMs)
+  }
+  const int nblocks = d.num_double + d.num_single;
+  const int head_blocks = 2;                                  // blocks whose modulation rows stay on the main stream
+  int64_t rows_main = c->n_mod;
+  overlap_join_block = -1;
+  if (c->mod_overlap && stage == 0 && nblocks > head_blocks + 2) {
+    rows_main = head_blocks <= d.num_double ? ml.dbl(head_blocks, 0, 0) : ml.sgl(head_blocks - d.num_double, 0);
+    if (!c->side) {
+      HIP_TRY(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+      HIP_TRY(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    }
+    HIP_TRY(hipEventRecord(c->ev_fork, st));                  // semb is ready
+    HIP_TRY(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+    const uint16_t* mw = W16(c, "mod.weight");
+    const uint16_t* mb = W16(c, "mod.bias");
+    HIP_TRY(launch_gemv(ws.semb, mw + rows_main * D, mb + rows_main, ws.mod + rows_main, B, (int)(c->n_mod - rows_main), (int)D, 0, 0,
+                        c->side, ldm));
+    if (W16(c, "mod_final.weight") != nullptr)
+      HIP_TRY(launch_gemv(ws.semb, W16(c, "mod_final.weight"), W16(c, "mod_final.bias"), ws.mod + ml.fin(0), B, (int)(2 * D),
+                          (int)D, 0, 0, c->side, ldm));
+    HIP_TRY(hipEventRecord(c->ev_join, c->side));
+    overlap_join_block = head_blocks;
+  }
+  HIP_TRY(launch_gemv(ws.semb, W16(c, "mod.weight"), W16(c, "mod.bias"), ws.mod, B, (int)rows_main, (int)D, 0, 0, st, ldm));
   // a separately bound norm_out.linear (the distillation student trains its own copy while the teacher keeps the
   // frozen one inside the stacked matrix: lakonlab/configs/flux/arcflux_2nfe_k16.py:20-25 freeze_exclude 'norm_out')
-  if (W16(c, "mod_final.weight") != nullptr)
+  if (overlap_join_block < 0 && W16(c, "mod_final.weight") != nullptr)
     HIP_TRY(launch_gemv(ws.semb, W16(c, "mod_final.weight"), W16(c, "mod_final.bias"), ws.mod + ml.fin(0), B, (int)(2 * D),
                         (int)D, 0, 0, st, ldm));
 
@@ -363,9 +443,16 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   }   // stage != 2
   if (stage == 1) return AFX_OK;       // the caller runs the blocks itself on the exported token matrix
 
+  auto join_side = [&](int blk) -> int {
+    if (overlap_join_block >= 0 && blk >= overlap_join_block) {
+      HIP_TRY(hipStreamWaitEvent(st, c->ev_join, 0));
+      overlap_join_block = -1;
+    }
+    return AFX_OK;
+  };
   // helper: one grouped GEMM over the image and text row ranges of every sample
-  auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const std::string& pre, const char* suffix,
-                         uint16_t* C, int64_t ldc, int Nout, int epi, int blk, int gate_chunk) -> int {
+  auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
+                         int blk, int gate_chunk) -> int {
     GemmBatch gb{};
     if (c->fp8) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
     for (int b = 0; b < B; ++b)
@@ -373,12 +460,11 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         GemmProblem& p = gb.p[gb.nprob++];
         p = GemmProblem{};
         const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
-        const std::string wn = pre + (s == 0 ? "img_" : "txt_") + suffix;
         p.A = A + row0 * lda; p.lda = lda;
-        p.W = W16(c, wn + ".weight"); p.ldw = K; p.bias = W16(c, wn + ".bias");
+        p.W = lw[s].w; p.ldw = K; p.bias = lw[s].b;
         if (c->fp8) {
           p.A = (const uint16_t*)(ws.q8 + row0 * K); p.lda = K;
-          p.W = (const uint16_t*)WQ(c, wn + ".weight_q"); p.fp8 = 1; p.a_scale = ws.qs + row0; p.w_scale = W32(c, wn + ".wscale");
+          p.W = (const uint16_t*)lw[s].wq; p.fp8 = 1; p.a_scale = ws.qs + row0; p.w_scale = lw[s].wscale;
         }
         p.C = C + row0 * ldc; p.ldc = ldc;
         p.M = (s == 0 ? N : T); p.N = Nout; p.K = K;
@@ -388,17 +474,26 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
           p.res = C + row0 * ldc; p.ldr = ldc;
         }
       }
+    gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
     return AFX_OK;
   };
+  // LN + modulate of both streams of every sample in one launch (text rows take the text stream's vectors)
+  static const bool dbg_oldnorm = getenv("AFX_DBG_OLDNORM") != nullptr, dbg_oldprep = getenv("AFX_DBG_OLDPREP") != nullptr;
   auto stream_norm = [&](int blk, int shift_chunk, int scale_chunk) -> int {
-    for (int b = 0; b < B; ++b)
-      for (int s = 0; s < 2; ++s) {
-        const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
-        HIP_TRY(launch_norm_modulate(ws.X + row0 * D, D, ws.Xn + row0 * D, D, s == 0 ? N : T, (int)D,
-                                     ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, scale_chunk),
-                                     ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, shift_chunk), 0, 1 << 30, 0, st));
-      }
+    if (dbg_oldnorm) {
+      for (int b = 0; b < B; ++b)
+        for (int s = 0; s < 2; ++s) {
+          const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
+          HIP_TRY(launch_norm_modulate(ws.X + row0 * D, D, ws.Xn + row0 * D, D, s == 0 ? N : T, (int)D,
+                                       ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, scale_chunk),
+                                       ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, shift_chunk), 0, 1 << 30, 0, st));
+        }
+      return AFX_OK;
+    }
+    HIP_TRY(launch_norm_modulate_joint(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
+                                       ws.mod + ml.dbl(blk, 0, shift_chunk), ws.mod + ml.dbl(blk, 1, scale_chunk),
+                                       ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, S, T, st));
     return AFX_OK;
   };
 
@@ -407,25 +502,33 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   uint16_t* QKV = ws.F;                 // [R, 3D]  rows k|v|q
   uint16_t* Hb = ws.F + R * 3 * D;      // [R, 4D]  MLP hidden
   for (int i = 0; stage == 0 && i < d.num_double; ++i) {
-    const std::string p = "d" + std::to_string(i) + ".";
-    const float* qkn = W32(c, p + "qknorm");   // [img_q, img_k, txt_q, txt_k][128]
+    const DoubleW& bw = c->dbl[i];
+    const float* qkn = bw.qkn;          // [img_q, img_k, txt_q, txt_k][128]
+    if ((rc = join_side(i))) return rc;
     if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     if ((rc = stream_norm(i, 0, 1))) return rc;
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "qkv", QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
-    HIP_TRY(launch_qk_norm_rope2(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn + 0 * 128, rope_cos,
-                                 rope_sin, B, S, T, H, st));                                                                // k and q
-    HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
-    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
-    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, p, "out", ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
+    // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
+    if (dbg_oldprep) {
+      HIP_TRY(launch_qk_norm_rope2(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn + 0 * 128, rope_cos,
+                                   rope_sin, B, S, T, H, st));
+      HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
+    } else
+    HIP_TRY(launch_kv_prep(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn, rope_cos, rope_sin, T, QKV + D,
+                           3 * D, ws.Vt, B, H, S, st));
+    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
+      HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
+    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
     if ((rc = stream_norm(i, 3, 4))) return rc;
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, p, "mlp1", Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0))) return rc;
-    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), p, "mlp2", ws.X, D, (int)D, EPI_GATE_RES, i, 5))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0))) return rc;
+    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5))) return rc;
   }
 
   // ---- single-stream blocks on the joint sequence -------------------------------------------------
   for (int i = 0; stage == 0 && i < d.num_single; ++i) {
-    const std::string p = "s" + std::to_string(i) + ".";
-    const float* qkn = W32(c, p + "qknorm");   // [q, k][128]
+    const SingleW& bw = c->sgl[i];
+    const float* qkn = bw.qkn;          // [q, k][128]
+    if ((rc = join_side(d.num_double + i))) return rc;
     if (c->ckpt)
       HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)(d.num_double + i) * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
@@ -433,30 +536,38 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     gb.nprob = 1;
     GemmProblem& f = gb.p[0];
     f = GemmProblem{};
-    f.A = ws.Xn; f.lda = D; f.W = W16(c, p + "fused.weight"); f.ldw = D; f.bias = W16(c, p + "fused.bias");
+    f.A = ws.Xn; f.lda = D; f.W = bw.fused.w; f.ldw = D; f.bias = bw.fused.b;
     f.C = ws.F; f.ldc = 7 * D; f.M = (int)R; f.N = (int)(7 * D); f.K = (int)D; f.epi = EPI_GELU; f.gelu_col0 = (int)(3 * D);
     if (c->fp8) {
       HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));
-      f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)WQ(c, p + "fused.weight_q"); f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = W32(c, p + "fused.wscale");
+      f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = bw.fused.wscale;
     }
+    gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
-    HIP_TRY(launch_qk_norm_rope2(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));   // k and q
-    HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
-    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128); HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st)); }
+    if (dbg_oldprep) {
+      HIP_TRY(launch_qk_norm_rope2(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));
+      HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
+    } else
+    HIP_TRY(launch_kv_prep(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, T, ws.F + D, 7 * D, ws.Vt, B,
+                           H, S, st));
+    { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
+      HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st)); }
     GemmBatch go{};
     go.nprob = 1;
     GemmProblem& o = go.p[0];
     o = GemmProblem{};
-    o.A = ws.F + 2 * D; o.lda = 7 * D; o.W = W16(c, p + "out.weight"); o.ldw = 5 * D; o.bias = W16(c, p + "out.bias");
+    o.A = ws.F + 2 * D; o.lda = 7 * D; o.W = bw.out.w; o.ldw = 5 * D; o.bias = bw.out.b;
     o.C = ws.X; o.ldc = D; o.M = (int)R; o.N = (int)D; o.K = (int)(5 * D); o.epi = EPI_GATE_RES;
     o.gate = ws.mod + ml.sgl(i, 2); o.ldg = ldm; o.rows_per_batch = S; o.res = ws.X; o.ldr = D;
     if (c->fp8) {
       HIP_TRY(launch_quant_rows_fp8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.qs, (int)R, (int)(5 * D), st));
-      o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)WQ(c, p + "out.weight_q"); o.fp8 = 1; o.a_scale = ws.qs;
-      o.w_scale = W32(c, p + "out.wscale");
+      o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)bw.out.wq; o.fp8 = 1; o.a_scale = ws.qs;
+      o.w_scale = bw.out.wscale;
     }
+    go.sk_slab = ws.sk_slab; go.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(go)); HIP_TRY(launch_gemm(go, st)); }
   }
+  if (stage == 0 && (rc = join_side(1 << 30))) return rc;      // short trunks: the head reads the norm_out rows
 
   // ---- norm_out (scale first) + velocity head on the image tokens --------------------------------------
   for (int b = 0; b < B; ++b)
@@ -674,10 +785,31 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
                              stream);
 }
 
+int64_t afx_linear_sk_ws_bytes(void) { return GEMM_SK_FLAG_BYTES + GEMM_SK_SLAB_BYTES; }
+
+static int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
+                       int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
+                       int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp,
+                       void* sk_ws, void* stream);
+
+int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
+                       int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
+                       int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, void* sk_ws, void* stream) {
+  if (!sk_ws || ((uintptr_t)sk_ws & 255) != 0) return fail(AFX_E_INVALID, "afx_linear_bf16_sk: sk_ws must be a 256-byte aligned device buffer");
+  return linear_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gelu_col0, gate, ldg, rows_per_batch, res, ldr, nullptr, 0, sk_ws, stream);
+}
+
 int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
                         int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
                         int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp,
                         void* stream) {
+  return linear_impl(A, lda, W, ldw, bias, C, ldc, M, N, K, epi, gelu_col0, gate, ldg, rows_per_batch, res, ldr, pre, ldp, nullptr, stream);
+}
+
+static int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
+                       int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,
+                       int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp,
+                       void* sk_ws, void* stream) {
   if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16");
   if (pre && ldp % 8) return fail(AFX_E_INVALID, "afx_linear_bf16_pre: ldp %% 8 == 0");
   if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 8)
@@ -693,6 +825,10 @@ int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, 
   p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
   p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
   p.pre = (const uint16_t*)pre; p.ldp = ldp;
+  if (sk_ws) {
+    gb.sk_flags = (uint32_t*)sk_ws;
+    gb.sk_slab = (float*)((char*)sk_ws + GEMM_SK_FLAG_BYTES);
+  }
   HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;
 }

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
   // ---- main loop -------------------------------------------------------------------------
   stage_tile(A, P.lda, m0, P.M, 0, smem, tid, wave);
   stage_tile(W, P.ldw, n0, P.N, 0, smem + TILE_BYTES, tid, wave);
-  __syncthreads();      // drains the DMA (vmcnt(0)) and releases the work-group
+  AFX_SYNC_DMA();       // drains the DMA (explicit vmcnt(0)) and releases the work-group
 
   const int frow = lane & 15, fq = lane >> 4;
   for (int kt = 0; kt < nk; ++kt) {
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_bf16_kernel(const GemmBa
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();    // next stage landed (vmcnt(0)) and every wave is done with this one
+    AFX_SYNC_DMA();     // next stage landed (explicit vmcnt(0)) and every wave is done with this one
   }
 
   // ---- epilogue: transpose through LDS, fused bias / activation / gated residual ------------
@@ -387,15 +387,89 @@ AFX_DEV void stage_half(const char* p0, const char* p1, int64_t kbyte, char* slo
 // (unit block scales; 2x the bf16 rate) covers the whole K-tile of a 16x16 output tile: the DMA / LDS / swizzle / phase code is
 // byte-for-byte the bf16 one, a phase is 8 MFMAs instead of 16.  The contraction order inside the instruction is free as
 // long as both operands agree, so lane (row, fq) simply feeds the two 16-byte chunks fq and 4 + fq it already reads.
+// ---- Stream-K tail (batch.sk_cus > 0) -----------------------------------------------------------------------------------
+// 216 / 648 / 864 tiles on 256 CUs leave the last "round" of a launch 84 % / 53 % / 38 % full.  With sk_cus = C CUs per XCD and
+// T = tiles / 8 tiles per XCD, every XCD runs its first full = floor(T / C) * C tiles as whole tiles (work-groups in dispatch
+// order, exactly as before) and splits the remaining rem = T - full tiles EVENLY over C more work-groups: the rem * nk K-tile
+// units are one linear range cut into C contiguous pieces, so a work-group computes (at most) the tail of one tile and the
+// head of the next.  The work-group that reaches a tile's last K-tile owns it (epilogue); a piece that stops short dumps its
+// raw fp32 accumulators (256 KB, lane-major: owner and helper share the lane <-> element map, no transposition) with 16-byte
+// write-through (sc1) stores into its slab and raises its flag; the owner polls the flags of the work-groups before it (one
+// lane, relaxed, s_sleep), ONE agent-scope acquire, adds the slabs and runs the normal epilogue.  Every work-group computes its
+// publishing piece FIRST, and an owner only ever waits for work-groups with a LOWER id: no cycle, no wait inside a publisher.
+// Hand-off protocol = cdna_hip_programming.md Guideline 16 R1 (sc1 payload, every wave drains vmcnt, one lane stores the flag,
+// consumer: relaxed poll -> one acquire -> __syncthreads -> loads); the consumer re-arms the flag (a slab has one reader).
+constexpr int SK_SLAB_FLOATS = BM * BN;
+constexpr unsigned SK_SPIN_LIMIT = 1u << 22;
+
+struct SkPiece { int nseg, tile, t0, n, role, g, s, j0, tot, nk; };
+
+// Piece ``sg`` (0 or 1) of this work-group: logical tile id, first K-tile, number of K-tiles (-1: the whole tile / split-K chunk),
+// role 0: whole tile, 1: owner of a tile whose head other work-groups computed, 2: publish a partial.  Pure scalar arithmetic
+// on blockIdx and kernel arguments.
+AFX_DEV SkPiece sk_piece(const GemmBatch& batch, int sg, int ES) {
+  SkPiece r{1, 0, 0, -1, 0, 0, 0, 0, 0, 0};
+  if (batch.sk_cus <= 0) {
+    r.tile = xcd_remap(blockIdx.x, gridDim.x);
+    return r;
+  }
+  const int xcd = blockIdx.x & 7, l = blockIdx.x >> 3;
+  const int T = batch.sk_tiles_per_xcd, full = batch.sk_full, C = batch.sk_cus;
+  if (l < full) {
+    r.tile = xcd * T + l;
+    return r;
+  }
+  r.s = l - full;
+  r.g = xcd * C + r.s;
+  r.nk = batch.p[0].K * ES / (BK * 2);               // the launcher guarantees one K for every problem of a stream-K launch
+  r.tot = (T - full) * r.nk;
+  const int u0 = (int)((int64_t)r.s * r.tot / C), u1 = (int)((int64_t)(r.s + 1) * r.tot / C);
+  r.j0 = u0 / r.nk;
+  const int it0 = u0 - r.j0 * r.nk;
+  const int tile_end = (r.j0 + 1) * r.nk;
+  const int base = xcd * T + full;
+  if (u1 <= tile_end) {                              // one piece
+    r.tile = base + r.j0; r.t0 = it0; r.n = u1 - u0;
+    r.role = u1 == tile_end ? (it0 > 0 ? 1 : 0) : 2;
+  } else {                                           // head of the next tile FIRST (published), then the owned tail
+    r.nseg = 2;
+    if (sg == 0) {
+      r.tile = base + r.j0 + 1; r.t0 = 0; r.n = u1 - tile_end; r.role = 2;
+    } else {
+      r.tile = base + r.j0; r.t0 = it0; r.n = tile_end - u0; r.role = it0 > 0 ? 1 : 0;
+    }
+  }
+  return r;
+}
+
 template <bool FP8>
 __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatch batch) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
+  constexpr int ES = FP8 ? 1 : 2;       // bytes per operand element
+
+  // ---- this work-group's pieces (decoded from blockIdx on demand: nothing but the piece index stays live across the main loop)
+  const int nseg = sk_piece(batch, 0, ES).nseg;
+
+#pragma unroll 1
+  for (int sg = 0; sg < nseg; ++sg) {
+  // Every lane constant is re-derived from an OPAQUE copy of threadIdx inside the piece loop: as loop invariants the compiler
+  // hoists ~60 of them (swizzle offsets, epilogue address pieces) in front of the loop and spills them around the main loop.
+  int tid_o = threadIdx.x;
+  asm volatile("" : "+v"(tid_o));
+  const int tid = tid_o;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
-
-  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int frow = lane & 15, fq = lane >> 4;
+  const int arow = wr * 64 + frow;      // + i*16
+  const int brow = wc * 32 + frow;      // + j*16
+  int role, wg;
+  int t0 = 0, nk = -1;
+  {
+    const SkPiece pc = sk_piece(batch, sg, ES);
+    wg = pc.tile; role = pc.role;
+    if (pc.n >= 0) { t0 = pc.t0; nk = pc.n; }
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
@@ -416,13 +490,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   const int tm = first_m + in_grp % gsz;
   const int tn = in_grp / gsz;
   const int m0 = tm * BM, n0 = tn * BN;
-  constexpr int ES = FP8 ? 1 : 2;       // bytes per operand element
-  int t0 = 0, nk = P.K * ES / (BK * 2);
-  if (P.split_k > 1) {
-    const int per = (nk + P.split_k - 1) / P.split_k;
-    t0 = chunk * per;
-    nk = min(per, nk - t0);
-    if (nk <= 0) return;                // (the launcher's chunking leaves no empty chunk; uniform, before any barrier)
+  if (nk < 0) {                         // whole tile or split-K chunk (stream-K pieces come with their own range)
+    nk = P.K * ES / (BK * 2);
+    if (P.split_k > 1) {
+      const int per = (nk + P.split_k - 1) / P.split_k;
+      t0 = chunk * per;
+      nk = min(per, nk - t0);
+      if (nk <= 0) return;              // (the launcher's chunking leaves no empty chunk; uniform, before any barrier)
+    }
   }
 #ifdef AFX_GEMM_TRACE
   unsigned tr[24];
@@ -478,9 +553,6 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   __builtin_amdgcn_s_barrier();         // ... and everybody else's
   if (wr == 1) __builtin_amdgcn_s_barrier();   // stagger: group 1 runs one barrier behind group 0
 
-  const int frow = lane & 15, fq = lane >> 4;
-  const int arow = wr * 64 + frow;      // + i*16
-  const int brow = wc * 32 + frow;      // + j*16
   bf16x8_t af[2][4], b0[2][2], b1[2][2];    // [kk][tile]
 
 #define AFX_MFMA_QUAD(MH, NH, BF)                                                                   \
@@ -557,6 +629,47 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   __syncthreads();
   AFX_TRC(20)
 
+  if (role == 2) {
+    // ---- publish the raw accumulators: slab[v][tid] 16-byte words, write-through, then this work-group's flag ----------
+    const int sk_g = sk_piece(batch, sg, ES).g;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(batch.sk_slab + (int64_t)sk_g * SK_SLAB_FLOATS, 0,
+                                                                 SK_SLAB_FLOATS * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs, ((i * 4 + j) * GEMM_THREADS + tid) * 16, 0, 16);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its own stores
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(batch.sk_flags + sk_g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    continue;
+  }
+  if (role == 1) {
+    // ---- add the partials of the work-groups that computed this tile's head: s-1, s-2, ... while their range reaches into it
+    const SkPiece pc = sk_piece(batch, sg, ES);
+    const int tile_u0 = pc.j0 * pc.nk, sk_tot = pc.tot, sk_s = pc.s, sk_g = pc.g;
+    for (int sp = sk_s - 1; sp >= 0 && (int)((int64_t)(sp + 1) * sk_tot / batch.sk_cus) > tile_u0; --sp) {
+      const int g = sk_g - sk_s + sp;
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(batch.sk_flags + g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < SK_SPIN_LIMIT)
+          __builtin_amdgcn_s_sleep(8);
+        if (spins >= SK_SPIN_LIMIT) __hip_atomic_store(batch.sk_flags + 8 * 64, 0xdeadu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(batch.sk_slab + (int64_t)g * SK_SLAB_FLOATS, 0, SK_SLAB_FLOATS * 4,
+                                                                   0x00020000);
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] += __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, ((i * 4 + j) * GEMM_THREADS + tid) * 16, 0, 0));
+      __syncthreads();                                    // every wave has its slab words (the adds above waited for them)
+      if (tid == 0) __hip_atomic_store(batch.sk_flags + g, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm for the next launch
+    }
+  }
+
   // ---- epilogue: straight from the (transposed) accumulators ------------------------------------
   epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq, chunk);
 #ifdef AFX_GEMM_TRACE
@@ -564,6 +677,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0)
     for (int i = 0; i < 22; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave][i] = tr[i];
 #endif
+  }   // pieces
 }
 
 LaunchTimer& launch_timer() {
@@ -600,6 +714,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (r != hipSuccess) return r;
   }
   batch.group_m = group_m;
+  batch.sk_cus = 0;
   int use = impl;
   bool conv = false;
   for (int i = 0; i < batch.nprob; ++i) conv = conv || batch.p[i].conv_cin_tiles > 0;
@@ -608,6 +723,31 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (batch.p[i].out_f32 == 3) use = 2;            // ... and so do split-K and the atomic epilogue
   bool fp8 = false;
   for (int i = 0; i < batch.nprob; ++i) fp8 = fp8 || batch.p[i].fp8 != 0;     // a launch is all-bf16 or all-fp8
+  // ---- stream-K tail: only with a caller-provided slab / flag workspace (the engine's), one K, plain bf16 / fp8 output tiles
+  static int sk_mode = -1, cus_per_xcd = 32;
+  if (sk_mode < 0) {
+    const char* e = getenv("AFX_GEMM_SK");               // 0: off
+    sk_mode = (e && e[0] == '0') ? 0 : 1;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
+      cus_per_xcd = prop.multiProcessorCount / 8;
+  }
+  if (sk_mode && use == 2 && !conv && batch.sk_slab != nullptr && batch.sk_flags != nullptr && total % 8 == 0 && cus_per_xcd <= 32) {
+    bool ok = true;
+    for (int i = 0; i < batch.nprob; ++i)
+      ok = ok && batch.p[i].out_f32 == 0 && batch.p[i].split_k == 1 && batch.p[i].K == batch.p[0].K && batch.p[i].fp8 == batch.p[0].fp8;
+    const int T = total / 8, C = cus_per_xcd;
+    const int full = T / C * C, rem = T - full;
+    const int nk = batch.p[0].K * (fp8 ? 1 : 2) / (BK * 2);
+    // worth it when the tail round is visibly under-filled and a piece keeps a useful number of K-tiles
+    if (ok && rem > 0 && rem * 8 <= C * 7 && (int64_t)rem * nk / C >= 6) {
+      batch.sk_cus = C;
+      batch.sk_tiles_per_xcd = T;
+      batch.sk_full = full;
+      total = 8 * (full + C);
+    }
+  }
   if (fp8 && launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(gemm_kernel_v2<true>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, launch_timer().start,
                           launch_timer().stop, 0, batch);

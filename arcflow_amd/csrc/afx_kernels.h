@@ -34,10 +34,17 @@ struct GemmBatch {
   int32_t nprob;
   int32_t total_tiles;
   int32_t group_m;     // tile-order super-row height (set by the launcher)
+  // stream-K tail (afx_gemm.hip): the caller lends a workspace -- sk_flags: 1024 zero-initialised uint32 (re-armed by the
+  // kernel), sk_slab: 256 x 256 KiB fp32 accumulator slabs; the launcher fills the three ints (sk_cus == 0: plain launch)
+  float* sk_slab;
+  uint32_t* sk_flags;
+  int32_t sk_cus, sk_tiles_per_xcd, sk_full;
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
+constexpr int64_t GEMM_SK_FLAG_BYTES = 4096;                       // 1024 flag words
+constexpr int64_t GEMM_SK_SLAB_BYTES = 256ll * 256 * 256 * 4;      // 256 work-groups x one fp32 256x256 tile
 
 // Optional per-launch timing without extra queue packets: when both are non-null, the NEXT launch_gemm / launch_attention issues
 // its kernel with hipExtLaunchKernelGGL(start, stop), which stamps the kernel's own begin / end on the events (the engine's
@@ -49,14 +56,13 @@ LaunchTimer& launch_timer();
 // vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)
 hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
                               hipStream_t stream);
-// qw_txt != nullptr: q is the RAW projection; RMSNorm(q) * w + RoPE are applied in the kernel's prologue (text rows: row % S < n_txt)
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream, float* lse = nullptr, const float* qw_txt = nullptr, const float* qw_img = nullptr,
-                            const float* cos_t = nullptr, const float* sin_t = nullptr, int n_txt = 0);
-// K <- RoPE(RMSNorm(K) w) in place and V -> V^T (key-permuted) in one launch
-hipError_t launch_kv_prep(uint16_t* k, int64_t ldk, const float* wk_txt, const float* wk_img, const float* cos_t, const float* sin_t,
-                          int n_txt, const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S, hipStream_t stream);
+                            hipStream_t stream, float* lse = nullptr);
+// K, Q <- RoPE(RMSNorm(.) w) in place (same row stride) and V -> V^T (key-permuted), one launch
+hipError_t launch_kv_prep(uint16_t* k, uint16_t* q, int64_t ldk, const float* wk_txt, const float* wk_img, const float* wq_txt,
+                          const float* wq_img, const float* cos_t, const float* sin_t, int n_txt, const uint16_t* v, int64_t ldv,
+                          uint16_t* vt, int B, int H, int S, hipStream_t stream);
 // text encoders: runtime scale, causal mask, additive bias table [H][2S-1] (pre-divided by scale), grouped KV heads, d 64|128
 hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
                                 uint16_t* vt_ws, uint16_t* o, int64_t ldo, int B, int H, int Hkv, int S, int head_dim, float scale,

@@ -29,10 +29,12 @@ def _cuda(t: torch.Tensor, dtype) -> torch.Tensor:
 
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: str = 'none',
            gelu_col0: int = 0, gate: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-           rows_per_batch: int = 0, out: Optional[torch.Tensor] = None, pre: Optional[torch.Tensor] = None) -> torch.Tensor:
+           rows_per_batch: int = 0, out: Optional[torch.Tensor] = None, pre: Optional[torch.Tensor] = None,
+           sk_ws: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = epi(a @ w.T + bias + pre); a [M,K] (last-dim contiguous, may be a strided view), w [N,K] bf16.
     epilogue: 'none' | 'gelu' (tanh, on columns >= gelu_col0) | 'gate_res' (residual + gate[b] * (.)).
-    pre [M,N] bf16 is added before the activation / gate (LoRA-dropout correction)."""
+    pre [M,N] bf16 is added before the activation / gate (LoRA-dropout correction).
+    sk_ws: a ``stream_k_workspace()`` buffer -> the launch may split its under-filled last round stream-K style."""
     lib = _lib.load()
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.stride(-1) == 1 and w.stride(-1) == 1
     M, K = a.shape
@@ -45,11 +47,23 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
         if gate.dim() == 1:
             gate = gate[None]
     rpb = rows_per_batch if rows_per_batch > 0 else max(M, 1)
+    if sk_ws is not None:
+        assert pre is None
+        _lib.check(lib.afx_linear_bf16_sk(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                          epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
+                                          _p(residual), 0 if residual is None else residual.stride(0), _p(sk_ws), _s()))
+        return out
     _lib.check(lib.afx_linear_bf16_pre(_p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                        epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
                                        _p(residual), 0 if residual is None else residual.stride(0),
                                        _p(pre), 0 if pre is None else pre.stride(0), _s()))
     return out
+
+
+def stream_k_workspace(device='cuda') -> torch.Tensor:
+    """Zero-initialised workspace for ``linear(..., sk_ws=)`` (hand-off flags + fp32 accumulator slabs of the stream-K tail)."""
+    lib = _lib.load()
+    return torch.zeros(lib.afx_linear_sk_ws_bytes(), dtype=torch.uint8, device=device)
 
 
 def lora_dropout(src: torch.Tensor, p: float, seed: int, row0: int = 0, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -327,6 +327,15 @@ int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, 
                         void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                         int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
                         int32_t rows_per_batch, const void* res, int64_t ldr, const void* pre, int64_t ldp, void* stream);
+/* afx_linear_bf16 with a caller-lent workspace for the stream-K tail of the 8-phase GEMM (the MMDiT engine lends a region of its
+ * own workspace to every block GEMM; this entry point exists for the parity tests and micro benches): sk_ws holds
+ * afx_linear_sk_ws_bytes() bytes, 256-byte aligned, whose first 4096 bytes were zeroed ONCE by the caller (hand-off flags; the
+ * kernel re-arms them).  When the launch's tile count does not leave an under-filled last round the call is a plain GEMM. */
+int64_t afx_linear_sk_ws_bytes(void);
+int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                       void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                       int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
+                       int32_t rows_per_batch, const void* res, int64_t ldr, void* sk_ws, void* stream);
 /* LoRA input dropout masks from a counter-based hash of (seed, row0 + row, col), keep probability 1 - p, delta = keep/(1-p) - 1:
  * mode 0: dst = src * delta;  1: dst = src * (1 + delta) (= dropout(src));  2: dst += src * delta */
 int afx_lora_dropout_bf16(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t N, int64_t row0, float p,

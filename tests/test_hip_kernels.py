@@ -284,3 +284,43 @@ def test_fp8_quant_and_linear():
     assert rel(ops.linear_fp8(aq, asc, wq, wsc, b, epilogue='gate_res', gate=gate, residual=r), r.float() + gate * (exact + b.float())) < 4e-3
     # and the quantisation error itself against the bf16 product stays at the e4m3 level
     assert rel(ops.linear_fp8(aq, asc, wq, wsc), a.float() @ w.float().t()) < 6e-2
+
+
+# ------------------------------------------------------------------------------------------ stream-K tail of the GEMM
+@pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 3072, 15360), (4608, 9216, 3072), (4608, 12288, 3072),
+                                   (2048, 1024, 512), (4608, 21504, 3072)])
+def test_linear_stream_k_tail(ops, M, N, K):
+    """The FLUX block GEMM shapes whose last round is under-filled (216 / 648 / 864 tiles on 256 CUs) with the stream-K tail
+    on: against fp32 math on the device AND against the plain launch (same products, only the order of the fp32 partial sums
+    differs).  Run twice on one workspace: the hand-off flags must be re-armed by the kernel."""
+    g = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device='cuda').bfloat16()
+    w = (torch.randn(N, K, generator=g, device='cuda') * 0.03).bfloat16()
+    b = torch.randn(N, generator=g, device='cuda').bfloat16()
+    ws = ops.stream_k_workspace()
+    plain = ops.linear(a, w, b, epilogue='gelu', gelu_col0=N // 2)
+    ref = a.float() @ w.float().t() + b.float()
+    ref[:, N // 2:] = torch.nn.functional.gelu(ref[:, N // 2:], approximate='tanh')
+    for rep in range(2):
+        out = ops.linear(a, w, b, epilogue='gelu', gelu_col0=N // 2, sk_ws=ws)
+        torch.cuda.synchronize()
+        assert rel_l2(out, ref) < 4e-3, rep
+        assert rel_l2(out, plain) < 1e-3, rep
+        assert (out.float() - plain.float()).abs().max().item() < 0.05 * plain.float().abs().max().item()
+    flags = ws[:4096].view(torch.int32)
+    assert int(flags.abs().sum()) == 0, 'hand-off flags not re-armed / timeout word set'
+
+
+def test_linear_stream_k_gate_residual_inplace(ops):
+    """mlp2 / proj_out form: C = res + gate * (A W^T + b) written over the residual, long K (the owner adds 1-2 partial slabs)."""
+    g = torch.Generator(device='cuda').manual_seed(77)
+    M, N, K = 4608, 3072, 12288
+    a = torch.randn(M, K, generator=g, device='cuda').bfloat16()
+    w = (torch.randn(N, K, generator=g, device='cuda') * 0.02).bfloat16()
+    b = torch.randn(N, generator=g, device='cuda').bfloat16()
+    gate = torch.randn(1, N, generator=g, device='cuda')
+    x = torch.randn(M, N, generator=g, device='cuda').bfloat16()
+    ref = x.float() + gate * (a.float() @ w.float().t() + b.float())
+    ws = ops.stream_k_workspace()
+    out = ops.linear(a, w, b, epilogue='gate_res', gate=gate, residual=x, rows_per_batch=M, out=x, sk_ws=ws)
+    assert rel_l2(out, ref) < 4e-3

@@ -34,9 +34,12 @@ def gemm():
         w = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()
         b = torch.randn(N, device='cuda').bfloat16()
         out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        ws = ops.stream_k_workspace()
         dt = timeit(lambda: ops.linear(a, w, b, out=out))
+        dk = timeit(lambda: ops.linear(a, w, b, out=out, sk_ws=ws))
         ref = timeit(lambda: torch.nn.functional.linear(a, w, b))
-        print(f'M={M:5d} N={N:5d} K={K:5d}  {dt*1e6:9.1f} us  {2*M*N*K/dt/1e12:7.1f} TF   (torch/hipBLASLt {2*M*N*K/ref/1e12:7.1f} TF)')
+        print(f'M={M:5d} N={N:5d} K={K:5d}  plain {dt*1e6:8.1f} us {2*M*N*K/dt/1e12:7.1f} TF | stream-K tail {dk*1e6:8.1f} us {2*M*N*K/dk/1e12:7.1f} TF'
+              f'   (torch/hipBLASLt {2*M*N*K/ref/1e12:7.1f} TF)')
 
 
 def gemm8():
