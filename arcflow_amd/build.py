@@ -48,6 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
     flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+    flags += os.environ.get('AFX_EXTRA_FLAGS', '').split()          # e.g. -DAFX_ATTN_TRACE for tools/attn_trace.py
     objs = []
     procs = []
     for src in SOURCES:

@@ -428,12 +428,328 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   }
 }
 
+
+// =================================================================================================================================
+// 8-wave "ping-pong" flash attention (head dim 128, no mask) -- EXPERIMENTAL, opt-in with AFX_ATTN_IMPL=2.
+// Status (r02, S = 4608, H = 24, tools/attn_trace.py stamps of one iteration): correct and race-free (same tests as the 4-wave
+// kernel), 372 us vs 335 us for the 4-wave kernel.  Per wave and tile: 16 + 16 MFMAs issue in 770 + 690 cycles (45 per MFMA, not
+// 32: the partner's v_exp / VALU issues block the shared issue port), the softmax takes 1300-1470 cycles beside the partner's
+// MFMAs, the V^T reads + DMA issue of the group that reaches the barrier last another 700-900: a half step lasts ~2030 cycles
+// where the matrix pipe needs 1024.  What it would take: hand-placed VALU fillers inside the MFMA gaps (<= 5 issues per gap,
+// MI355X_MICROARCH "one wave per SIMD") instead of two compiler-scheduled streams arbitrating for one issue port.
+//
+// Same per-wave mathematics and operand layouts as attention_kernel above (S^T = K Q^T and O^T = V^T P^T on the 32x32x16 MFMA,
+// lane-local softmax rows, key-permuted V^T), but ONE work-group of 8 waves x 32 queries per CU instead of two independent
+// 4-wave work-groups: the two wave groups of a SIMD run the SAME loop half a KV tile apart, so that one issues its 32 MFMAs of a
+// tile (O^T += V^T P^T of tile t-1, then S^T of tile t: 1024 matrix-pipe cycles) exactly while its partner does the online softmax
+// of its own tile (~1000 VALU cycles, 32 v_exp) -- the matrix pipe and the VALU of every SIMD are both busy all the time instead
+// of whenever two unsynchronised work-groups happen to be out of phase (measured: the 4-wave kernel keeps the matrix pipe 50 %
+// busy at best).  One raw s_barrier per half step keeps the stagger; group 1 enters the loop one barrier late.
+//   M(t):  ds_read K(t) fragments | 16 MFMA  O^T += V^T(t-1) P^T(t-1) | 16 MFMA  S^T = K(t) Q^T | ds_read V^T(t) fragments
+//   S(t):  LDS-DMA of tile t+3 | mask / max / exp2 / row sum -> P^T(t) | counted wait
+// K / V^T tiles are shared by all 8 waves (half the L2 -> LDS traffic per query of the 4-wave kernel) and live in a 4-slot LDS
+// ring (4 x 32 KiB): the DMA of tile t+3 is issued in S(t) and must have landed before M(t+3) -- 2.5 tile times later, against
+// 1.0 with the two-slot ring.  Waits are counted and explicit (never __syncthreads(), see AFX_SYNC_DMA): at the end of S(t)
+// s_waitcnt vmcnt(4) leaves only tile t+3 in flight, so when group 0 enters M(t+1) group 1 (whose last check was S(t-1)) has
+// confirmed tiles <= t+1 and group 0 tiles <= t+2.  A slot is refilled one barrier after its last reader's ds_reads retired
+// (lgkmcnt(0) before every barrier).  Past the last tile the DMA re-fetches tile ntiles-1 into a free slot: the count per
+// iteration stays 4 ops per lane.
+constexpr int PP_WAVES = 8;
+constexpr int PP_THREADS = PP_WAVES * 64;
+constexpr int PP_QB = PP_WAVES * QW;                 // 256 queries per work-group
+constexpr int PP_SLOT_BYTES = 2 * KVB * 128 * 2;     // K tile [64][128] | V^T tile [128][64]
+constexpr int PP_SLOTS = 4;
+constexpr int PP_LDS_BYTES = PP_SLOTS * PP_SLOT_BYTES;
+
+#ifndef AFX_PP_PRIO
+#define AFX_PP_PRIO 1
+#endif
+#if AFX_PP_PRIO
+#define PP_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PP_PRIO(x)
+#endif
+__global__ __launch_bounds__(PP_THREADS, 2) void attention_pp_kernel(
+    const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
+    const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int64_t ldo, int H, int S, int S_pad, int nq, int B,
+    float* __restrict__ lse, unsigned* __restrict__ trace) {
+  constexpr int HD = 128, KS = 8, DT = 4, KROW = 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef AFX_ATTN_TRACE
+  unsigned tr[12];
+#define PP_TR(i) if (t == 36) tr[i] = (unsigned)__builtin_readcyclecounter();
+#else
+#define PP_TR(i)
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave_u >> 2;
+  const int ql = lane & 31, hi = lane >> 5;
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int per_head = nq * B;
+  const int h = xcd + 8 * (slot_id / per_head);
+  if (h >= H) return;
+  const int rem = slot_id % per_head;
+  const int b = rem / nq;
+  const int q0 = (rem % nq) * PP_QB + wave_u * QW;
+  const int qrow = min(q0 + ql, S - 1);
+  const int ntiles = S_pad / KVB;
+
+  const bf16_t* qp = q + ((int64_t)b * S + qrow) * ldq + h * HD;
+  const bf16_t* kbase = k + (int64_t)b * S * ldk + h * HD;
+  const bf16_t* vbase = vt + ((int64_t)(b * H + h) * HD) * S_pad;
+
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const bf16x8_t*>(qp + s * 16 + hi * 8);
+
+  // per-lane DMA offsets: K chunk p = i*512 + tid -> row tid/16 + 32 i, physical chunk tid%16 (swizzle chunk ^ (row & 15));
+  //                       V^T chunk p = i*512 + tid -> row tid/8 + 64 i, physical chunk tid%8 (swizzle chunk ^ ((row >> 1) & 7))
+  const int r0 = tid >> 4, cp = tid & 15;
+  const int kswz = (cp ^ (r0 & 15)) << 3;
+  const int d0 = tid >> 3, vp = tid & 7;
+  const int vswz = (vp ^ ((d0 >> 1) & 7)) << 3;
+  uint32_t koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    koff[i] = (uint32_t)(((int64_t)(r0 + 32 * i) * ldk + kswz) * 2);
+    voff[i] = (uint32_t)(((int64_t)(d0 + 64 * i) * S_pad + vswz) * 2);
+  }
+  const bool ragged = S_pad != S;
+  auto stage_tile = [&](int t, int slot) {
+    t = t < ntiles ? t : ntiles - 1;
+    const int kv0 = t * KVB;
+    char* kd = smem + slot * PP_SLOT_BYTES;
+    char* vd = kd + KVB * HD * 2;
+    const char* kt = reinterpret_cast<const char*>(kbase) + (int64_t)kv0 * ldk * 2;     // uniform
+    const char* vt_ = reinterpret_cast<const char*>(vbase) + (int64_t)kv0 * 2;
+    if (ragged && t == ntiles - 1) {                 // keys past the end: clamp the row (never read unmasked)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int kr = min(kv0 + r0 + 32 * i, S - 1);
+        const bf16_t* ksrc = kbase + (int64_t)kr * ldk + kswz;
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)ksrc, (lds_void_t*)(kd + (i * PP_THREADS + wave_u * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * PP_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(kt + koff[i]), (lds_void_t*)(kd + (i * PP_THREADS + wave_u * 64) * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * PP_THREADS + wave_u * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  stage_tile(0, 0);
+  stage_tile(1, 1);
+  stage_tile(2, 2);
+  // the Q fragments (8 oldest VMEM ops) are pinned as landed here; the three tiles stay in flight
+#pragma unroll
+  for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(qf[s]));
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");        // tiles 0 and 1 (this wave's pieces)
+  __builtin_amdgcn_s_barrier();                            // ... and everybody else's
+  if (grp == 1) __builtin_amdgcn_s_barrier();              // group 1 runs half a tile behind group 0
+
+  f32x16_t oacc[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+  bf16x8_t kf0[KS], kf1[KS], vf[DT][4], pf[4];
+  {
+    const u32x4_t z = (u32x4_t){0u, 0u, 0u, 0u};           // M(0) multiplies a zero P^T with a zero V^T: no branch in the loop
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      pf[g] = __builtin_bit_cast(bf16x8_t, z);
+#pragma unroll
+      for (int d = 0; d < DT; ++d) vf[d][g] = __builtin_bit_cast(bf16x8_t, z);
+    }
+  }
+  const int krow1 = 32 + ql;
+  const int sw0 = ql & 15, sw1 = krow1 & 15;
+
+  for (int t = 0; t < ntiles; ++t) {
+    const char* ks = smem + (t & 3) * PP_SLOT_BYTES;
+    const char* vs = ks + KVB * HD * 2;
+    // ================================ M(t) ================================
+    PP_TR(0)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf0[s] = *reinterpret_cast<const bf16x8_t*>(ks + ql * KROW + (((s * 2 + hi) ^ sw0) << 4));
+    __builtin_amdgcn_sched_barrier(0);
+    PP_PRIO(1);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][g], pf[g], oacc[d], 0, 0, 0);
+    PP_PRIO(0);
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(1)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) kf1[s] = *reinterpret_cast<const bf16x8_t*>(ks + krow1 * KROW + (((s * 2 + hi) ^ sw1) << 4));
+    f32x16_t sacc[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+    PP_PRIO(1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {      // the two accumulator chains interleaved: a dependent 32x32 MFMA issues every ~44 cycles, an independent one every 32
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[s], qf[s], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[s], qf[s], sacc[1], 0, 0, 0);
+    }
+    PP_PRIO(0);
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(2)
+    // V^T(t) fragments for the NEXT M step: issued here, behind the MFMAs (the matrix pipe drains its queue meanwhile), they
+    // complete under this wave's softmax; the registers were released by O^T += V^T P^T(t-1) at the top of this step
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      const int vrow = d * 32 + ql;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        vf[d][g] = *reinterpret_cast<const bf16x8_t*>(vs + vrow * 128 + (((g * 2 + hi) ^ ((vrow >> 1) & 7)) << 4));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(3)
+    // ================================ S(t) ================================
+    stage_tile(t + 3, (t + 3) & 3);                        // slot of tile t-1: its last readers retired their ds_reads before the barrier above
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(4)
+    if (t == ntiles - 1 && ragged) {
+      asm volatile("" ::: "memory");       // keep this a wave-uniform BRANCH
+      const int kv0 = t * KVB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kv0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= S) sacc[kb][r] = -INFINITY;
+        }
+    }
+    float mt = sacc[0][0];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sacc[kb][r]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float m_new = fmaxf(m_run, mt);
+    if (__any((m_new - m_run) * c > RESCALE_LOG2)) {       // deferred rescale, as in attention_kernel
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
+    }
+    const float mc = m_run * c;
+    float psum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float pv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        pv[j] = __builtin_amdgcn_exp2f(sacc[g >> 1][(g & 1) * 8 + j] * c - mc);
+        psum += pv[j];
+      }
+      const u32x4_t w = pack8(pv);
+      pf[g] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    l_run += psum;
+    // Pin P^T and the row sum as COMPUTED here: they are only consumed by the next M step, and without an opaque use the
+    // compiler sinks all 32 v_exp + the packing below the barrier -- into the partner's VALU half step (measured: the M
+    // half step then lasts 2190 cycles instead of 1330 and the ping-pong degenerates).
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(pf[g]));
+    asm volatile("" : "+v"(l_run));
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(5)
+    asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");   // only tile t+3 may still be in flight; the V^T reads retired
+    PP_TR(6)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    PP_TR(7)
+  }
+#ifdef AFX_ATTN_TRACE
+  if (trace != nullptr && (blockIdx.x == 0 || blockIdx.x == 1000) && lane == 0)
+    for (int i = 0; i < 8; ++i) trace[((blockIdx.x ? 1 : 0) * 8 + wave_u) * 8 + i] = tr[i];
+#endif
+  if (grp == 0) __builtin_amdgcn_s_barrier();              // pairs with group 1's extra barrier in front of the loop
+  // ---- the last tile's O^T += V^T P^T, drain the re-fetches of the last tile ----
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[d][g], pf[g], oacc[d], 0, 0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  if (lse != nullptr && hi == 0 && q0 + ql < S) lse[((int64_t)b * H + h) * S_pad + q0 + ql] = m_run * c + __log2f(l_tot);
+  if (q0 + ql < S) {
+    bf16_t* op = o + ((int64_t)b * S + q0 + ql) * ldo + h * HD;
+#pragma unroll
+    for (int d = 0; d < DT; ++d)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x2_t w;
+        w[0] = pack_bf16x2(oacc[d][4 * g + 0] * inv, oacc[d][4 * g + 1] * inv);
+        w[1] = pack_bf16x2(oacc[d][4 * g + 2] * inv, oacc[d][4 * g + 3] * inv);
+        *reinterpret_cast<u32x2_t*>(op + d * 32 + g * 8 + hi * 4) = w;
+      }
+  }
+}
+
+// cycle stamps of one iteration of two work-groups (builds with -DAFX_ATTN_TRACE only: tools/attn_trace.py)
+static unsigned* pp_trace_buffer() {
+#ifdef AFX_ATTN_TRACE
+  static unsigned* buf = nullptr;
+  if (!buf && hipMalloc(&buf, 2 * 8 * 8 * sizeof(unsigned)) != hipSuccess) buf = nullptr;
+  return buf;
+#else
+  return nullptr;
+#endif
+}
+extern "C" int afx_debug_attn_trace(unsigned* host_out) {
+#ifdef AFX_ATTN_TRACE
+  unsigned* b = pp_trace_buffer();
+  if (!b) return -1;
+  return hipMemcpy(host_out, b, 2 * 8 * 8 * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+#else
+  (void)host_out;
+  return -1;
+#endif
+}
+
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
                             hipStream_t stream, float* lse) {
   const int S_pad = (int)attn_spad(S);
-  const int nq = (S + QB - 1) / QB;
   const int heads_per_xcd = (H + 7) / 8;
+  static int impl = -1;
+  if (impl < 0) {
+    const char* e = getenv("AFX_ATTN_IMPL");               // 2: the 8-wave ping-pong kernel (experimental, see its header), default: 4-wave
+    impl = (e && e[0] == '2') ? 2 : 1;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
+    if (r != hipSuccess) return r;
+  }
+  if (impl == 2 && S >= 2 * PP_QB) {
+    const int nq8 = (S + PP_QB - 1) / PP_QB;
+    dim3 grid8(8 * heads_per_xcd * nq8 * B);
+    if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+      hipExtLaunchKernelGGL(attention_pp_kernel, grid8, dim3(PP_THREADS), PP_LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0, q,
+                            ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq8, B, lse, (unsigned*)nullptr);
+    else
+      hipLaunchKernelGGL(attention_pp_kernel, grid8, dim3(PP_THREADS), PP_LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nq8, B, lse,
+                         pp_trace_buffer());
+    return hipGetLastError();
+  }
+  const int nq = (S + QB - 1) / QB;
   dim3 grid(8 * heads_per_xcd * nq * B);
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL((attention_kernel<128, false>), grid, dim3(ATT_THREADS), 0, stream, launch_timer().start, launch_timer().stop,

@@ -828,6 +828,7 @@ static int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, c
   if (sk_ws) {
     gb.sk_flags = (uint32_t*)sk_ws;
     gb.sk_slab = (float*)((char*)sk_ws + GEMM_SK_FLAG_BYTES);
+    gb.sk_force = 1;
   }
   HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;

@@ -726,8 +726,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   // ---- stream-K tail: only with a caller-provided slab / flag workspace (the engine's), one K, plain bf16 / fp8 output tiles
   static int sk_mode = -1, cus_per_xcd = 32;
   if (sk_mode < 0) {
-    const char* e = getenv("AFX_GEMM_SK");               // 0: off
-    sk_mode = (e && e[0] == '0') ? 0 : 1;
+    const char* e = getenv("AFX_GEMM_SK");               // 0: off, 1: launches with >= 1 full round (default), 2: every eligible launch
+    sk_mode = e ? atoi(e) : 1;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
@@ -740,8 +740,11 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     const int T = total / 8, C = cus_per_xcd;
     const int full = T / C * C, rem = T - full;
     const int nk = batch.p[0].K * (fp8 ? 1 : 2) / (BK * 2);
-    // worth it when the tail round is visibly under-filled and a piece keeps a useful number of K-tiles
-    if (ok && rem > 0 && rem * 8 <= C * 7 && (int64_t)rem * nk / C >= 6) {
+    // Worth it when the tail round is visibly under-filled and a piece keeps a useful number of K-tiles.  Launches that are ONE
+    // under-filled round (216 tiles: full == 0) split EVERY tile: 256 partial slabs = 64 MB written through + read back per
+    // launch, which costs what the 16 % tail would win (r02d: 4608x3072xK, K = 3072 / 12288 / 15360: -10 % / -3 % / -1.5 %);
+    // launches with full rounds in front split only the remainder tiles (N = 9216: +6 %, N = 12288: +3 %).
+    if (ok && rem > 0 && rem * 8 <= C * 7 && (int64_t)rem * nk / C >= 6 && (full > 0 || sk_mode >= 2 || batch.sk_force)) {
       batch.sk_cus = C;
       batch.sk_tiles_per_xcd = T;
       batch.sk_full = full;

@@ -39,6 +39,7 @@ struct GemmBatch {
   float* sk_slab;
   uint32_t* sk_flags;
   int32_t sk_cus, sk_tiles_per_xcd, sk_full;
+  int32_t sk_force;    // caller asks for the stream-K tail on every eligible launch (parity tests / micro benches), not only where it pays
   GemmProblem p[GEMM_MAX_PROBLEMS];
 };
 
