@@ -131,7 +131,7 @@ class _PipelineBase(ArcFlowLoaderMixin):
             t_src = ts_host[tid]
             sigma_src = t_src / ntt
             self._current_timestep = t_src
-            out = fwd(latents.to(torch.bfloat16), torch.full((latents.shape[0],), t_src / 1000.0, device=device))
+            out = fwd(latents.to(torch.bfloat16), torch.full((latents.shape[0],), t_src / 1000.0, device=device), prompt_embeds)
             tid += per_step[i]
             sigma_end = (ts_host[tid] / ntt) if tid < len(ts_host) else 0.0
             latents = ops.arcflow_step(latents, out.means, out.logweights, out.loggammas,
@@ -141,6 +141,8 @@ class _PipelineBase(ArcFlowLoaderMixin):
                 cb = callback_on_step_end(self, i, torch.tensor(t_src, device=device),
                                           {k: local[k] for k in callback_on_step_end_tensor_inputs})
                 latents = cb.pop('latents', latents)
+                # the reference also takes back a modified conditioning (arcflux_pipeline.py:519 pops "prompt_embeds")
+                prompt_embeds = cb.pop('prompt_embeds', prompt_embeds)
         self._current_timestep = None
         return latents
 
@@ -296,8 +298,8 @@ class ArcFluxPipeline(_PipelineBase):
         guidance = torch.full((B,), guidance_scale, device=device, dtype=torch.float32) \
             if self.transformer.guidance_embeds else None
 
-        def fwd(x, t):
-            return self.transformer(x, t, prompt_embeds, pooled, guidance, hp, wp)
+        def fwd(x, t, pe):
+            return self.transformer(x, t, pe.to(device, torch.bfloat16), pooled, guidance, hp, wp)
         latents = self._denoise(latents, hp, wp, num_inference_steps, total_substeps, timestep_ratio, fwd,
                                 callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds)
         if output_type == 'latent':

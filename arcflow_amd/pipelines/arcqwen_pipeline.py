@@ -136,8 +136,8 @@ class ArcQwenImagePipeline(_PipelineBase):
         B = prompt_embeds.shape[0]
         latents, hp, wp = self._prepare_latents(B, height, width, generator, latents)
 
-        def fwd(x, t):
-            return self.transformer(x, t, prompt_embeds, None, None, hp, wp)
+        def fwd(x, t, pe):
+            return self.transformer(x, t, pe.to(device, torch.bfloat16), None, None, hp, wp)
         latents = self._denoise(latents, hp, wp, num_inference_steps, total_substeps, timestep_ratio, fwd,
                                 callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds)
         if output_type == 'latent':

@@ -84,7 +84,8 @@ def distill_setup(cfg: Dict[str, Any]) -> Tuple[str, Dict[str, Any], DistillConf
         window_substeps=tc.get('window_substeps', 3), gm_dropout=tc.get('gm_dropout', 0.0),
         num_intermediate_states=tc.get('num_intermediate_states', 4), num_decay_iters=tc.get('num_decay_iters', 2000),
         shift=sampler.get('shift', 3.2), loss_scale=loss.get('rescale_cfg', {}).get('scale', 1.0),
-        guidance=tc.get('distilled_guidance_scale', 3.5), teacher_guidance_scale=tc.get('teacher_guidance_scale', 1.0),
+        guidance=tc.get('distilled_guidance_scale', 3.5), teacher_guidance=tc.get('teacher_distilled_guidance_scale'),
+        teacher_guidance_scale=tc.get('teacher_guidance_scale', 1.0),
         lr=opt.get('lr', 1e-4), betas=tuple(opt.get('betas', (0.9, 0.999))), weight_decay=opt.get('weight_decay', 0.0),
         loggamma_lr_mult=mults.get('proj_out_loggamma', {}).get('lr_mult', 1.0),
         warmup_iters=lr_cfg.get('warmup_iters', 0), warmup_ratio=lr_cfg.get('warmup_ratio', 1.0),

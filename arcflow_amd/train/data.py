@@ -122,13 +122,41 @@ class PromptEmbedCache:
               'pooled_prompt_embeds': 'pooled_projections', 'prompt_embeds_mask': 'encoder_hidden_states_mask'}     # :86-91
 
     def __init__(self, cache_dir: str, datalist: Optional[Sequence[str]] = None, pad_seq_len: Optional[int] = None,
-                 latent_size=(16, 128, 128), bucketize: bool = False):
+                 latent_size=(16, 128, 128), bucketize: bool = False, negative_prompt_embeds_path: Optional[str] = None,
+                 size_index: Optional[str] = None):
+        """negative_prompt_embeds_path: a torch.load-able dict of the NEGATIVE prompt's embeddings (same keys / legacy keys as an
+        item), attached to every item as ``negative_prompt_embed_kwargs`` -- the reference's option of the same name
+        (image_prompts.py:57-60,158-163,432), needed whenever the teacher runs true classifier-free guidance (Qwen config).
+        size_index: JSON file {file name: [C, H, W]} with the latent size of every item.  ``bucketize`` needs the sizes up front;
+        without an index it unpickles every cache file once (fine for thousands of items, hours for the reference's 3 M) and
+        writes ``latent_sizes.json`` next to the cache so the next start is instant."""
         self.cache_dir, self.pad_seq_len, self.latent_size = cache_dir, pad_seq_len, tuple(latent_size)
         if datalist is None:
             datalist = sorted(f for f in os.listdir(cache_dir) if f.endswith(('.zst', '.pkl', '.pt')))
         self.files = list(datalist)
+        self.negative_prompt_embed_kwargs = None
+        if negative_prompt_embeds_path is not None:
+            self.negative_prompt_embed_kwargs = self._parse(_load_item(negative_prompt_embeds_path), pad=False)
         if bucketize:          # one bucket per latent size: batches never mix resolutions
-            sizes = [tuple(_load_item(os.path.join(cache_dir, f)).get('latent_size', self.latent_size)) for f in self.files]
+            index_path = size_index or os.path.join(cache_dir, 'latent_sizes.json')
+            known = {}
+            if os.path.exists(index_path):
+                import json
+                with open(index_path) as f:
+                    known = {k: tuple(v) for k, v in json.load(f).items()}
+            sizes, scanned = [], False
+            for fn in self.files:
+                if fn not in known:
+                    known[fn] = tuple(_load_item(os.path.join(cache_dir, fn)).get('latent_size', self.latent_size))
+                    scanned = True
+                sizes.append(known[fn])
+            if scanned and size_index is None:
+                try:
+                    import json
+                    with open(index_path, 'w') as f:
+                        json.dump({k: list(v) for k, v in known.items()}, f)
+                except OSError:
+                    pass               # read-only cache directory: scan again next time
             order = {s: i for i, s in enumerate(sorted(set(sizes)))}
             self.bucket_ids = [order[s] for s in sizes]
 
@@ -142,22 +170,33 @@ class PromptEmbedCache:
             return x[:self.pad_seq_len]
         return torch.cat([x, x.new_zeros((self.pad_seq_len - x.size(0),) + tuple(x.shape[1:]))], dim=0)
 
-    def __getitem__(self, i: int) -> dict:
-        raw = _load_item(os.path.join(self.cache_dir, self.files[i]))
+    def _parse(self, raw: dict, pad: bool = True) -> dict:
+        """parse_prompt_embeds (image_prompts.py:286-309): legacy key names, the optional int8 scale, padding."""
         kw = dict(raw.get('prompt_embed_kwargs', {}))
         for old, new in self.LEGACY.items():
             if old in raw and new not in kw:
                 kw[new] = raw[old]
+        for new in self.LEGACY.values():
+            if new in raw and new not in kw:
+                kw[new] = raw[new]
         scale = kw.pop('encoder_hidden_states_scale', None)
+        padf = self._pad if pad else (lambda x: x)
         if 'encoder_hidden_states' in kw:
             e = kw['encoder_hidden_states'].float()
-            kw['encoder_hidden_states'] = self._pad(e * scale if scale is not None else e)
+            kw['encoder_hidden_states'] = padf(e * scale if scale is not None else e)
         if 'pooled_projections' in kw:
             kw['pooled_projections'] = kw['pooled_projections'].float()
         if 'encoder_hidden_states_mask' in kw:
-            kw['encoder_hidden_states_mask'] = self._pad(kw['encoder_hidden_states_mask'])
-        return dict(ids=i, name=raw.get('prompt', ''), prompt_embed_kwargs=kw,
+            kw['encoder_hidden_states_mask'] = padf(kw['encoder_hidden_states_mask'])
+        return kw
+
+    def __getitem__(self, i: int) -> dict:
+        raw = _load_item(os.path.join(self.cache_dir, self.files[i]))
+        item = dict(ids=i, name=raw.get('prompt', ''), prompt_embed_kwargs=self._parse(raw),
                     latent_size=tuple(raw.get('latent_size', self.latent_size)))
+        if self.negative_prompt_embed_kwargs is not None:
+            item['negative_prompt_embed_kwargs'] = self.negative_prompt_embed_kwargs
+        return item
 
 
 def collate(items: List[dict], device='cuda') -> dict:
@@ -166,10 +205,23 @@ def collate(items: List[dict], device='cuda') -> dict:
     if len(sizes) != 1:
         raise ValueError(f'mixed latent sizes in one batch: {sorted(sizes)} (use bucketize=True)')
     _, h, w = next(iter(sizes))
+    def stack(kws):
+        """[B, T, D] zero padded to the longest item; with masks (Qwen caches are pre-padded to a fixed length) the text is first
+        truncated to the longest REAL length of the batch, as the reference does before the transformer
+        (lakonlab/models/architecture/arcflow/arcqwen.py:325-330) -- zero pad tokens must not enter joint attention / the text RoPE."""
+        embs = [k['encoder_hidden_states'] for k in kws]
+        if all('encoder_hidden_states_mask' in k for k in kws):
+            keep = max(int(k['encoder_hidden_states_mask'].sum()) for k in kws)
+            embs = [e[:max(keep, 1)] for e in embs]
+        T = max(e.size(0) for e in embs)
+        return torch.stack([torch.cat([e, e.new_zeros(T - e.size(0), e.size(1))]) for e in embs]).to(device=device, dtype=torch.bfloat16)
     kws = [it['prompt_embed_kwargs'] for it in items]
-    T = max(k['encoder_hidden_states'].size(0) for k in kws)
-    pe = torch.stack([torch.cat([k['encoder_hidden_states'], k['encoder_hidden_states'].new_zeros(T - k['encoder_hidden_states'].size(0), k['encoder_hidden_states'].size(1))]) for k in kws])
-    cond = dict(prompt_embeds=pe.to(device=device, dtype=torch.bfloat16), hp=h // 2, wp=w // 2)
+    cond = dict(prompt_embeds=stack(kws), hp=h // 2, wp=w // 2)
     if 'pooled_projections' in kws[0]:
         cond['pooled'] = torch.stack([k['pooled_projections'] for k in kws]).to(device=device, dtype=torch.bfloat16)
+    if 'negative_prompt_embed_kwargs' in items[0]:
+        nk = [it['negative_prompt_embed_kwargs'] for it in items]
+        cond['negative_prompt_embeds'] = stack(nk)
+        if 'pooled_projections' in nk[0]:
+            cond['negative_pooled'] = torch.stack([k['pooled_projections'] for k in nk]).to(device=device, dtype=torch.bfloat16)
     return cond

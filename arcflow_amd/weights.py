@@ -205,3 +205,84 @@ def init_arcflow_heads_from_teacher(sd: Dict[str, Tensor], K: int = 16, L: int =
     rates = torch.logspace(math.log10(0.2), math.log10(4.0), K - 1, base=10)
     out['proj_out_loggamma.bias'] = torch.log(rates).unsqueeze(1).repeat(1, L).flatten().to(b.dtype)
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# Expected diffusers state-dict layout (names -> shapes) of the transformers this engine ingests: what
+# ``tools/check_snapshot.py`` validates a real checkpoint's safetensors headers against (SURVEY 8c self-check 1: weight names and
+# shapes of FLUX.1-dev / Qwen-Image as the reference's ``from_pretrained`` + ``load_arcflow_adapter`` consume them,
+# lakonlab/pipelines/arcflow_loader.py:241-263).
+def expected_transformer_keys(family: str, cfg: Dict, student: bool = False, K: int = 16, L: int = 4) -> Dict[str, tuple]:
+    """family 'flux' | 'qwen'; cfg = the transformer's config.json (diffusers field names).  student: ArcFlow heads
+    (proj_out_means / _logweights / _loggamma) instead of the plain ``proj_out``."""
+    H, hd = cfg.get('num_attention_heads', 24), cfg.get('attention_head_dim', 128)
+    D = H * hd
+    C = cfg.get('in_channels', 64)
+    J = cfg.get('joint_attention_dim', 4096 if family == 'flux' else 3584)
+    e: Dict[str, tuple] = {}
+
+    def lin(name, o, i):
+        e[name + '.weight'] = (o, i)
+        e[name + '.bias'] = (o,)
+    if family == 'flux':
+        lin('x_embedder', D, C)
+        lin('context_embedder', D, J)
+        names = ['timestep_embedder', 'text_embedder'] + (['guidance_embedder'] if cfg.get('guidance_embeds', True) else [])
+        for nm in names:
+            lin(f'time_text_embed.{nm}.linear_1', D, cfg.get('pooled_projection_dim', 768) if nm == 'text_embedder' else 256)
+            lin(f'time_text_embed.{nm}.linear_2', D, D)
+        for i in range(cfg.get('num_layers', 19)):
+            p = f'transformer_blocks.{i}.'
+            lin(p + 'norm1.linear', 6 * D, D)
+            lin(p + 'norm1_context.linear', 6 * D, D)
+            for nm in ('to_q', 'to_k', 'to_v', 'add_q_proj', 'add_k_proj', 'add_v_proj', 'to_out.0', 'to_add_out'):
+                lin(p + 'attn.' + nm, D, D)
+            for nm in ('norm_q', 'norm_k', 'norm_added_q', 'norm_added_k'):
+                e[p + f'attn.{nm}.weight'] = (hd,)
+            for ff in ('ff', 'ff_context'):
+                lin(p + ff + '.net.0.proj', 4 * D, D)
+                lin(p + ff + '.net.2', D, 4 * D)
+        for i in range(cfg.get('num_single_layers', 38)):
+            p = f'single_transformer_blocks.{i}.'
+            lin(p + 'norm.linear', 3 * D, D)
+            for nm in ('to_q', 'to_k', 'to_v'):
+                lin(p + 'attn.' + nm, D, D)
+            e[p + 'attn.norm_q.weight'] = (hd,)
+            e[p + 'attn.norm_k.weight'] = (hd,)
+            lin(p + 'proj_mlp', 4 * D, D)
+            lin(p + 'proj_out', D, 5 * D)
+    elif family == 'qwen':
+        lin('img_in', D, C)
+        lin('txt_in', D, J)
+        e['txt_norm.weight'] = (J,)
+        lin('time_text_embed.timestep_embedder.linear_1', D, 256)
+        lin('time_text_embed.timestep_embedder.linear_2', D, D)
+        for i in range(cfg.get('num_layers', 60)):
+            p = f'transformer_blocks.{i}.'
+            lin(p + 'img_mod.1', 6 * D, D)
+            lin(p + 'txt_mod.1', 6 * D, D)
+            for nm in ('to_q', 'to_k', 'to_v', 'add_q_proj', 'add_k_proj', 'add_v_proj', 'to_out.0', 'to_add_out'):
+                lin(p + 'attn.' + nm, D, D)
+            for nm in ('norm_q', 'norm_k', 'norm_added_q', 'norm_added_k'):
+                e[p + f'attn.{nm}.weight'] = (hd,)
+            for ff in ('img_mlp', 'txt_mlp'):
+                lin(p + ff + '.net.0.proj', 4 * D, D)
+                lin(p + ff + '.net.2', D, 4 * D)
+    else:
+        raise ValueError(family)
+    lin('norm_out.linear', 2 * D, D)
+    if student:
+        lin('proj_out_means', K * C, D)
+        lin('proj_out_logweights', K * L, D)
+        lin('proj_out_loggamma', (K - 1) * L, D)
+    else:
+        lin('proj_out', C, D)
+    return e
+
+
+def check_state_shapes(shapes: Dict[str, tuple], expected: Dict[str, tuple]):
+    """-> (missing names, [(name, got, want)] shape mismatches, unexpected names)."""
+    missing = sorted(k for k in expected if k not in shapes)
+    wrong = sorted((k, tuple(shapes[k]), tuple(expected[k])) for k in expected if k in shapes and tuple(shapes[k]) != tuple(expected[k]))
+    extra = sorted(k for k in shapes if k not in expected)
+    return missing, wrong, extra

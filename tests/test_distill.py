@@ -109,6 +109,57 @@ def test_train_step_matches_cpu_autograd():
     assert info['skipped'] and torch.equal(dist.params, p_now)
 
 
+@pytest.mark.gpu
+def test_teacher_fp8_step_tracks_bf16_step_and_oracle():
+    """BASELINE.json configs[4] ("fp8 MFMA fwd + bf16 grads"): DistillConfig.teacher_fp8 runs the frozen teacher's block linears on
+    the e4m3 MFMA (row-wise scales); student forward, gradients and optimizer stay bf16 / fp32.  Stated tolerance: the teacher
+    targets move by fp8 quantisation noise only -- loss within 5 %, every gradient block within 0.25 rel-L2 of the bf16-teacher
+    step on the same draws, and the loss within 6 % of autograd through the fp32 CPU oracle."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg, w = _setup()
+    B, hp, wp, T = 2, 8, 8, 12
+    N = hp * wp
+    g = torch.Generator().manual_seed(3)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, N, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+    res = {}
+    for fp8 in (False, True):
+        dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, teacher_fp8=fp8)
+        d = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+        assert d.teacher._weights.get('d0.img_qkv.weight_q') is not None if fp8 else True       # the quantised copies exist
+        d.iteration = 1
+        info = d.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+        res[fp8] = (info, d.grad.clone(), d.last_x.clone())
+    (i16, g16, x16), (i8, g8, x8) = res[False], res[True]
+    assert not i8['skipped'] and i8['loss'] != i16['loss']                          # the fp8 teacher really ran
+    assert abs(i8['loss'] - i16['loss']) < 5e-2 * abs(i16['loss']), (i8['loss'], i16['loss'])
+    assert ((g8 - g16).norm() / g16.norm()).item() < 0.25
+    assert ((x8 - x16).norm() / x16.norm()).item() < 3e-2
+    # ---- fp32 CPU oracle (same chain as test_train_step_matches_cpu_autograd, loss only) -----------------------------------
+    wt = {k: v.float() for k, v in w.items()}
+    gd = torch.full((B,), 3.5)
+
+    def teacher(x_lat, t):
+        u = D.flux_teacher_forward(wt, cfg, R.pack_latents(x_lat).bfloat16().float(), pe.float(), pooled.float(), t, gd, hp, wp)
+        return R.unpack_latents(u.bfloat16().float(), hp, wp)
+    with torch.no_grad():
+        x, raw, total = x0.clone(), torch.ones(B), 0.0
+        for step in range(2):
+            m, lw, lg = D.flux_forward(wt, cfg, x.bfloat16().float(), pe.float(), pooled.float(), R.shift_sigma(raw), gd, hp, wp)
+            ml, lwl, lgl = R.unpack_mixture(m.bfloat16().float(), lw.bfloat16().float(), lg.bfloat16().float(), hp, wp)
+            u_drop, u_stu, u_tea = draws[step]
+            mask = R.gm_dropout_mask(u_drop.reshape(B, 16, 1, 1, 1), 0.1)
+            loss, x_dst, raw = R.segment_distill(teacher, R.unpack_latents(x, hp, wp), ml, lwl, lgl, raw, 0.75, 0.5, u_stu, u_tea, drop_mask=mask)
+            total += float(loss) * 0.5
+            x = R.pack_latents(x_dst)
+    assert abs(i8['loss'] - total) < 6e-2 * abs(total), (i8['loss'], total)
+
+
 def _dp_worker(rank, world, port, tmp):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -120,6 +120,35 @@ def test_prompt_cache_items_and_collate(tmp_path):
         DATA.collate([a, ds[2]], device='cpu')
 
 
+def test_prompt_cache_negative_embeds_mask_truncation_and_size_index(tmp_path):
+    """(medium) a --data-dir cache must deliver negative_prompt_embeds for the true-CFG (Qwen) teacher; (low) masks
+    truncate the text to the longest real length of the batch (arcqwen.py:325-330); (low) the bucket sizes come from an index."""
+    import json
+    g = torch.Generator().manual_seed(1)
+    cache = tmp_path / 'cache'
+    cache.mkdir()
+    for i, real in enumerate([3, 5]):
+        e = torch.zeros(8, 16)
+        e[:real] = torch.randn(real, 16, generator=g)
+        m = torch.zeros(8, dtype=torch.long)
+        m[:real] = 1
+        pickle.dump(dict(prompt=f'q{i}', prompt_embed_kwargs=dict(encoder_hidden_states=e, encoder_hidden_states_mask=m),
+                         latent_size=(16, 8, 8)), open(cache / f'{i:03d}.pkl', 'wb'))
+    neg = dict(prompt_embeds=torch.randn(2, 16, generator=g), prompt_embeds_mask=torch.ones(2, dtype=torch.long))   # legacy keys
+    torch.save(neg, tmp_path / 'neg.pt')
+    ds = DATA.PromptEmbedCache(str(cache), bucketize=True, negative_prompt_embeds_path=str(tmp_path / 'neg.pt'))
+    assert json.load(open(cache / 'latent_sizes.json')) == {'000.pkl': [16, 8, 8], '001.pkl': [16, 8, 8]}     # written once
+    (cache / '000.pkl').rename(cache / '000.pkl.moved')          # a second start must not unpickle the items for their sizes
+    ds2 = DATA.PromptEmbedCache(str(cache), datalist=['000.pkl', '001.pkl'], bucketize=True)
+    assert ds2.bucket_ids == [0, 0]
+    (cache / '000.pkl.moved').rename(cache / '000.pkl')
+    cond = DATA.collate([ds[0], ds[1]], device='cpu')
+    assert cond['prompt_embeds'].shape == (2, 5, 16)                                  # 8 padded tokens -> 5 real ones
+    assert torch.all(cond['prompt_embeds'][0, 3:] == 0)
+    assert cond['negative_prompt_embeds'].shape == (2, 2, 16)
+    assert torch.allclose(cond['negative_prompt_embeds'][1].float(), neg['prompt_embeds'].bfloat16().float())
+
+
 _TINY_CFG = """
 name = 'tiny'
 model = dict(diffusion=dict(type='ArcFlowImitationDataFree', policy_type='ArcFlow', policy_kwargs=dict(),

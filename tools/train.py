@@ -35,6 +35,8 @@ def parse_args():
     ap.add_argument('--transformer-dir', help='local diffusers transformer directory of the teacher')
     ap.add_argument('--synthetic', action='store_true', help='random-init weights and prompt embeddings')
     ap.add_argument('--data-dir', help='prompt-embedding cache directory')
+    ap.add_argument('--negative-prompt-embeds', help='torch.load-able embeddings of the negative prompt (true-CFG teacher: Qwen config; '
+                                                     'the reference dataset option negative_prompt_embeds_path)')
     ap.add_argument('--prompts', help='text file, one prompt per line: encode on the fly with the HIP text encoders (needs --snapshot)')
     ap.add_argument('--snapshot', help='local FLUX.1-dev / Qwen-Image snapshot (text_encoder*/, tokenizer*/) for --prompts')
     ap.add_argument('--latent-tokens', type=int, nargs=2, default=[64, 64], help='synthetic data: packed latent grid (64 64 = 1024^2)')
@@ -106,7 +108,12 @@ def main():
     B = run['samples_per_gpu']
     loader = None
     if args.data_dir:
-        ds = data.PromptEmbedCache(args.data_dir, pad_seq_len=512 if family == 'flux' else None, bucketize=True)
+        neg_path = args.negative_prompt_embeds or run['data_train'].get('negative_prompt_embeds_path')
+        if dc.teacher_guidance_scale > 1.0 and not neg_path:
+            raise SystemExit(f'teacher_guidance_scale = {dc.teacher_guidance_scale} (true CFG) needs the negative prompt embeddings: '
+                             'pass --negative-prompt-embeds <file> (or data.train.negative_prompt_embeds_path in the config)')
+        ds = data.PromptEmbedCache(args.data_dir, pad_seq_len=512 if family == 'flux' else None, bucketize=True,
+                                   negative_prompt_embeds_path=neg_path)
         sampler = data.DistributedSampler(ds, world, rank, shuffle=True, samples_per_gpu=B, seed=args.seed)
         sampler.set_iter(dist_.iteration)
 
