@@ -1,5 +1,7 @@
 // HBM-bound helper kernels of the MMDiT trunk and the ArcFlow policy math (gfx950, wave64).
 // Everything here streams 16 B per lane and reduces with wave shuffles; fp32 math, bf16 storage.
+#include <cstdlib>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -506,14 +508,22 @@ hipError_t launch_arcflow_step(const float* x_in, const void* means, const void*
   const int64_t tokens = (int64_t)B * n_tok;
   if (tokens == 0) return hipSuccess;
   if (K == 16 && ch == 64 && pp == 4) {             // the shipped mixture shape: one coefficient per lane (see above)
-    constexpr int TPW = 2;
-    dim3 g2((unsigned)((tokens + 4 * TPW - 1) / (4 * TPW)));
-    if (mix_bf16)
-      hipLaunchKernelGGL((arcflow_step_k16_kernel<bf16_t, TPW>), g2, dim3(256), 0, stream, x_in, (const bf16_t*)means, (const bf16_t*)logw,
-                         (const bf16_t*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out, tokens, n_tok, velocity_only, drop);
-    else
-      hipLaunchKernelGGL((arcflow_step_k16_kernel<float, TPW>), g2, dim3(256), 0, stream, x_in, (const float*)means, (const float*)logw,
-                         (const float*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out, tokens, n_tok, velocity_only, drop);
+    static int tpw = -1;
+    if (tpw < 0) {
+      const char* e = getenv("AFX_STEP_TPW");       // tokens per wave: 1 | 2 | 4 (cold-cache kernel time at 1024^2, r02p: 6.1 | 6.6 | 8.8 us)
+      tpw = e ? atoi(e) : 1;
+      if (tpw != 1 && tpw != 2 && tpw != 4) tpw = 1;
+    }
+#define AFX_STEP_LAUNCH(T, TPW)                                                                                                     \
+    hipLaunchKernelGGL((arcflow_step_k16_kernel<T, TPW>), dim3((unsigned)((tokens + 4 * TPW - 1) / (4 * TPW))), dim3(256), 0, stream, \
+                       x_in, (const T*)means, (const T*)logw, (const T*)logg, s_src, s_start, s_end, sigma_vec, eps, x_out, tokens,  \
+                       n_tok, velocity_only, drop)
+    if (mix_bf16) {
+      if (tpw == 1) AFX_STEP_LAUNCH(bf16_t, 1); else if (tpw == 4) AFX_STEP_LAUNCH(bf16_t, 4); else AFX_STEP_LAUNCH(bf16_t, 2);
+    } else {
+      if (tpw == 1) AFX_STEP_LAUNCH(float, 1); else if (tpw == 4) AFX_STEP_LAUNCH(float, 4); else AFX_STEP_LAUNCH(float, 2);
+    }
+#undef AFX_STEP_LAUNCH
     return hipGetLastError();
   }
   dim3 grid((unsigned)((tokens + 3) / 4)), block(256);

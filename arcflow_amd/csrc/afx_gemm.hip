@@ -726,8 +726,12 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   // ---- stream-K tail: only with a caller-provided slab / flag workspace (the engine's), one K, plain bf16 / fp8 output tiles
   static int sk_mode = -1, cus_per_xcd = 32;
   if (sk_mode < 0) {
-    const char* e = getenv("AFX_GEMM_SK");               // 0: off, 1: launches with >= 1 full round (default), 2: every eligible launch
-    sk_mode = e ? atoi(e) : 1;
+    // 0 (default): off, 1: launches with >= 1 full round in front of the tail, 2: every eligible launch.  OFF by default: in the
+    // FLUX forward the tail costs more than it wins (r02p, same box, 3 interleaved runs: 7.06 / 7.02 / 6.93 images/s for 0 / 1 / 2)
+    // although the isolated qkv GEMM gains 6-9 % -- the 64 MB of write-through partial slabs per launch compete with the next
+    // launches' operands for the L2 / Infinity Cache.  Kept (and tested through afx_linear_bf16_sk) as the measured negative result.
+    const char* e = getenv("AFX_GEMM_SK");
+    sk_mode = e ? atoi(e) : 0;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
