@@ -132,7 +132,153 @@ AFX_DEV void epi_store_rows(const GemmProblem& P, const float* patch, int row0, 
 // v_permlane16_swap per register between the column tiles jj, jj+1 pairs the 16-lane groups fq, fq^1: afterwards an even-fq
 // lane owns 8 consecutive columns of tile jj, an odd-fq lane 8 of tile jj+1 -> every bias / gate / residual access and the
 // store are 16 bytes per lane (64 contiguous bytes per row and instruction), no LDS round trip, no barrier.
+//
+// epi_store_fast<EPI>: the bf16-output modes of the forward (bias, bias + GELU, gate * x + residual) as straight-line code.  The
+// generic body below re-reads its GemmProblem fields from the kernel-argument segment inside every one of its 16 unrolled
+// (row tile, column pair) steps (hipcc rematerialises the s_load instead of holding ~40 SGPRs) and waits lgkmcnt(0) behind each:
+// ~12.7 k cycles per tile, 9.5 % of a K = 3072 tile (tools/gemm_trace.hip).  Here every uniform field is read ONCE, the batch
+// index of a row is a float multiply + fix-up instead of an integer division, and the residual / gate loads of row tile ii + 1
+// are issued before row tile ii is converted and stored (the residual may alias C: a lane reads exactly the 16 bytes it writes).
+// A raw buffer descriptor over [p, p + bytes) built from values forced into SGPRs: if hipcc cannot prove the descriptor
+// wave-uniform it wraps every buffer access in a readfirstlane "waterfall" loop (12 instructions + a branch per store).
+template <typename T>
+AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)p);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uintptr_t)p >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int EPI, int MI, int NJ>
+AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+  constexpr int NP = NJ / 2;     // column-tile pairs
+  constexpr uint32_t OOB = 0x80000000u;        // a byte offset past every buffer below: the hardware drops the access
+  const int M = P.M, N = P.N;
+  // Raw buffer descriptors over the wave's MI*16 rows of C / the residual (num_records = the rows that exist): rows >= M and
+  // masked columns fall outside and are dropped / read as zero by the bounds check -- no exec-mask branch per step, so the whole
+  // epilogue is ONE basic block the scheduler can interleave (a taken branch costs a lone wave ~30 cycles of refetch).
+  const int rows_ok = min(max(M - row_base, 0), MI * 16);
+  const int64_t ldc = P.ldc;
+  __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.C + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 2));
+  const int ldc2 = (int)(ldc * 2);
+  int ldr2 = 0, rpb = 1, ldg4 = 0;
+  float inv_rpb = 1.f;
+  bool has_gate = false;
+  __amdgpu_buffer_rsrc_t rr_ = rc, rg_ = rc;
+  if constexpr (EPI == EPI_GATE_RES) {
+    const int64_t ldr = P.ldr;
+    ldr2 = (int)(ldr * 2);
+    rr_ = uniform_rsrc(const_cast<uint16_t*>(P.res) + (int64_t)row_base * ldr, (int)(rows_ok * ldr * 2));
+    rpb = P.rows_per_batch;
+    inv_rpb = 1.0f / (float)rpb;
+    has_gate = P.gate != nullptr;
+    ldg4 = (int)(P.ldg * 4);
+    const int nb = (M + rpb - 1) / rpb;                           // gate rows
+    rg_ = uniform_rsrc(const_cast<float*>(P.gate), has_gate ? (int)(((nb - 1) * P.ldg + N) * 4) : 0);   // (ldg may be 0: one gate row)
+  }
+  const int gelu_col0 = EPI == EPI_GELU ? P.gelu_col0 : 0;
+  int gcol[NP];
+  uint32_t coff[NP];             // byte offset of the lane's 8 columns in a bf16 row, or OOB
+  float bias[NP][8];
+  const uint16_t* const biasp = P.bias;
+#pragma unroll
+  for (int jp = 0; jp < NP; ++jp) {
+    gcol[jp] = col_base + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;
+    const bool col_ok = gcol[jp] < N;
+    coff[jp] = col_ok ? (uint32_t)gcol[jp] * 2u : OOB;
+#ifdef AFX_GEMM_TRACE
+    if (EPI == EPI_NONE && P.gelu_col0 == -12345) coff[jp] = OOB;     // tools/gemm_trace.hip TRACE_NOSTORE: epilogue without write traffic
+#endif
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
+    if (biasp != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[jp]), bias[jp]);
+  }
+  // GATE_RES: the residual words of row tile ii + PF are requested before row tile ii is converted and stored (requesting ALL
+  // rows up front serialises the read burst and the write burst: 25 k cycles per 256 x 256 tile against 15 k).  The gate vector is
+  // loaded once when every row of the wave belongs to one batch sample (uniform test; always so for batch 1), per row tile otherwise.
+  constexpr int PF = 2;
+  u32x4_t rw[PF + 1][NP];
+  auto fetch_res = [&](int ii, u32x4_t (&r)[NP]) {
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp)
+      r[jp] = __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)((uint32_t)((ii * 16 + frow) * ldr2) + coff[jp]), 0, 0);
+  };
+  f32x4_t g1[NP][2];
+  bool single = true;
+  if constexpr (EPI == EPI_GATE_RES) {
+#pragma unroll
+    for (int ii = 0; ii < PF && ii < MI; ++ii) fetch_res(ii, rw[ii % (PF + 1)]);
+    const int b_first = row_base / rpb, b_last = (row_base + MI * 16 - 1) / rpb;      // scalar divisions, once
+    single = b_first == b_last;
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      const uint32_t go = (uint32_t)(b_first * ldg4) + 2u * coff[jp];                  // (OOB * 2 wraps to 0: harmless, the store is dropped)
+      g1[jp][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)go, 0, 0));
+      g1[jp][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)(go + 16u), 0, 0));
+    }
+  }
+#pragma unroll
+  for (int ii = 0; ii < MI; ++ii) {
+    const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
+    f32x4_t gi[NP][2];
+    if constexpr (EPI == EPI_GATE_RES) {
+      if (ii + PF < MI) fetch_res(ii + PF, rw[(ii + PF) % (PF + 1)]);
+#pragma unroll
+      for (int jp = 0; jp < NP; ++jp) { gi[jp][0] = g1[jp][0]; gi[jp][1] = g1[jp][1]; }
+      if (!single) {                                            // (uniform) rows of several samples in this wave's tile
+        const int grow = row_base + ii * 16 + frow;
+        int b = (int)((float)grow * inv_rpb);                   // floor(grow / rpb) up to +-1: fix up exactly
+        const int rem = grow - b * rpb;
+        b += rem >= rpb ? 1 : (rem < 0 ? -1 : 0);
+#pragma unroll
+        for (int jp = 0; jp < NP; ++jp) {
+          const uint32_t go = (uint32_t)(b * ldg4) + 2u * coff[jp];
+          gi[jp][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)go, 0, 0));
+          gi[jp][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)(go + 16u), 0, 0));
+        }
+      }
+    }
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * jp][e]), __float_as_uint(acc[ii][2 * jp + 1][e]), false, false);
+        v[e] = __uint_as_float(sw[0]);
+        v[4 + e] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] += bias[jp][e];
+      if constexpr (EPI == EPI_GELU) {
+        if (gcol[jp] >= gelu_col0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+        }
+      } else if constexpr (EPI == EPI_GATE_RES) {
+        float rr[8];
+        unpack8(rw[ii % (PF + 1)][jp], rr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = rr[e] + (has_gate ? gi[jp][e >> 2][e & 3] : 1.0f) * v[e];      // no gate: plain residual add
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rc, (int)(roff + coff[jp]), 0, 0);
+    }
+  }
+}
+
+// (uniform) the forward's epilogue modes: bf16 out, no fp8 scales / convolution border / pre-add
+AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.fp8 == 0 && P.conv_wp == 0 && P.pre == nullptr; }
+
+template <int MI, int NJ>
+AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ>(P, acc, row_base, col_base, frow, fq);
+  else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ>(P, acc, row_base, col_base, frow, fq);
+  else epi_store_fast<EPI_NONE, MI, NJ>(P, acc, row_base, col_base, frow, fq);
+}
+
 AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
+  if (epi_is_fast(P)) {
+    epi_store_fast_any<8, 4>(P, acc, row_base, col_base, frow, fq);
+    return;
+  }
   const bool first_chunk = chunk == 0;
   float wsc[2][8];            // fp8: per-output-channel weight scales of this lane's 2 x 8 columns
   int gcol[2];
@@ -503,6 +649,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   unsigned tr[24];
   const int trace_t = nk / 2;
   AFX_TRC(17)
+  tr[22] = (unsigned)__builtin_amdgcn_s_memrealtime();      // 100 MHz reference clock: shader clock = d(memtime) / d(realtime)
 #endif
 
   // ---- per-lane DMA source pointers (k = 0) of the two 16-byte chunks this lane moves per half tile
@@ -674,10 +821,234 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq, chunk);
 #ifdef AFX_GEMM_TRACE
   AFX_TRC(21)
+  tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
   if ((blockIdx.x == 0 || blockIdx.x == 300) && lane == 0)
-    for (int i = 0; i < 22; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave][i] = tr[i];
+    for (int i = 0; i < 24; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave][i] = tr[i];
 #endif
   }   // pieces
+}
+
+
+// =================================================================================================
+// v3: ONE wave per SIMD, tile shape a template parameter.  4 waves (2 x 2), each (16 MI) x (16 NJ) of a (32 MI) x (32 NJ) tile with
+// 4 MI NJ fp32 accumulators per lane in the accumulator file (<= 256: the 512-register budget of a 256-thread work-group):
+//   <8, 8>  256 x 256, 128 MFMAs / 32 ds_read_b128 / 16 DMA instructions per wave and K-tile (the 8-phase kernel: 2.67 MFMAs per
+//           read, 196 KB of LDS reads per CU and K-tile against 128 KB here -- this kernel runs at a higher clock under the power cap)
+//   <9, 6>  288 x 192: M = 4608 = 16 x 288 and N = 3072 j = 16 j x 192, so EVERY joint-stream FLUX GEMM is a whole number of
+//           256-tile rounds (N = 3072: 256 tiles instead of 216 256 x 256 tiles in one 84 %-filled round)
+//   <10, 6> 320 x 192: the two-problem launches of the double blocks (4096 + 512 rows): 15 x N/192 tiles
+// Schedule per K-tile (64), per wave: k-half 0 multiplies from registers while the k-half-1 fragments are read (one ds_read_b128
+// every second MFMA, all issued in the first half of the phase) and W(t+2) is issued (one DMA instruction every few MFMAs in the
+// second half); ONE barrier in the middle of the tile (every LDS read of tile t is done, A(t+1) / W(t+1) have landed); k-half 1
+// multiplies while tile t+1's k-half-0 fragments are read and A(t+2) is issued.  Never two memory instructions between two
+// MFMAs: a ds_read_b128 / DMA issue costs the lone wave of a SIMD ~6-20 cycles of MFMA issue when they queue up (measured with
+// tools/gemm_trace.hip: 2664 -> 2376 cycles per K-tile from the interleave alone; the 8-phase kernel: 2440).
+//   * LDS = A x 2 slots + W x 3 slots: W(t+2) goes to the slot W(t-1) left at mid-tile t-1 (1.5 tiles ahead of its first read),
+//     A(t+2) to the slot A(t) leaves at mid-tile t (one tile ahead).
+//   * epilogue: the bf16 modes of epi_store_fast only -- the launcher keeps every other mode on the 8-phase kernel.
+#ifndef V3_EXP
+#define V3_EXP 0
+#endif
+AFX_DEV uint64_t v3_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit value, in an SGPR pair
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+constexpr int V3_THREADS = 256;
+constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (32 * NJ) * 128; }
+
+template <int MI, int NJ>
+__global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3(const GemmBatch batch) {
+  constexpr int TM = 32 * MI, TN = 32 * NJ;
+  constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
+  constexpr int NM = MI * NJ;                                  // MFMAs per k-half
+  constexpr int W_SP = (NM / 2) / NJ, A_SP = (NM / 2) / MI;    // MFMAs between two DMA issues in the second half of a phase
+  static_assert(4 * MI * NJ <= 256 && NJ % 2 == 0 && 2 * (MI + NJ) <= NM && W_SP >= 2 && A_SP >= 2, "v3 tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const smem_w = smem + 2 * A_SLOT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int wg = xcd_remap(blockIdx.x, gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
+  const GemmProblem& P = batch.p[pi];
+  wg -= P.tile_start;
+  const int GM_ = batch.group_m;
+  const int per_group = GM_ * P.tiles_n;
+  const int grp = wg / per_group;
+  const int first_m = grp * GM_;
+  const int gsz = min(P.tiles_m - first_m, GM_);
+  const int in_grp = wg - grp * per_group;
+  const int tm = first_m + in_grp % gsz;
+  const int tn = in_grp / gsz;
+  const int m0 = tm * TM, n0 = tn * TN;
+  const int nk = P.K / BK;
+
+  // per-lane byte offsets of this lane's chunks of an A tile (MI pieces of 32 rows) / a W tile (NJ pieces), k = 0
+  const int prow = tid >> 3;                                       // + 32 i
+  const int pc = ((tid & 7) ^ ((prow >> 1) & 7)) * 16;             // logical 16-byte chunk stored at physical chunk tid & 7
+  uint32_t aoff[MI], woff[NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    int ar = m0 + prow + 32 * i;
+    ar = ar < P.M ? ar : P.M - 1;
+    aoff[i] = (uint32_t)((int64_t)ar * P.lda * 2 + pc);
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) {
+    int br = n0 + prow + 32 * i;
+    br = br < P.N ? br : P.N - 1;
+    woff[i] = (uint32_t)((int64_t)br * P.ldw * 2 + pc);
+  }
+  const char* abase = reinterpret_cast<const char*>(P.A);
+  const char* wbase = reinterpret_cast<const char*>(P.W);
+  auto stage_a = [&](int t) {
+    t = t < nk ? t : nk - 1;
+    const char* src = abase + (int64_t)t * (BK * 2);
+    char* dst = smem + (t & 1) * A_SLOT;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + aoff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
+  };
+  auto stage_w = [&](int t) {
+    t = t < nk ? t : nk - 1;
+    const char* src = wbase + (int64_t)t * (BK * 2);
+    char* dst = smem_w + (t % 3) * W_SLOT;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + woff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x4_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15, fq = lane >> 4;
+  const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
+
+#ifdef AFX_GEMM_TRACE
+  unsigned tr[24];
+  const int trace_t = nk / 2;
+  AFX_TRC(17)
+  tr[22] = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+  // prologue: A(0) W(0) | W(1) A(1) stay in flight
+  stage_a(0); stage_w(0); stage_w(1); stage_a(1);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
+  __builtin_amdgcn_s_barrier();
+  bf16x8_t a0[MI], b0[NJ], a1[MI], b1[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; ++i) b0[i] = lds_frag(smem_w, brow + i * 16, fq);
+#pragma unroll
+  for (int i = 0; i < MI; ++i) a0[i] = lds_frag(smem, arow + i * 16, fq);
+
+  // The MFMAs are inline asm with the accumulator pinned to the accumulator file ("+a"): left to itself hipcc keeps part of the
+  // accumulators in arch VGPRs and shuttles them through v_accvgpr moves around every MFMA (452 moves per 128 MFMAs).  An asm
+  // statement with a "memory" clobber is also the ordering tool: the fragment reads and DMA issues written between two MFMAs
+  // stay there, which is the interleave sched_group_barrier would give for builtin MFMAs.
+#define V3_ONE(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+#define V3_FENCE() asm volatile("" ::: "memory")
+  // LDS-DMA in the SGPR-base + 32-bit-lane-offset form (hipcc widens the builtin's address to a 64-bit VGPR pair with a
+  // v_lshl_add_u64 in front of every issue); M0 = LDS byte address of the wave's 1 KiB destination
+#define V3_DMA(BASE_U64, VOFF, LDS_PTR)                                                                                            \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"((uint32_t)(uintptr_t)(LDS_PTR)), "v"(VOFF), \
+               "s"(BASE_U64)                                                                                                       \
+               : "memory", "m0")
+  // MFMA m of a k-half: A row tile m / NJ, W column tile m % NJ (operands swapped: the accumulator holds C^T, see epi_store_fast)
+#define V3_MFMA_AT(m, AF, BF) V3_ONE(acc[(m) / NJ][(m) % NJ], BF[(m) % NJ], AF[(m) / NJ])
+
+  AFX_TRC(18)
+  // Two copies of the K-tile body: tiles whose successor t+2 exists issue its DMA, the last two tiles issue nothing -- as a
+  // compile-time flag, because a scalar branch around each DMA issue costs the lone wave ~30 cycles of instruction refetch
+  // (16 per K-tile: +20 %).
+  int t = 0;
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+  const bool more = part == 0;                 // a constant once the two parts are unrolled
+  const int t_end = more ? nk - 2 : nk;
+#pragma unroll 1
+  for (; t < t_end; ++t) {
+    const char* sa = smem + (t & 1) * A_SLOT;
+    const char* sw = smem_w + (t % 3) * W_SLOT;
+    AFX_TR(0)
+    // ---- k-half 0 multiplies; the k-half-1 fragments stream in; W(t+2) -> slot (t+2) % 3 ------------------------------------
+    {
+      const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(t + 2) * (BK * 2)));
+      char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {          // one memory instruction at most between two MFMAs (12 free issue cycles)
+        V3_MFMA_AT(m, a0, b0);
+        V3_FENCE();
+        if ((m & 1) && (m >> 1) < MI + NJ) {
+          const int r = m >> 1;               // b1[0..NJ), a1[0..MI)
+          if (V3_EXP == 2) {
+          } else if (r < NJ) b1[r] = lds_frag(sw, brow + r * 16, 4 + fq);
+          else a1[r - NJ] = lds_frag(sa, arow + (r - NJ) * 16, 4 + fq);
+        }
+        if (m >= NM / 2 && (m - NM / 2) % W_SP == 1 && (m - NM / 2) / W_SP < NJ && V3_EXP != 1) {
+          const int q = (m - NM / 2) / W_SP;
+          if (more) V3_DMA(wsrc_u, woff[q], wdst + (q * V3_THREADS + wave * 64) * 16);
+        }
+        V3_FENCE();
+      }
+    }
+    // ---- mid-tile: every LDS read of tile t is done; W(t+1), A(t+1) have landed (W(t+2), just issued, may still fly)
+    AFX_TR(1)
+    if (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    AFX_TR(2)
+    __builtin_amdgcn_s_barrier();
+    AFX_TR(3)
+    // ---- k-half 1 multiplies; DMA of A(t+2) -> slot t & 1 and the k-half-0 fragments of tile t+1 ---------------------------
+    {
+      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + (int64_t)(t + 2) * (BK * 2)));
+      char* adst = smem + (t & 1) * A_SLOT;
+      const char* na = smem + ((t + 1) & 1) * A_SLOT;
+      const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        V3_MFMA_AT(m, a1, b1);
+        V3_FENCE();
+        if ((m & 1) && (m >> 1) < MI + NJ) {
+          const int r = m >> 1;               // (past the last tile: re-reads a landed slot, unused)
+          if (V3_EXP == 2) {
+          } else if (r < NJ) b0[r] = lds_frag(nw, brow + r * 16, fq);
+          else a0[r - NJ] = lds_frag(na, arow + (r - NJ) * 16, fq);
+        }
+        if (m >= NM / 2 && (m - NM / 2) % A_SP == 1 && (m - NM / 2) / A_SP < MI && V3_EXP != 1) {
+          const int q = (m - NM / 2) / A_SP;
+          if (more) V3_DMA(asrc_u, aoff[q], adst + (q * V3_THREADS + wave * 64) * 16);
+        }
+        V3_FENCE();
+      }
+    }
+    AFX_TR(4)
+  }
+  }
+  AFX_TRC(19)
+  // MFMA -> accumulator-read wait states hipcc cannot see inside the asm (nothing is in flight any more: the last two tiles issue no DMA)
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
+  {   // lane constants of the epilogue from an OPAQUE copy of threadIdx: otherwise they are hoisted above the main loop (all 512
+      // registers are spoken for there) and the accumulators get shuffled through v_accvgpr moves to make room
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
+    const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
+    AFX_TRC(20)
+    epi_store_fast_any<MI, NJ>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+#ifdef AFX_GEMM_TRACE
+    AFX_TRC(21)
+    tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
+    if ((blockIdx.x == 0 || blockIdx.x == 300) && lane2 == 0)
+      for (int i = 0; i < 24; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave2][i] = tr[i];
+#endif
+  }
 }
 
 LaunchTimer& launch_timer() {
@@ -685,24 +1056,75 @@ LaunchTimer& launch_timer() {
   return t;
 }
 
-hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
+// ---- tile shape / kernel choice -------------------------------------------------------------------------------------------
+struct GemmMode { int impl = -1, tile = 0; };
+static GemmMode& gemm_mode() {
+  static GemmMode m;
+  return m;
+}
+void gemm_set_mode(int impl, int tile) {
+  gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;
+  gemm_mode().tile = (tile >= 0 && tile <= 3) ? tile : 0;
+}
+struct TileCfg { int tm, tn, group_m; };
+static const TileCfg kTileCfg[3] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}};
+
+static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   int total = 0;
   for (int i = 0; i < batch.nprob; ++i) {
     GemmProblem& p = batch.p[i];
-    p.tiles_m = (p.M + BM - 1) / BM;
-    p.tiles_n = (p.N + BN - 1) / BN;
-    p.tile_start = total;
-    if (p.split_k < 1 || p.out_f32 != 3) p.split_k = 1;
-    total += p.tiles_m * p.tiles_n * p.split_k;
+    const int tiles_m = (p.M + tm - 1) / tm, tiles_n = (p.N + tn - 1) / tn;
+    const int sk = (p.split_k < 1 || p.out_f32 != 3) ? 1 : p.split_k;
+    if (fill) {
+      p.tiles_m = tiles_m;
+      p.tiles_n = tiles_n;
+      p.tile_start = total;
+      p.split_k = sk;
+    }
+    total += tiles_m * tiles_n * sk;
   }
-  batch.total_tiles = total;
-  if (total == 0) return hipSuccess;
-  static int impl = -1;
-  static int group_m = GROUP_M;
-  if (impl < 0) {
-    if (const char* g = getenv("AFX_GEMM_GROUP_M")) group_m = atoi(g) > 0 ? atoi(g) : GROUP_M;
-    const char* e = getenv("AFX_GEMM_IMPL");           // 1: simple 2-stage kernel (reference / A-B), default: 8-phase v2
-    impl = (e && e[0] == '1') ? 1 : 2;
+  return total;
+}
+
+template <int MI, int NJ>
+static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       v3_lds_bytes(MI, NJ));
+    if (r != hipSuccess) return r;
+    attr = true;
+  }
+  if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
+                          launch_timer().stop, 0, batch);
+  else
+    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
+  static int cus = 256, sk_env = 0;
+  static int group_m_env = 0;
+  static bool init = false;
+  int& impl = gemm_mode().impl;
+  int& tile_env = gemm_mode().tile;
+  if (!init) {
+    init = true;
+    if (const char* g = getenv("AFX_GEMM_GROUP_M")) group_m_env = atoi(g) > 0 ? atoi(g) : 0;
+    // AFX_GEMM_IMPL: 1 = simple 2-stage kernel (reference / A-B), 2 = 8-phase kernel only, 3 (default) = one-wave-per-SIMD kernel
+    // for the forward's bf16 epilogue modes (8-phase for everything else).  AFX_GEMM_TILE (impl 3): 0 = pick per launch,
+    // 1 / 2 / 3 = force 256x256 / 288x192 / 320x192.  afx_gemm_set_mode() overrides both (parity tests, A/B runs).
+    if (impl < 0) {
+      const char* e = getenv("AFX_GEMM_IMPL");
+      impl = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 3;
+      if (const char* t = getenv("AFX_GEMM_TILE")) tile_env = atoi(t);
+    }
+    if (const char* k = getenv("AFX_GEMM_SK")) sk_env = atoi(k);             // the stream-K tail lives in the 8-phase kernel
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
@@ -713,9 +1135,47 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     if (r != hipSuccess) return r;
   }
+  // ---- one-wave-per-SIMD kernel: bf16 launches whose every problem is in a fast epilogue mode.  The tile shape is the one with
+  // the least (rounds of `cus` tiles) x (tile area): the launch is as long as its fullest CU.
+  bool v3_ok = impl == 3 && sk_env == 0 && batch.sk_force == 0;
+  for (int i = 0; i < batch.nprob; ++i) {
+    const GemmProblem& p = batch.p[i];
+    v3_ok = v3_ok && p.out_f32 == 0 && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
+  }
+  if (v3_ok) {
+    int best = 0;
+    if (tile_env >= 1 && tile_env <= 3) best = tile_env - 1;
+    else {
+      double best_cost = 0;
+      for (int c = 0; c < 3; ++c) {
+        const int tiles = count_tiles(batch, kTileCfg[c].tm, kTileCfg[c].tn, false);
+        if (tiles == 0) return hipSuccess;
+        const int rounds = (tiles + cus - 1) / cus;
+        // 256x256 has the best MFMA : LDS-read ratio (4 : 1 against 3.6 : 1 / 3.75 : 1) and the chip is power-capped: a tile
+        // shape that fills the last round only makes every CU clock lower.  Measured with weights streaming from HBM
+        // (tools/gemm_trace.hip TRACE_COLD=1, r02s): 288x192 wins 4-6 % at K = 3072 where it saves a round or fills a 216-tile
+        // launch, is level at K = 12288 and loses 3 % at K = 15360 (its W slots leave the DMA the shorter lead); 320x192 never won.
+        double pen = 1.0;
+        if (c == 1) pen = batch.p[0].K <= 8192 ? 1.05 : 1.5;
+        if (c == 2) pen = 1.10;
+        const double cost = (double)rounds * kTileCfg[c].tm * kTileCfg[c].tn * pen;
+        if (c == 0 || cost < best_cost) { best = c; best_cost = cost; }
+      }
+    }
+    const int total = count_tiles(batch, kTileCfg[best].tm, kTileCfg[best].tn, true);
+    batch.total_tiles = total;
+    if (total == 0) return hipSuccess;
+    batch.group_m = group_m_env ? group_m_env : kTileCfg[best].group_m;
+    batch.sk_cus = 0;
+    return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream) : launch_v3<10, 6>(batch, total, stream);
+  }
+  int total = count_tiles(batch, BM, BN, true);
+  batch.total_tiles = total;
+  if (total == 0) return hipSuccess;
+  const int group_m = group_m_env ? group_m_env : GROUP_M;
   batch.group_m = group_m;
   batch.sk_cus = 0;
-  int use = impl;
+  int use = impl == 1 ? 1 : 2;
   bool conv = false;
   for (int i = 0; i < batch.nprob; ++i) conv = conv || batch.p[i].conv_cin_tiles > 0;
   if (conv) use = 2;                                 // the implicit-conv addressing lives in the 8-phase kernel

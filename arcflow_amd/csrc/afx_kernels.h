@@ -44,6 +44,7 @@ struct GemmBatch {
 };
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
+void gemm_set_mode(int impl, int tile);      // kernel / tile-shape override of AFX_GEMM_IMPL / AFX_GEMM_TILE (see launch_gemm)
 constexpr int64_t GEMM_SK_FLAG_BYTES = 4096;                       // 1024 flag words
 constexpr int64_t GEMM_SK_SLAB_BYTES = 256ll * 256 * 256 * 4;      // 256 work-groups x one fp32 256x256 tile
 

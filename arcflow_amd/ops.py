@@ -60,6 +60,12 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return out
 
 
+def set_gemm_mode(impl: int = 3, tile: int = 0) -> None:
+    """Kernel / tile-shape override of every bf16 GEMM (``afx_gemm_set_mode``): impl 3 = one-wave-per-SIMD kernel with tile 0 = picked
+    per launch, 1 / 2 / 3 = 256x256 / 288x192 / 320x192; impl 2 = 8-phase 256x256 kernel; impl 1 = simple reference kernel."""
+    _lib.check(_lib.load().afx_gemm_set_mode(impl, tile))
+
+
 def stream_k_workspace(device='cuda') -> torch.Tensor:
     """Zero-initialised workspace for ``linear(..., sk_ws=)`` (hand-off flags + fp32 accumulator slabs of the stream-K tail)."""
     lib = _lib.load()

@@ -111,6 +111,12 @@ def cpu_baseline(budget_s: float = 12.0):
     }
 
 
+GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 8>'      # the bf16 block GEMMs of the forward (AFX_GEMM_IMPL=2: afx::gemm_kernel_v2<false>)
+if os.environ.get('AFX_GEMM_IMPL', '3')[:1] == '2':
+    GEMM_KERNEL_NAME = 'afx::gemm_kernel_v2<false>'
+POWER_CAPPED_MFMA_TF = 1950.0
+
+
 def _traffic(model):
     """HBM-side bytes per GEMM launch from the last committed PMC pass (profiles/traffic.json); bench.py cannot
     run rocprofv3 on itself, so the corrected counter value is recorded there per round, or null."""
@@ -352,11 +358,15 @@ def main(argv=None):
         if prof and gemm_n:
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
-                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else 'afx::gemm_kernel_v2<false>', 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1),
+                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else GEMM_KERNEL_NAME, 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1),
                 'unit': 'TFLOP/s', 'frac': ach / (MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1)), 'traffic': None if args.fp8 else _traffic(args.model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,
                 'share_of_step_time': gemm_ms * 1e-3 / dt,
+                # what the power cap leaves of `peak`: a loop of nothing but 16x16x32 bf16 MFMAs on random operands runs at
+                # 1.93-1.98 GHz / 1927-1984 TFLOP/s on this part (tools/gemm_trace.hip mfma_burn_rand, profiles/r02s_gemm_trace.txt)
+                'power_capped_mfma_peak': POWER_CAPPED_MFMA_TF,
+                'frac_of_power_capped_peak': ach / (POWER_CAPPED_MFMA_TF * (2 if args.fp8 else 1)),
             }
             if att_n:
                 a2 = att_fl / (att_ms * 1e-3) / 1e12

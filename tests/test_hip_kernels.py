@@ -31,8 +31,27 @@ def bf(t):
 
 
 # ------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (300, 264, 128), (77, 3072, 4096), (1000, 520, 3072), (513, 1152, 192)])
-def test_linear_plain(ops, M, N, K):
+# (impl, tile) of afx_gemm_set_mode: the one-wave-per-SIMD kernel with the tile shape picked per launch / forced to 256x256 /
+# 288x192 / 320x192, and the 8-phase 256x256 kernel.  Every mode must give the same results on the same inputs.
+GEMM_MODES = [(3, 0), (3, 1), (3, 2), (3, 3), (2, 0)]
+GEMM_MODE_IDS = ['auto', 'v3-256x256', 'v3-288x192', 'v3-320x192', '8phase']
+
+
+@pytest.fixture
+def gemm_mode(request, ops):
+    impl, tile = request.param
+    ops.set_gemm_mode(impl, tile)
+    yield request.param
+    ops.set_gemm_mode(3, 0)
+
+
+all_gemm_modes = pytest.mark.parametrize('gemm_mode', GEMM_MODES, ids=GEMM_MODE_IDS, indirect=True)
+
+
+@all_gemm_modes
+@pytest.mark.parametrize('M,N,K', [(256, 256, 64), (300, 264, 128), (77, 3072, 4096), (1000, 520, 3072), (513, 1152, 192), (640, 576, 64),
+                                   (289, 200, 192)])
+def test_linear_plain(ops, gemm_mode, M, N, K):
     g = torch.Generator().manual_seed(M + N + K)
     a = bf(torch.randn(M, K, generator=g)).to(dev())
     w = bf(torch.randn(N, K, generator=g) * 0.05).to(dev())
@@ -43,7 +62,8 @@ def test_linear_plain(ops, M, N, K):
     assert (out.float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
 
 
-def test_linear_identity_asymmetric(ops):
+@all_gemm_modes
+def test_linear_identity_asymmetric(ops, gemm_mode):
     """A = I against an asymmetric W catches row/col swaps in the MFMA -> C mapping exactly."""
     n = 512
     a = torch.eye(n, dtype=torch.bfloat16, device=dev())
@@ -52,7 +72,8 @@ def test_linear_identity_asymmetric(ops):
     assert torch.equal(out.float(), w.float().T)
 
 
-def test_linear_strided_gelu_cols(ops):
+@all_gemm_modes
+def test_linear_strided_gelu_cols(ops, gemm_mode):
     g = torch.Generator().manual_seed(5)
     M, K, N = 333, 256, 512
     big = bf(torch.randn(M, 3 * K, generator=g)).to(dev())
@@ -67,7 +88,8 @@ def test_linear_strided_gelu_cols(ops):
     assert outbuf[:, N:].abs().max().item() == 0           # nothing written past N
 
 
-def test_linear_gate_residual_inplace(ops):
+@all_gemm_modes
+def test_linear_gate_residual_inplace(ops, gemm_mode):
     g = torch.Generator().manual_seed(6)
     B, S, K, N = 2, 150, 512, 256
     a = bf(torch.randn(B * S, K, generator=g)).to(dev())
@@ -229,8 +251,9 @@ def test_arcflow_step_full_size_properties(ops):
     assert torch.allclose(a, b, rtol=1e-4, atol=1e-4)
 
 
+@all_gemm_modes
 @pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4096, 1152, 3072), (512, 9216, 3072), (4608, 3072, 15360), (2304, 21504, 3072)])
-def test_linear_full_size_vs_device_reference(ops, M, N, K):
+def test_linear_full_size_vs_device_reference(ops, gemm_mode, M, N, K):
     """Full-size shapes of the FLUX forward, checked on-device against torch's (hipBLASLt) bf16 linear,
     three launches each so a rare pipeline race (DMA landing late / restaged early) shows up."""
     g = torch.Generator(device='cuda').manual_seed(K + N)
