@@ -9,7 +9,7 @@ are dealt round-robin to the ranks, a dataset exposing ``bucket_ids`` only yield
 ``PromptEmbedCache`` reads the per-prompt files the reference's preprocessing writes
 (lakonlab/datasets/image_prompts.py:286-309,357-437): a pickled dict with ``prompt``, ``prompt_embed_kwargs``
 (``encoder_hidden_states`` + optional ``encoder_hidden_states_scale``, ``pooled_projections`` /
-``encoder_hidden_states_mask``; or the legacy top-level ``prompt_embeds*`` spelling) and ``latent_size``; ``.zst`` files need the ``zstandard`` module (absent from this image: plain ``.pkl`` / ``.pt`` work).
+``encoder_hidden_states_mask``; or the legacy top-level ``prompt_embeds*`` spelling) and ``latent_size``; ``.zst`` files are read through ``zstd_io`` (the ``zstandard`` module, or pyarrow's zstd codec).
 """
 from __future__ import annotations
 
@@ -104,12 +104,9 @@ class DistributedSampler:
 
 def _load_item(path: str):
     if path.endswith('.zst'):
-        try:
-            import zstandard
-        except ImportError as e:          # no silent fallback: the file cannot be read here
-            raise RuntimeError(f'{path}: reading .zst caches needs the zstandard module') from e
-        with open(path, 'rb') as f, zstandard.ZstdDecompressor().stream_reader(f) as r:
-            return pickle.load(io.BytesIO(r.read()))
+        from . import zstd_io
+        with open(path, 'rb') as f:                     # no silent fallback: zstd_io raises when no codec is present
+            return pickle.load(io.BytesIO(zstd_io.decompress(f.read())))
     if path.endswith('.pt'):
         return torch.load(path, map_location='cpu', weights_only=False)
     with open(path, 'rb') as f:

@@ -76,16 +76,13 @@ def write_cache(encoder: PromptEncoder, prompts: Iterable[str], out_dir: str, la
                 start_index: int = 0, compress: Optional[bool] = None) -> List[str]:
     """Encode ``prompts`` and write one item per prompt in the layout ``PromptEmbedCache`` / the reference's ``ImagePrompt``
     dataset read (image_prompts.py:357-383): a pickled dict {prompt, prompt_embed_kwargs (fp16, unpadded), latent_size}.
-    Files are ``<index>.zst`` when the zstandard module is importable (what the reference reads), else ``<index>.pkl``.
+    Files are ``<index>.zst`` (what the reference reads) when a zstd codec is present (``zstd_io``), else ``<index>.pkl``.
     Returns the datalist (file stems); also written to ``<out_dir>.jsonl``."""
-    try:
-        import zstandard
-    except ImportError:
-        zstandard = None
+    from . import zstd_io
     if compress is None:
-        compress = zstandard is not None
-    if compress and zstandard is None:
-        raise RuntimeError('compress=True needs the zstandard module')
+        compress = zstd_io.available()
+    if compress and not zstd_io.available():
+        raise RuntimeError('compress=True needs the zstandard module or pyarrow with the zstd codec')
     os.makedirs(out_dir, exist_ok=True)
     names: List[str] = []
     buf: List[str] = []
@@ -109,7 +106,7 @@ def write_cache(encoder: PromptEncoder, prompts: Iterable[str], out_dir: str, la
             raw = pickle.dumps(item, protocol=pickle.HIGHEST_PROTOCOL)
             if compress:
                 with open(os.path.join(out_dir, stem + '.zst'), 'wb') as f:
-                    f.write(zstandard.ZstdCompressor(level=3).compress(raw))
+                    f.write(zstd_io.compress(raw, level=3))
             else:
                 with open(os.path.join(out_dir, stem + '.pkl'), 'wb') as f:
                     f.write(raw)

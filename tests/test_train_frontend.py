@@ -120,6 +120,42 @@ def test_prompt_cache_items_and_collate(tmp_path):
         DATA.collate([a, ds[2]], device='cpu')
 
 
+def test_prompt_cache_reads_and_writes_zstd_items(tmp_path):
+    """The reference's cache items are zstd-compressed pickles (image_prompts.py:357-383: `<stem>.zst`).  This image has no
+    `zstandard` module; `zstd_io` goes through pyarrow's zstd codec.  Checked: a standard frame written here reads back, a
+    frame with an UNKNOWN content size (what a streaming writer such as the reference's produces) reads back, the dataset
+    loads `.zst` files, and `write_cache` emits them."""
+    from arcflow_amd.train import zstd_io
+    assert zstd_io.available()
+    blob = b'prompt cache ' * 1000
+    assert zstd_io.decompress(zstd_io.compress(blob)) == blob
+    # zstd frame of the 3 bytes b'abc' without a content-size field: magic, frame header 0x00 0x58 (single segment off, window
+    # descriptor), one raw last block (header 0x19 0x00 0x00 = last, raw, size 3) -- hand-assembled from RFC 8878
+    frame = bytes.fromhex('28b52ffd' '00' '58' '190000') + b'abc'
+    assert zstd_io.decompress(frame) == b'abc'
+    assert zstd_io.decompress(frame + zstd_io.compress(b'def')) == b'abcdef'          # concatenated frames
+    g = torch.Generator().manual_seed(3)
+    e, p = torch.randn(5, 32, generator=g).half(), torch.randn(16, generator=g).half()
+    item = dict(prompt='a cat', prompt_embed_kwargs=dict(encoder_hidden_states=e, pooled_projections=p), latent_size=(16, 8, 8))
+    with open(tmp_path / '0000.zst', 'wb') as f:
+        f.write(zstd_io.compress(pickle.dumps(item)))
+    ds = DATA.PromptEmbedCache(str(tmp_path), pad_seq_len=6)
+    assert len(ds) == 1 and ds[0]['name'] == 'a cat'
+    assert torch.equal(ds[0]['prompt_embed_kwargs']['encoder_hidden_states'][:5], e.float())
+
+    class Enc:          # the PromptEncoder surface write_cache uses
+        def encode(self, prompts):
+            n = len(prompts)
+            return dict(encoder_hidden_states=torch.ones(n, 4, 8), pooled_projections=torch.ones(n, 3))
+
+    from arcflow_amd.train.prompts import write_cache
+    out = tmp_path / 'written'
+    names = write_cache(Enc(), ['x', 'y', 'z'], str(out), latent_size=(16, 8, 8), batch=2)
+    assert names == ['00000000', '00000001', '00000002'] and sorted(os.listdir(out)) == [n + '.zst' for n in names]
+    ds2 = DATA.PromptEmbedCache(str(out))
+    assert len(ds2) == 3 and ds2[2]['name'] == 'z' and ds2[2]['prompt_embed_kwargs']['encoder_hidden_states'].shape == (4, 8)
+
+
 def test_prompt_cache_negative_embeds_mask_truncation_and_size_index(tmp_path):
     """(medium) a --data-dir cache must deliver negative_prompt_embeds for the true-CFG (Qwen) teacher; (low) masks
     truncate the text to the longest real length of the batch (arcqwen.py:325-330); (low) the bucket sizes come from an index."""
