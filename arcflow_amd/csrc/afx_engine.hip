@@ -342,7 +342,29 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     return fail(AFX_E_INVALID, "null argument to afx_mmdit_forward");
   if (!c->finalized) return fail(AFX_E_MISSING, "afx_finalize() has not succeeded on this context");
   const afx_model_desc& d = c->d;
-  if (B < 1 || B > 4 || N < 1 || T < 1) return fail(AFX_E_INVALID, "bad shape: batch must be 1..4, N,T >= 1");
+  if (B < 1 || N < 1 || T < 1) return fail(AFX_E_INVALID, "bad shape: batch, N, T >= 1");
+  if (B > AFX_MAX_MICRO_BATCH) {
+    // A grouped launch holds 2 problems per sample (GEMM_MAX_PROBLEMS = 8) and the workspace is carved for 4 samples: larger
+    // batches run as micro-batches of 4 on the same stream (samples are independent: the reference's batch dimension,
+    // arcflux.py:134-257, has no cross-sample op).  The staged (training) calls keep one micro-batch per call.
+    if (stage != 0 || c->ckpt) return fail(AFX_E_INVALID, "staged / checkpointed forward: batch must be 1..4 per call");
+    const int64_t K = d.num_gaussians, Cc = d.in_channels, lw = d.logweights_channels;
+    for (int b0 = 0; b0 < B; b0 += AFX_MAX_MICRO_BATCH) {
+      const int nb = B - b0 < AFX_MAX_MICRO_BATCH ? B - b0 : AFX_MAX_MICRO_BATCH;
+      const uint16_t* xb = (const uint16_t*)x + (int64_t)b0 * N * Cc;
+      const uint16_t* cb = (const uint16_t*)ctx_emb + (int64_t)b0 * T * d.joint_dim;
+      const uint16_t* pb = pooled ? (const uint16_t*)pooled + (int64_t)b0 * d.pooled_dim : nullptr;
+      uint16_t* mb = (uint16_t*)means + (int64_t)b0 * N * (d.head_mode == 0 ? K * Cc : Cc);
+      uint16_t* wb = logw ? (uint16_t*)logw + (int64_t)b0 * N * K * lw : nullptr;
+      uint16_t* gb_ = logg ? (uint16_t*)logg + (int64_t)b0 * N * (K - 1) * lw : nullptr;
+      const float* temb_all = c->temb_override;
+      if (temb_all) c->temb_override = temb_all + (int64_t)b0 * c->D;
+      const int rc = afx_mmdit_forward_stage(c, xb, cb, pb, t + b0, g ? g + b0 : nullptr, rope_cos, rope_sin, nb, N, T, mb, wb, gb_, 0, stream_);
+      c->temb_override = temb_all;
+      if (rc != AFX_OK) return rc;
+    }
+    return AFX_OK;
+  }
   if (d.guidance_embeds && !g) return fail(AFX_E_INVALID, "guidance vector required");
   if (d.pooled_dim > 0 && !pooled) return fail(AFX_E_INVALID, "pooled projections required");
   if (d.head_mode == 0 && (!logw || !logg)) return fail(AFX_E_INVALID, "logw/logg outputs required");

@@ -162,15 +162,8 @@ class MMDiTEngine:
         if height_tokens is None:
             height_tokens = width_tokens = int(round(N ** 0.5))
         assert height_tokens * width_tokens == N, 'pass height_tokens/width_tokens for non-square latents'
-        if B > 4:   # the grouped launches hold 2 problems per sample
+        if B > 4:   # the library runs micro-batches of 4 (2 problems per sample in a grouped launch); staged calls do not
             assert stage == 0, 'staged forwards take at most 4 samples'
-            outs = [self.forward(hidden_states[i:i + 4], timestep[i:i + 4], encoder_hidden_states[i:i + 4],
-                                 None if pooled_projections is None else pooled_projections[i:i + 4],
-                                 None if guidance is None else guidance[i:i + 4], height_tokens, width_tokens)
-                    for i in range(0, B, 4)]
-            if self.teacher_head:
-                return torch.cat(outs)
-            return ArcFlowModelOutput(*[torch.cat([getattr(o, k) for o in outs]) for k in ('means', 'logweights', 'loggammas')])
         dev = self.device
         x = hidden_states.to(dev, torch.bfloat16).contiguous()
         ctx = encoder_hidden_states.to(dev, torch.bfloat16).contiguous()
@@ -178,7 +171,7 @@ class MMDiTEngine:
         g = None if guidance is None else guidance.to(dev, torch.float32).expand(B).contiguous()
         pooled = None if pooled_projections is None else pooled_projections.to(dev, torch.bfloat16).contiguous()
         cos, sin = self.rope_tables(height_tokens, width_tokens, T)
-        self._workspace(B, N, T)
+        self._workspace(min(B, 4), N, T)
         K, L = self.num_gaussians, self.logweights_channels
         if self.teacher_head:
             means = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=dev)

@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define AFX_OK 0
+#define AFX_MAX_MICRO_BATCH 4  /* samples per grouped launch: afx_mmdit_forward splits larger batches itself; staged calls take <= 4 */
 #define AFX_E_INVALID (-1)     /* bad argument / shape */
 #define AFX_E_MISSING (-2)     /* a required weight is not bound */
 #define AFX_E_WORKSPACE (-3)   /* workspace missing or too small */

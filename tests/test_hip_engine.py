@@ -21,14 +21,15 @@ def _inputs(B, hp, wp, T, joint, pooled_dim, seed=1):
     return hid, ctx, pooled
 
 
-@pytest.mark.parametrize('B,hp,wp,T,nd,ns', [(1, 8, 8, 16, 2, 2), (2, 6, 10, 7, 1, 3), (1, 16, 16, 77, 1, 0)])
+@pytest.mark.parametrize('B,hp,wp,T,nd,ns', [(1, 8, 8, 16, 2, 2), (2, 6, 10, 7, 1, 3), (1, 16, 16, 77, 1, 0),
+                                             (6, 4, 4, 5, 1, 1)])      # batch 6: two micro-batches (4 + 2) inside the library
 def test_flux_forward_vs_oracle(B, hp, wp, T, nd, ns):
     from arcflow_amd import MMDiTEngine
     from oracle import dit_ref as D
     cfg = D.FluxCfg(num_layers=nd, num_single_layers=ns, heads=2, joint_dim=128, pooled_dim=64)
     w = D.make_flux_weights(cfg, seed=3)
     hid, ctx, pooled = _inputs(B, hp, wp, T, 128, 64)
-    t = torch.tensor([1.0, 0.7619][:B])
+    t = torch.tensor([1.0, 0.7619, 0.5, 0.3, 0.9, 0.1][:B])
     gd = torch.full((B,), 3.5)
     rm, rlw, rlg = D.flux_forward(w, cfg, hid.float(), ctx.float(), pooled.float(), t, gd, hp, wp)
     eng = MMDiTEngine('flux', nd, ns, heads=2, joint_dim=128, pooled_dim=64)
