@@ -30,7 +30,7 @@ EXPORTS = [
     'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override', 'afx_set_fp8_linear',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
     'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward',
-    'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
+    'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_adamw8bit_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
 ]
 
 
@@ -141,6 +141,7 @@ def load() -> C.CDLL:
     lib.afx_mmdit_export.argtypes = [vp, C.c_char_p, vp, i32, i32, i32, vp]
     lib.afx_sumsq.argtypes = [vp, vp, i64, vp]
     lib.afx_adamw_step.argtypes = [vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i64, vp]
+    lib.afx_adamw8bit_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32, i64, vp]
     lib.afx_ema_lerp.argtypes = [vp, vp, f32, i64, vp]
     lib.afx_cast_f32_bf16.argtypes = [vp, vp, i64, vp]
     for name in EXPORTS:

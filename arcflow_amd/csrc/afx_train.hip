@@ -194,6 +194,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   p[i] = pi;
 }
 
+// AdamW with block-wise 8-bit moments (the reference trains with bitsandbytes AdamW8bit: lakonlab/configs/flux/_ddp_train.py:18-26,
+// lakonlab/runner/optimizer/builder.py:11-24).  bitsandbytes is absent from /root/reference (unpinned third-party dependency):
+// this restates its published block-wise scheme -- each block of 256 values stores one fp32 absmax and 256 one-byte codes into a
+// 256-entry "dynamic" code book (signed for exp_avg, unsigned for exp_avg_sq; arcflow_amd/ops.py dynamic_map); a step dequantises,
+// applies the fp32 AdamW recurrences above, updates the parameter from the UNquantised new moments, and stores the moments
+// re-quantised to the nearest code against the block's new absmax.  One work-group = one block, one value per lane.
+AFX_DEV int nearest_code(const float* __restrict__ qmap, float x) {
+  // qmap is sorted ascending over 256 entries: binary search for the insertion point, then the nearer neighbour
+  int lo = 0, hi = 255;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int mid = (lo + hi) >> 1;
+    if (qmap[mid] < x) lo = mid + 1; else hi = mid;
+  }
+  if (lo > 0 && x - qmap[lo - 1] <= qmap[lo] - x) --lo;
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void adamw8bit_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        uint8_t* __restrict__ c1, uint8_t* __restrict__ c2,
+                                                        float* __restrict__ absmax1, float* __restrict__ absmax2,
+                                                        const float* __restrict__ qmap1, const float* __restrict__ qmap2, float lr,
+                                                        float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                        float gscale, int64_t n) {
+  __shared__ float q1[256], q2[256], red[2][4];
+  const int tid = threadIdx.x;
+  q1[tid] = qmap1[tid];
+  q2[tid] = qmap2[tid];
+  __syncthreads();
+  const int64_t blk = blockIdx.x, i = blk * 256 + tid;
+  const bool on = i < n;
+  float mi = 0.f, vi = 0.f, gi = 0.f;
+  if (on) {
+    gi = g[i] * gscale;
+    mi = b1 * (q1[c1[i]] * absmax1[blk]) + (1.0f - b1) * gi;
+    vi = b2 * (q2[c2[i]] * absmax2[blk]) + (1.0f - b2) * gi * gi;
+  }
+  float a1 = fabsf(mi), a2 = vi;                     // block maxima (v >= 0)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a1 = fmaxf(a1, __shfl_xor(a1, o, 64));
+    a2 = fmaxf(a2, __shfl_xor(a2, o, 64));
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = a1; red[1][tid >> 6] = a2; }
+  __syncthreads();
+  a1 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  a2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  if (tid == 0) { absmax1[blk] = a1; absmax2[blk] = a2; }
+  if (!on) return;
+  c1[i] = (uint8_t)nearest_code(q1, a1 > 0.f ? mi / a1 : 0.f);
+  c2[i] = (uint8_t)nearest_code(q2, a2 > 0.f ? vi / a2 : 0.f);
+  float pi = p[i] * (1.0f - lr * wd);
+  pi -= lr * (mi / bc1) / (sqrtf(vi / bc2) + eps);
+  p[i] = pi;
+}
+
 // ema = net + (ema - net) * beta        (mmgen lerp; lakonlab/runner/hooks/ema_hook.py:118-124)
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ net, float beta,
                                                   int64_t n) {
@@ -533,6 +589,19 @@ int afx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq,
                      lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_adamw8bit_step(float* param, const float* grad, void* state1, void* state2, float* absmax1, float* absmax2,
+                       const float* qmap1, const float* qmap2, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int32_t step, float grad_scale, int64_t n, void* stream) {
+  if (!param || !grad || !state1 || !state2 || !absmax1 || !absmax2 || !qmap1 || !qmap2 || n < 0 || step < 1)
+    return fail(AFX_E_INVALID, "bad argument to afx_adamw8bit_step");
+  if (n == 0) return AFX_OK;
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw8bit_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad, (uint8_t*)state1,
+                     (uint8_t*)state2, absmax1, absmax2, qmap1, qmap2, lr, beta1, beta2, eps, weight_decay, bc1, bc2, grad_scale, n);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -396,6 +396,67 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, lr, step, betas=(0.9, 0.95), ep
                                   weight_decay, step, grad_scale, param.numel(), _s()))
 
 
+def dynamic_map(signed: bool = True, max_exponent_bits: int = 7, total_bits: int = 8) -> torch.Tensor:
+    """The 256-entry "dynamic" 8-bit code book of bitsandbytes' block-wise optimizers (functional.create_dynamic_map; bitsandbytes
+    is an unvendored, unpinned dependency of the reference -- requirements.txt:11 -- so this restates its published construction):
+    for every exponent i the interval [0.1, 1] * 10^(i - 6) is cut into 2^i (signed) or 2^(i+1) (unsigned) equal cells whose
+    midpoints are codes (mirrored when signed), plus 0 and 1; sorted ascending.  Signed for exp_avg, unsigned for exp_avg_sq."""
+    data = []
+    non_sign_bits = total_bits - 1
+    additional_items = 2 ** (non_sign_bits - max_exponent_bits) - 1
+    i = 0
+    for i in range(max_exponent_bits):
+        fraction_items = int(2 ** (i + non_sign_bits - max_exponent_bits) + 1 if signed else 2 ** (i + non_sign_bits - max_exponent_bits + 1) + 1)
+        boundaries = torch.linspace(0.1, 1, fraction_items, dtype=torch.float64)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    if additional_items > 0:
+        boundaries = torch.linspace(0.1, 1, additional_items + 1, dtype=torch.float64)
+        means = (boundaries[:-1] + boundaries[1:]) / 2.0
+        data += ((10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+        if signed:
+            data += (-(10 ** (-(max_exponent_bits - 1) + i)) * means).tolist()
+    data += [0.0, 1.0]
+    assert len(data) == 2 ** total_bits, len(data)
+    return torch.tensor(sorted(data), dtype=torch.float32)
+
+
+class AdamW8bitState:
+    """Block-wise 8-bit moments of ``n`` values: code bytes + one absmax per block of 256 (zero absmax = zero moments)."""
+    BLOCK = 256
+
+    def __init__(self, n: int, device):
+        nb = (n + self.BLOCK - 1) // self.BLOCK
+        self.n = n
+        self.state1 = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.state2 = torch.zeros(n, dtype=torch.uint8, device=device)
+        self.absmax1 = torch.zeros(nb, dtype=torch.float32, device=device)
+        self.absmax2 = torch.zeros(nb, dtype=torch.float32, device=device)
+        self.qmap1 = dynamic_map(True).to(device)
+        self.qmap2 = dynamic_map(False).to(device)
+
+    def moments(self):
+        """Dequantised (exp_avg, exp_avg_sq) -- for tests and checkpoint conversion."""
+        rep = lambda a: a.repeat_interleave(self.BLOCK)[:self.n]   # noqa: E731
+        return self.qmap1[self.state1.long()] * rep(self.absmax1), self.qmap2[self.state2.long()] * rep(self.absmax2)
+
+    def state_dict(self):
+        return {k: getattr(self, k).detach().cpu() for k in ('state1', 'state2', 'absmax1', 'absmax2')}
+
+    def load_state_dict(self, sd):
+        for k in ('state1', 'state2', 'absmax1', 'absmax2'):
+            getattr(self, k).copy_(sd[k])
+
+
+def adamw8bit_step(param, grad, st: AdamW8bitState, lr, step, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    lib = _lib.load()
+    assert param.numel() == st.n
+    _lib.check(lib.afx_adamw8bit_step(_p(param), _p(grad), _p(st.state1), _p(st.state2), _p(st.absmax1), _p(st.absmax2), _p(st.qmap1),
+                                      _p(st.qmap2), lr, betas[0], betas[1], eps, weight_decay, step, grad_scale, param.numel(), _s()))
+
+
 def ema_lerp(ema, net, beta: float):
     lib = _lib.load()
     _lib.check(lib.afx_ema_lerp(_p(ema), _p(net), beta, ema.numel(), _s()))

@@ -107,7 +107,11 @@ def build_checkpoint(distiller, fp16: bool = True, fp16_ema: bool = False, save_
     m = dict(meta or {})
     m.update(iter=distiller.iteration, epoch=1, time=time.asctime(), writer='arcflow_amd')
     ckpt = {'meta': m, 'state_dict': state}
-    if save_optimizer:
+    if save_optimizer and getattr(distiller, 'exp_avg', None) is None:       # adamw8bit: per learning-rate group, codes + block absmax
+        ckpt['optimizer'] = {'diffusion': {'format': 'arcflow_amd.flat_adamw8bit', 'step': distiller.opt_steps,
+                                           'groups8': {k: st.state_dict() for k, st in distiller.opt8.items()},
+                                           'groups32': {k: (m.detach().cpu(), v.detach().cpu()) for k, (m, v) in distiller._small.items()}}}
+    elif save_optimizer:
         ckpt['optimizer'] = {'diffusion': {'format': 'arcflow_amd.flat_adamw', 'step': distiller.opt_steps,
                                            'exp_avg': distiller.exp_avg.detach().cpu(), 'exp_avg_sq': distiller.exp_avg_sq.detach().cpu()}}
     return ckpt
@@ -147,7 +151,22 @@ def load_checkpoint(distiller, path: str, strict: bool = True) -> dict:
     if extra:
         warnings.warn(f'{len(extra)} checkpoint tensors are not trained by this engine and were skipped: {extra[:4]}')
     opt = (ckpt.get('optimizer') or {}).get('diffusion')
-    if isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw' and opt['exp_avg'].numel() == distiller.params.numel():
+    if getattr(distiller, 'exp_avg', None) is None:                          # adamw8bit distiller
+        from .. import ops
+        distiller.opt8.clear()
+        distiller._small.clear()
+        distiller.opt_steps = 0
+        if isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw8bit':
+            for (a, b), sd in opt['groups8'].items():
+                st = ops.AdamW8bitState(b - a, distiller.device)
+                st.load_state_dict(sd)
+                distiller.opt8[(a, b)] = st
+            for k, (m, v) in opt['groups32'].items():
+                distiller._small[k] = (m.to(distiller.device), v.to(distiller.device))
+            distiller.opt_steps = int(opt['step'])
+        elif 'optimizer' in ckpt:
+            warnings.warn('optimizer state is not this engine\'s 8-bit format: moments restart at zero')
+    elif isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw' and opt['exp_avg'].numel() == distiller.params.numel():
         distiller.exp_avg.copy_(opt['exp_avg'])
         distiller.exp_avg_sq.copy_(opt['exp_avg_sq'])
         distiller.opt_steps = int(opt['step'])

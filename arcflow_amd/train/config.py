@@ -87,6 +87,7 @@ def distill_setup(cfg: Dict[str, Any]) -> Tuple[str, Dict[str, Any], DistillConf
         guidance=tc.get('distilled_guidance_scale', 3.5), teacher_guidance=tc.get('teacher_distilled_guidance_scale'),
         teacher_guidance_scale=tc.get('teacher_guidance_scale', 1.0),
         lr=opt.get('lr', 1e-4), betas=tuple(opt.get('betas', (0.9, 0.999))), weight_decay=opt.get('weight_decay', 0.0),
+        optimizer='adamw8bit' if opt.get('type') == 'AdamW8bit' else 'adamw',       # optimizer/builder.py:11-24 registers bnb's class
         loggamma_lr_mult=mults.get('proj_out_loggamma', {}).get('lr_mult', 1.0),
         warmup_iters=lr_cfg.get('warmup_iters', 0), warmup_ratio=lr_cfg.get('warmup_ratio', 1.0),
         grad_clip=tc.get('diffusion_grad_clip', 0.0), grad_clip_begin_iter=tc.get('diffusion_grad_clip_begin_iter', 0),

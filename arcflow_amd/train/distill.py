@@ -53,6 +53,8 @@ class DistillConfig:
     lr: float = 1e-4
     betas: tuple = (0.9, 0.95)
     weight_decay: float = 0.0
+    optimizer: str = 'adamw'          # 'adamw': fp32 moments (the pinned math); 'adamw8bit': block-wise 8-bit moments as the
+                                      # reference's bitsandbytes AdamW8bit keeps them (_ddp_train.py:18-26), groups < 4096 values stay fp32
     loggamma_lr_mult: float = 0.1
     warmup_iters: int = 100
     warmup_ratio: float = 0.001
@@ -116,8 +118,15 @@ class ArcFlowDistiller:
         self._view(self.params, 1).copy_(packed['head.bias'].float())
         self._view(self.params, 2).copy_(no_w.flatten())
         self._view(self.params, 3).copy_(no_b)
-        self.exp_avg = torch.zeros_like(self.params)
-        self.exp_avg_sq = torch.zeros_like(self.params)
+        if cfg.optimizer not in ('adamw', 'adamw8bit'):
+            raise ValueError(f'optimizer must be adamw or adamw8bit, got {cfg.optimizer!r}')
+        self.opt8 = {}                                 # (a, b) -> ops.AdamW8bitState of that learning-rate group (adamw8bit)
+        if cfg.optimizer == 'adamw8bit':               # fp32 moments only for the groups bitsandbytes keeps in 32 bit (< 4096 values)
+            self.exp_avg = self.exp_avg_sq = None
+            self._small = {}
+        else:
+            self.exp_avg = torch.zeros_like(self.params)
+            self.exp_avg_sq = torch.zeros_like(self.params)
         self.ema = self.params.clone()
         self.grad = torch.zeros_like(self.params)      # ONE buffer: both student steps accumulate into it
         self.grads = [self.grad]                       # (kept for callers that index the summed gradient as grads[0])
@@ -409,7 +418,21 @@ class ArcFlowDistiller:
                       (hb, hb + n2, lr), (hb + n2, self._off[2], lr * c.loggamma_lr_mult),
                       (self._off[2], self.params.numel(), lr)]
             for a, b, glr in groups:
-                ops.adamw_step(self.params[a:b], g[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b], glr, self.opt_steps,
+                if b <= a:
+                    continue
+                if c.optimizer == 'adamw8bit' and b - a >= 4096:       # bitsandbytes min_8bit_size
+                    if (a, b) not in self.opt8:
+                        self.opt8[(a, b)] = ops.AdamW8bitState(b - a, self.device)
+                    ops.adamw8bit_step(self.params[a:b], g[a:b], self.opt8[(a, b)], glr, self.opt_steps, betas=c.betas,
+                                       weight_decay=c.weight_decay, grad_scale=scale)
+                    continue
+                if c.optimizer == 'adamw8bit':
+                    if (a, b) not in self._small:
+                        self._small[(a, b)] = (torch.zeros(b - a, device=self.device), torch.zeros(b - a, device=self.device))
+                    m_, v_ = self._small[(a, b)]
+                else:
+                    m_, v_ = self.exp_avg[a:b], self.exp_avg_sq[a:b]
+                ops.adamw_step(self.params[a:b], g[a:b], m_, v_, glr, self.opt_steps,
                                betas=c.betas, weight_decay=c.weight_decay, grad_scale=scale)
             self._sync_working_copies()
             if self.trunk is not None:

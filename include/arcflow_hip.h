@@ -244,6 +244,13 @@ int afx_add_scale_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, c
 int afx_sumsq(const float* x, float* out_accum, int64_t n, void* stream);
 int afx_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, float grad_scale, int64_t n, void* stream);
+/* The same update with block-wise 8-bit moments (the reference's optimizer is bitsandbytes AdamW8bit: _ddp_train.py:18-26,
+ * optimizer/builder.py:11-24): state1 / state2 hold one code byte per value, absmax1 / absmax2 one f32 per block of 256 values
+ * (ceil(n / 256) entries), qmap1 (signed) / qmap2 (unsigned) the 256-entry sorted code books (arcflow_amd/ops.py dynamic_map).
+ * Zero-initialised absmax + any codes = zero moments.  The parameter is updated from the new moments BEFORE they are re-quantised. */
+int afx_adamw8bit_step(float* param, const float* grad, void* state1, void* state2, float* absmax1, float* absmax2,
+                       const float* qmap1, const float* qmap2, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int32_t step, float grad_scale, int64_t n, void* stream);
 int afx_ema_lerp(float* ema, const float* net, float beta, int64_t n, void* stream);
 int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 

@@ -67,11 +67,11 @@ def test_qwen_layout_skips_last_txt_mlp():
     assert not any(n.startswith('transformer_blocks.2.txt_mlp') for n in names)     # arcqwen_2nfe_k16.py:52-56 range(59)
 
 
-def _tiny_distiller(lora_rank=64):
+def _tiny_distiller(lora_rank=64, optimizer='adamw'):
     from arcflow_amd.train import ArcFlowDistiller, DistillConfig
     from tests.test_distill import _setup
     cfg, w = _setup()
-    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=0, ema_start_iter=0, lora_rank=lora_rank)
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=0, ema_start_iter=0, lora_rank=lora_rank, optimizer=optimizer)
     return ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc), w
 
 
@@ -106,6 +106,38 @@ def test_checkpoint_resume_is_exact(tmp_path):
     assert abs(float(ia['loss']) - float(ib['loss'])) <= 1e-6 * max(1.0, abs(float(ia['loss'])))
     for k, v in CK.flat_to_state(a.params, lay).items():
         assert torch.allclose(v, CK.flat_to_state(b.params, lay)[k], rtol=0, atol=1e-7), k
+
+
+@pytest.mark.gpu
+def test_adamw8bit_distiller_first_step_equals_fp32_and_resumes_exactly(tmp_path):
+    """`optimizer='adamw8bit'` (the reference's bitsandbytes class, _ddp_train.py:18-26): block-wise 8-bit moments for the groups of
+    >= 4096 values, fp32 for the small ones.  The parameter update uses the un-quantised new moments, so the FIRST step from
+    zero moments equals the fp32 optimizer to the last bits; later steps differ by the quantisation of the carried moments; the 8-bit
+    state survives a checkpoint round trip exactly."""
+    a, _ = _tiny_distiller(optimizer='adamw8bit')
+    f, _ = _tiny_distiller(optimizer='adamw')
+    ra, rf = (torch.Generator(device='cuda').manual_seed(5) for _ in range(2))
+    a.train_step(_cond(), 2, rng=ra)
+    f.train_step(_cond(), 2, rng=rf)
+    assert a.exp_avg is None and a.opt8 and all(b - a_ >= 4096 for a_, b in a.opt8) and all(b - a_ < 4096 for a_, b in a._small)
+    assert torch.allclose(a.params, f.params, rtol=0, atol=1e-7)        # (gradients of two runs differ by ~1e-10: atomics)
+    a.train_step(_cond(seed=6), 2, rng=ra)
+    f.train_step(_cond(seed=6), 2, rng=rf)
+    d = float((a.params - f.params).norm() / (f.params - _tiny_distiller()[0].params).norm())
+    assert 0 < d < 0.1, d            # second step: same direction, a few % apart (moments carried in 8 bits)
+    st_bytes = sum(s.state1.numel() + s.state2.numel() + 4 * (s.absmax1.numel() + s.absmax2.numel()) for s in a.opt8.values())
+    assert st_bytes < 0.26 * 8 * sum(b - a_ for a_, b in a.opt8)                # 2 B + 2 x 4 B / 256 per value against 8 B
+    path = CK.save_checkpoint(a, str(tmp_path), fp16=False)
+    assert torch.load(path, map_location='cpu', weights_only=False)['optimizer']['diffusion']['format'] == 'arcflow_amd.flat_adamw8bit'
+    b, _ = _tiny_distiller(optimizer='adamw8bit')
+    CK.load_checkpoint(b, path)
+    assert b.opt_steps == a.opt_steps == 2 and set(b.opt8) == set(a.opt8)
+    for k in a.opt8:
+        assert torch.equal(a.opt8[k].state1, b.opt8[k].state1) and torch.equal(a.opt8[k].absmax2, b.opt8[k].absmax2)
+    r1, r2 = (torch.Generator(device='cuda').manual_seed(9) for _ in range(2))
+    a.train_step(_cond(seed=4), 2, rng=r1)
+    b.train_step(_cond(seed=4), 2, rng=r2)
+    assert torch.allclose(a.params, b.params, rtol=0, atol=1e-7)
 
 
 @pytest.mark.gpu
