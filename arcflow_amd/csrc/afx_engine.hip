@@ -473,8 +473,11 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     return AFX_OK;
   };
   // helper: one grouped GEMM over the image and text row ranges of every sample
+  // q / k RMSNorm + RoPE inside the epilogue of the k|v|q projections (GemmProblem::qk_D) when the GEMM kernel in use offers it:
+  // the separate launch then only transposes V.  Not in fp8 mode (that kernel has no such epilogue).
+  const bool qk_fuse = gemm_qk_fusion_available() && !c->fp8;
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
-                         int blk, int gate_chunk) -> int {
+                         int blk, int gate_chunk, const float* qkn = nullptr) -> int {
     GemmBatch gb{};
     if (c->fp8) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
     for (int b = 0; b < B; ++b)
@@ -491,6 +494,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         p.C = C + row0 * ldc; p.ldc = ldc;
         p.M = (s == 0 ? N : T); p.N = Nout; p.K = K;
         p.epi = epi; p.gelu_col0 = 0;
+        if (qkn != nullptr) {           // [img_q, img_k, txt_q, txt_k][128]
+          p.qk_D = (int)D; p.qk_wq = qkn + (s == 0 ? 0 : 2) * 128; p.qk_wk = qkn + (s == 0 ? 1 : 3) * 128;
+          p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_row0 = (s == 0 ? T : 0); p.rope_period = 1 << 30; p.rope_rows = (int)S;
+        }
         if (epi == EPI_GATE_RES) {
           p.gate = ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, gate_chunk); p.ldg = 0; p.rows_per_batch = 1 << 30;
           p.res = C + row0 * ldc; p.ldr = ldc;
@@ -529,13 +536,15 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if ((rc = join_side(i))) return rc;
     if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     if ((rc = stream_norm(i, 0, 1))) return rc;
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr))) return rc;
     // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
     if (dbg_oldprep) {
       HIP_TRY(launch_qk_norm_rope2(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn + 0 * 128, rope_cos,
                                    rope_sin, B, S, T, H, st));
       HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
-    } else
+    } else if (qk_fuse)
+      HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
+    else
     HIP_TRY(launch_kv_prep(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn, rope_cos, rope_sin, T, QKV + D,
                            3 * D, ws.Vt, B, H, S, st));
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
@@ -564,12 +573,18 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));
       f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = bw.fused.wscale;
     }
+    if (qk_fuse) {                      // [q, k][128]; the joint rows of every sample: position = row % S
+      f.qk_D = (int)D; f.qk_wq = qkn; f.qk_wk = qkn + 128;
+      f.rope_cos = rope_cos; f.rope_sin = rope_sin; f.rope_row0 = 0; f.rope_period = (int)S; f.rope_rows = (int)S;
+    }
     gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
     if (dbg_oldprep) {
       HIP_TRY(launch_qk_norm_rope2(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));
       HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
-    } else
+    } else if (qk_fuse)
+      HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
+    else
     HIP_TRY(launch_kv_prep(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, T, ws.F + D, 7 * D, ws.Vt, B,
                            H, S, st));
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);

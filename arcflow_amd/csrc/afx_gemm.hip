@@ -148,10 +148,16 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<T*>(((uintptr_t)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
 
-template <int EPI, int MI, int NJ>
+// SWAP: pair the column tiles with v_permlane16_swap so that a lane owns 8 consecutive columns (16-byte accesses, 64 contiguous
+// bytes per row and instruction) -- or not: 4 consecutive columns per lane straight from the C^T accumulator, 8-byte accesses,
+// twice the memory instructions but no cross-lane exchange in the dependency chain (the one-wave-per-SIMD kernel has no partner
+// wave to hide that chain's latency behind).
+template <int EPI, int MI, int NJ, bool SWAP>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
-  constexpr int NP = NJ / 2;     // column-tile pairs
+  constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
+  constexpr int NS = SWAP ? NJ / 2 : NJ;       // steps per row tile
   constexpr uint32_t OOB = 0x80000000u;        // a byte offset past every buffer below: the hardware drops the access
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
   const int M = P.M, N = P.N;
   // Raw buffer descriptors over the wave's MI*16 rows of C / the residual (num_records = the rows that exist): rows >= M and
   // masked columns fall outside and are dropped / read as zero by the bounds check -- no exec-mask branch per step, so the whole
@@ -176,90 +182,124 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     rg_ = uniform_rsrc(const_cast<float*>(P.gate), has_gate ? (int)(((nb - 1) * P.ldg + N) * 4) : 0);   // (ldg may be 0: one gate row)
   }
   const int gelu_col0 = EPI == EPI_GELU ? P.gelu_col0 : 0;
-  int gcol[NP];
-  uint32_t coff[NP];             // byte offset of the lane's 8 columns in a bf16 row, or OOB
-  float bias[NP][8];
+  int gcol[NS];
+  uint32_t coff[NS];             // byte offset of the lane's CW columns in a bf16 row, or OOB
+  float bias[NS][CW];
   const uint16_t* const biasp = P.bias;
 #pragma unroll
-  for (int jp = 0; jp < NP; ++jp) {
-    gcol[jp] = col_base + (2 * jp + (fq & 1)) * 16 + (fq >> 1) * 8;
-    const bool col_ok = gcol[jp] < N;
-    coff[jp] = col_ok ? (uint32_t)gcol[jp] * 2u : OOB;
+  for (int st = 0; st < NS; ++st) {
+    gcol[st] = SWAP ? col_base + (2 * st + (fq & 1)) * 16 + (fq >> 1) * 8 : col_base + st * 16 + fq * 4;
+    const bool col_ok = gcol[st] < N;
+    coff[st] = col_ok ? (uint32_t)gcol[st] * 2u : OOB;
 #ifdef AFX_GEMM_TRACE
-    if (EPI == EPI_NONE && P.gelu_col0 == -12345) coff[jp] = OOB;     // tools/gemm_trace.hip TRACE_NOSTORE: epilogue without write traffic
+    if (EPI == EPI_NONE && P.gelu_col0 == -12345) coff[st] = OOB;     // tools/gemm_trace.hip TRACE_NOSTORE: epilogue without write traffic
 #endif
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bias[jp][e] = 0.f;
-    if (biasp != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[jp]), bias[jp]);
+    for (int e = 0; e < CW; ++e) bias[st][e] = 0.f;
+    if (biasp != nullptr && col_ok) {
+      if constexpr (SWAP) {
+        unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[st]), bias[st]);
+      } else {
+        const u32x2_t w = *reinterpret_cast<const u32x2_t*>(biasp + gcol[st]);
+        bias[st][0] = __uint_as_float(w[0] << 16); bias[st][1] = __uint_as_float(w[0] & 0xffff0000u);
+        bias[st][2] = __uint_as_float(w[1] << 16); bias[st][3] = __uint_as_float(w[1] & 0xffff0000u);
+      }
+    }
   }
   // GATE_RES: the residual words of row tile ii + PF are requested before row tile ii is converted and stored (requesting ALL
   // rows up front serialises the read burst and the write burst: 25 k cycles per 256 x 256 tile against 15 k).  The gate vector is
   // loaded once when every row of the wave belongs to one batch sample (uniform test; always so for batch 1), per row tile otherwise.
   constexpr int PF = 2;
-  u32x4_t rw[PF + 1][NP];
-  auto fetch_res = [&](int ii, u32x4_t (&r)[NP]) {
+  uint32_t rw[PF + 1][NS][CW / 2];
+  auto fetch_res = [&](int ii, uint32_t (&r)[NS][CW / 2]) {
 #pragma unroll
-    for (int jp = 0; jp < NP; ++jp)
-      r[jp] = __builtin_amdgcn_raw_buffer_load_b128(rr_, (int)((uint32_t)((ii * 16 + frow) * ldr2) + coff[jp]), 0, 0);
+    for (int st = 0; st < NS; ++st) {
+      const int off = (int)((uint32_t)((ii * 16 + frow) * ldr2) + coff[st]);
+      if constexpr (SWAP) {
+        const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rr_, off, 0, 0);
+        r[st][0] = w[0]; r[st][1] = w[1]; r[st][2] = w[2]; r[st][3] = w[3];
+      } else {
+        const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rr_, off, 0, 0);
+        r[st][0] = w[0]; r[st][1] = w[1];
+      }
+    }
   };
-  f32x4_t g1[NP][2];
+  auto fetch_gate = [&](int b, float (&g)[NS][CW]) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const uint32_t go = (uint32_t)(b * ldg4) + 2u * coff[st];   // (OOB * 2 wraps to 0: harmless, the store is dropped)
+#pragma unroll
+      for (int h = 0; h < CW / 4; ++h) {
+        const f32x4_t w = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)(go + 16u * h), 0, 0));
+        g[st][4 * h] = w[0]; g[st][4 * h + 1] = w[1]; g[st][4 * h + 2] = w[2]; g[st][4 * h + 3] = w[3];
+      }
+    }
+  };
+  float g1[NS][CW];
   bool single = true;
   if constexpr (EPI == EPI_GATE_RES) {
 #pragma unroll
     for (int ii = 0; ii < PF && ii < MI; ++ii) fetch_res(ii, rw[ii % (PF + 1)]);
     const int b_first = row_base / rpb, b_last = (row_base + MI * 16 - 1) / rpb;      // scalar divisions, once
     single = b_first == b_last;
-#pragma unroll
-    for (int jp = 0; jp < NP; ++jp) {
-      const uint32_t go = (uint32_t)(b_first * ldg4) + 2u * coff[jp];                  // (OOB * 2 wraps to 0: harmless, the store is dropped)
-      g1[jp][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)go, 0, 0));
-      g1[jp][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)(go + 16u), 0, 0));
-    }
+    fetch_gate(b_first, g1);
   }
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
-    f32x4_t gi[NP][2];
+    float gi[NS][CW];
     if constexpr (EPI == EPI_GATE_RES) {
       if (ii + PF < MI) fetch_res(ii + PF, rw[(ii + PF) % (PF + 1)]);
 #pragma unroll
-      for (int jp = 0; jp < NP; ++jp) { gi[jp][0] = g1[jp][0]; gi[jp][1] = g1[jp][1]; }
+      for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) gi[st][e] = g1[st][e];
       if (!single) {                                            // (uniform) rows of several samples in this wave's tile
         const int grow = row_base + ii * 16 + frow;
         int b = (int)((float)grow * inv_rpb);                   // floor(grow / rpb) up to +-1: fix up exactly
         const int rem = grow - b * rpb;
         b += rem >= rpb ? 1 : (rem < 0 ? -1 : 0);
-#pragma unroll
-        for (int jp = 0; jp < NP; ++jp) {
-          const uint32_t go = (uint32_t)(b * ldg4) + 2u * coff[jp];
-          gi[jp][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)go, 0, 0));
-          gi[jp][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rg_, (int)(go + 16u), 0, 0));
-        }
+        fetch_gate(b, gi);
       }
     }
 #pragma unroll
-    for (int jp = 0; jp < NP; ++jp) {
-      float v[8];
+    for (int st = 0; st < NS; ++st) {
+      float v[CW];
+      if constexpr (SWAP) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * jp][e]), __float_as_uint(acc[ii][2 * jp + 1][e]), false, false);
-        v[e] = __uint_as_float(sw[0]);
-        v[4 + e] = __uint_as_float(sw[1]);
+        for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+          v[e] = __uint_as_float(sw[0]);
+          v[4 + e] = __uint_as_float(sw[1]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[ii][st][e];
       }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] += bias[jp][e];
+      for (int e = 0; e < CW; ++e) v[e] += bias[st][e];
       if constexpr (EPI == EPI_GELU) {
-        if (gcol[jp] >= gelu_col0) {
+        if (gcol[st] >= gelu_col0) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+          for (int e = 0; e < CW; ++e) v[e] = gelu_tanh(v[e]);
         }
       } else if constexpr (EPI == EPI_GATE_RES) {
-        float rr[8];
-        unpack8(rw[ii % (PF + 1)][jp], rr);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = rr[e] + (has_gate ? gi[jp][e >> 2][e & 3] : 1.0f) * v[e];      // no gate: plain residual add
+        for (int e = 0; e < CW; ++e) {
+          const uint32_t w = rw[ii % (PF + 1)][st][e >> 1];
+          const float rr = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+          v[e] = rr + (has_gate ? gi[st][e] : 1.0f) * v[e];       // no gate: plain residual add
+        }
       }
-      __builtin_amdgcn_raw_buffer_store_b128(pack8(v), rc, (int)(roff + coff[jp]), 0, 0);
+      if constexpr (SWAP) {
+        float v8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v8[e] = v[e % CW];
+        __builtin_amdgcn_raw_buffer_store_b128(pack8(v8), rc, (int)(roff + coff[st]), 0, 0);
+      } else {
+        const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        __builtin_amdgcn_raw_buffer_store_b64(o, rc, (int)(roff + coff[st]), 0, 0);
+      }
     }
   }
 }
@@ -267,16 +307,109 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 // (uniform) the forward's epilogue modes: bf16 out, no fp8 scales / convolution border / pre-add
 AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.fp8 == 0 && P.conv_wp == 0 && P.pre == nullptr; }
 
-template <int MI, int NJ>
+// Keys / queries of a fused k|v|q projection (GemmProblem::qk_D): the wave's 128 columns are one head.  After the permlane
+// exchange lane (frow, fq) owns, for row ii*16 + frow, the 8-column chunks 4 st + 2 (fq & 1) + (fq >> 1), st = 0..3, of that head:
+// its 32 values + those of the three other fq lanes are the 128 of the RMSNorm (two cross-lane adds); a chunk holds 4 whole
+// rotation pairs.  cos / sin of the NEXT row tile are requested before this one is finished.
+template <int MI>
+AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_base, int col_base, int frow, int fq, const float* wn) {
+  constexpr uint32_t OOB = 0x80000000u;
+  const int M = P.M, N = P.N;
+  const int rows_ok = min(max(M - row_base, 0), MI * 16);
+  const int64_t ldc = P.ldc;
+  __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.C + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 2));
+  __amdgpu_buffer_rsrc_t rcs = uniform_rsrc(const_cast<float*>(P.rope_cos), P.rope_rows * 256);
+  __amdgpu_buffer_rsrc_t rsn = uniform_rsrc(const_cast<float*>(P.rope_sin), P.rope_rows * 256);
+  const int ldc2 = (int)(ldc * 2);
+  const int period = P.rope_period, pos0 = P.rope_row0 + row_base;
+  const float inv_period = 1.0f / (float)period;
+  uint32_t coff[4], toff[4];
+  float bias[4][8], w[4][8];
+  const uint16_t* const biasp = P.bias;
+#pragma unroll
+  for (int st = 0; st < 4; ++st) {
+    const int c8 = 4 * st + 2 * (fq & 1) + (fq >> 1);          // chunk of 8 columns inside the head
+    const int gcol = col_base + c8 * 8;
+    const bool col_ok = gcol < N;
+    coff[st] = col_ok ? (uint32_t)gcol * 2u : OOB;
+    toff[st] = (uint32_t)c8 * 16u;                              // 4 pairs = 4 floats of a [., 64] table row
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[st][e] = 0.f;
+    if (biasp != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol), bias[st]);
+    const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wn + c8 * 8), w1 = *reinterpret_cast<const f32x4_t*>(wn + c8 * 8 + 4);
+    w[st][0] = w0[0]; w[st][1] = w0[1]; w[st][2] = w0[2]; w[st][3] = w0[3];
+    w[st][4] = w1[0]; w[st][5] = w1[1]; w[st][6] = w1[2]; w[st][7] = w1[3];
+  }
+  f32x4_t cs[2][4], sn[2][4];
+  auto fetch = [&](int ii, f32x4_t (&c)[4], f32x4_t (&s_)[4]) {
+    int pos = pos0 + ii * 16 + frow;
+    int q = (int)((float)pos * inv_period);                       // pos % period (period may be huge: q = 0)
+    int rem = pos - q * period;
+    rem += rem < 0 ? period : (rem >= period ? -period : 0);
+    const uint32_t ro = (uint32_t)rem * 256u;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      c[st] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rcs, (int)(ro + toff[st]), 0, 0));
+      s_[st] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rsn, (int)(ro + toff[st]), 0, 0));
+    }
+  };
+  fetch(0, cs[0], sn[0]);
+#pragma unroll
+  for (int ii = 0; ii < MI; ++ii) {
+    if (ii + 1 < MI) fetch(ii + 1, cs[(ii + 1) & 1], sn[(ii + 1) & 1]);
+    const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
+    float v[4][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        v[st][e] = __uint_as_float(sw[0]);
+        v[st][4 + e] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[st][e] += bias[st][e];
+        ss += v[st][e] * v[st][e];
+      }
+    }
+    ss += __shfl_xor(ss, 16, 64);
+    ss += __shfl_xor(ss, 32, 64);
+    const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      float r[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float a = v[st][2 * i] * rstd * w[st][2 * i];
+        const float b = v[st][2 * i + 1] * rstd * w[st][2 * i + 1];
+        const float c = cs[ii & 1][st][i], s_ = sn[ii & 1][st][i];
+        r[2 * i] = a * c - b * s_;
+        r[2 * i + 1] = a * s_ + b * c;
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(pack8(r), rc, (int)(roff + coff[st]), 0, 0);
+    }
+  }
+}
+
+template <int MI, int NJ, bool SWAP>
 AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
-  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ>(P, acc, row_base, col_base, frow, fq);
-  else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ>(P, acc, row_base, col_base, frow, fq);
-  else epi_store_fast<EPI_NONE, MI, NJ>(P, acc, row_base, col_base, frow, fq);
+  if constexpr (NJ == 8 && SWAP) {
+    if (P.qk_D > 0) {                                            // (uniform) which 128-column head of k | v | q (| mlp) is this wave's?
+      const int region = col_base / P.qk_D;
+      if (region == 0) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
+      if (region == 2) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
+    }
+  }
+  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
+  else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
+  else epi_store_fast<EPI_NONE, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
 }
 
 AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
   if (epi_is_fast(P)) {
-    epi_store_fast_any<8, 4>(P, acc, row_base, col_base, frow, fq);
+    epi_store_fast_any<8, 4, true>(P, acc, row_base, col_base, frow, fq);
     return;
   }
   const bool first_chunk = chunk == 0;
@@ -1041,7 +1174,10 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3(const GemmBatch 
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
     AFX_TRC(20)
-    epi_store_fast_any<MI, NJ>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+#ifndef V3_EPI_SWAP
+#define V3_EPI_SWAP 1
+#endif
+    epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
 #ifdef AFX_GEMM_TRACE
     AFX_TRC(21)
     tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
@@ -1061,6 +1197,16 @@ struct GemmMode { int impl = -1, tile = 0; };
 static GemmMode& gemm_mode() {
   static GemmMode m;
   return m;
+}
+bool gemm_qk_fusion_available() {
+  if (gemm_mode().impl < 0) {                           // same defaults as launch_gemm's first call
+    const char* e = getenv("AFX_GEMM_IMPL");
+    gemm_mode().impl = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 3;
+    if (const char* t = getenv("AFX_GEMM_TILE")) gemm_mode().tile = atoi(t);
+  }
+  const char* k = getenv("AFX_GEMM_SK");
+  const char* f = getenv("AFX_QK_FUSE");                // AFX_QK_FUSE=0: keep the separate kv_prep launch (A/B)
+  return gemm_mode().impl == 3 && !(k && atoi(k) != 0) && !(f && f[0] == '0');
 }
 void gemm_set_mode(int impl, int tile) {
   gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;
@@ -1142,9 +1288,21 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     const GemmProblem& p = batch.p[i];
     v3_ok = v3_ok && p.out_f32 == 0 && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
   }
+  bool qk = false;
+  for (int i = 0; i < batch.nprob; ++i) {
+    const GemmProblem& p = batch.p[i];
+    if (p.qk_D > 0) {
+      qk = true;
+      if (p.qk_D % 128 || p.N < 3 * p.qk_D || !p.qk_wk || !p.qk_wq || !p.rope_cos || !p.rope_sin || p.rope_period < 1 || p.rope_rows < 1 ||
+          p.epi == EPI_GATE_RES)
+        return hipErrorInvalidValue;
+    }
+  }
+  if (qk && !v3_ok) return hipErrorInvalidValue;        // callers ask gemm_qk_fusion_available() first
   if (v3_ok) {
     int best = 0;
-    if (tile_env >= 1 && tile_env <= 3) best = tile_env - 1;
+    if (qk) best = 0;                                   // one head = one wave's 128 columns: the 256x256 shape only
+    else if (tile_env >= 1 && tile_env <= 3) best = tile_env - 1;
     else {
       double best_cost = 0;
       for (int c = 0; c < 3; ++c) {

@@ -27,6 +27,16 @@ struct GemmProblem {
   int32_t fp8;          // 1: A and W hold OCP e4m3 bytes (lda/ldw/K in elements = bytes, K % 128 == 0); the product is scaled by
   const float* a_scale; //    a_scale[m] * w_scale[n] (per-row activation scale, per-output-channel weight scale) before the epilogue
   const float* w_scale;
+  // Fused q / k preparation of a k|v|q(|mlp) projection (one-wave-per-SIMD kernel, 256x256 tile only; gemm_qk_fusion_available()):
+  // columns [0, qk_D) are keys, [2 qk_D, 3 qk_D) queries -- every 128-column head of those two ranges leaves the epilogue as
+  // RoPE(RMSNorm_128(x + bias) * w) (diffusers FluxAttnProcessor order: norm_q / norm_k, then apply_rotary_emb on interleaved
+  // pairs; reference call sites arcflux.py:63-83), computed on the fp32 accumulators.  Row r of the problem sits at joint
+  // sequence position (rope_row0 + r) % rope_period of the [rope_rows, 64] f32 cos / sin tables.  qk_D == 0: off.
+  const float* qk_wk;   // [128] RMSNorm weight of the keys
+  const float* qk_wq;   // [128] ... of the queries
+  const float* rope_cos;
+  const float* rope_sin;
+  int32_t qk_D, rope_row0, rope_period, rope_rows;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 
@@ -44,6 +54,7 @@ struct GemmBatch {
 };
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
+bool gemm_qk_fusion_available();            // the launcher would take a problem with qk_D > 0 (kernel mode 3, no stream-K request)
 void gemm_set_mode(int impl, int tile);      // kernel / tile-shape override of AFX_GEMM_IMPL / AFX_GEMM_TILE (see launch_gemm)
 constexpr int64_t GEMM_SK_FLAG_BYTES = 4096;                       // 1024 flag words
 constexpr int64_t GEMM_SK_SLAB_BYTES = 256ll * 256 * 256 * 4;      // 256 work-groups x one fp32 256x256 tile

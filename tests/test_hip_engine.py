@@ -44,6 +44,32 @@ def test_flux_forward_vs_oracle(B, hp, wp, T, nd, ns):
     assert torch.allclose(out.logweights.float().exp().sum(dim=2).cpu(), torch.ones(B, hp * wp, 4), atol=2e-2)
 
 
+def test_flux_forward_8phase_gemm_and_separate_qk_prep_launch():
+    """The default forward runs the one-wave-per-SIMD GEMM with q / k RMSNorm + RoPE fused into the k|v|q projections' epilogue
+    (GemmProblem::qk_D).  With the 8-phase kernel selected the engine falls back to the separate kv_prep launch: same parity bar,
+    and the two paths agree with each other (the fused one normalises the fp32 accumulators, the separate one bf16-rounded q / k)."""
+    from arcflow_amd import MMDiTEngine, ops
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=1, num_single_layers=2, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=5)
+    hid, ctx, pooled = _inputs(2, 8, 8, 9, 128, 64, seed=4)
+    t, gd = torch.tensor([0.9, 0.4]), torch.full((2,), 3.5)
+    rm, rlw, rlg = D.flux_forward(w, cfg, hid.float(), ctx.float(), pooled.float(), t, gd, 8, 8)
+    eng = MMDiTEngine('flux', 1, 2, heads=2, joint_dim=128, pooled_dim=64)
+    eng.load_state_dict(w)
+    fused = eng(hid.cuda(), t.cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8)
+    try:
+        ops.set_gemm_mode(2, 0)
+        plain = eng(hid.cuda(), t.cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8)
+    finally:
+        ops.set_gemm_mode(3, 0)
+    torch.cuda.synchronize()
+    for out in (fused, plain):
+        assert rel_l2(out.means.float(), rm) < TOL and rel_l2(out.loggammas.float(), rlg) < TOL
+    assert rel_l2(fused.means.float(), plain.means.float()) < 1.5e-2
+    assert not torch.equal(fused.means, plain.means)          # (they ARE different code paths)
+
+
 def test_flux_teacher_head():
     from arcflow_amd import MMDiTEngine
     from oracle import dit_ref as D
