@@ -1038,6 +1038,10 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3(const GemmBatch 
     woff[i] = (uint32_t)((int64_t)br * P.ldw * 2 + pc);
   }
   const char* abase = reinterpret_cast<const char*>(P.A);
+  // (Measured and dropped, r02u: W stored TILE-MAJOR -- the TN x 64 block of a (column tile, K-tile) as one contiguous run, so a
+  // tile's weight stream is sequential in HBM instead of 128-byte pieces 6 KB apart.  With weights streaming from HBM the loop loses
+  // its DMA waits, 2561 -> 2388 cycles per K-tile at N = 12288, and the launch takes the same 287 us: the clock drops by what the
+  // stall cycles had saved in power.)
   const char* wbase = reinterpret_cast<const char*>(P.W);
   auto stage_a = [&](int t) {
     t = t < nk ? t : nk - 1;
