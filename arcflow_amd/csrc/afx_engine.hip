@@ -508,18 +508,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     return AFX_OK;
   };
   // LN + modulate of both streams of every sample in one launch (text rows take the text stream's vectors)
-  static const bool dbg_oldnorm = getenv("AFX_DBG_OLDNORM") != nullptr, dbg_oldprep = getenv("AFX_DBG_OLDPREP") != nullptr;
   auto stream_norm = [&](int blk, int shift_chunk, int scale_chunk) -> int {
-    if (dbg_oldnorm) {
-      for (int b = 0; b < B; ++b)
-        for (int s = 0; s < 2; ++s) {
-          const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
-          HIP_TRY(launch_norm_modulate(ws.X + row0 * D, D, ws.Xn + row0 * D, D, s == 0 ? N : T, (int)D,
-                                       ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, scale_chunk),
-                                       ws.mod + (int64_t)b * ldm + ml.dbl(blk, s, shift_chunk), 0, 1 << 30, 0, st));
-        }
-      return AFX_OK;
-    }
     HIP_TRY(launch_norm_modulate_joint(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
                                        ws.mod + ml.dbl(blk, 0, shift_chunk), ws.mod + ml.dbl(blk, 1, scale_chunk),
                                        ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, S, T, st));
@@ -538,11 +527,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if ((rc = stream_norm(i, 0, 1))) return rc;
     if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr))) return rc;
     // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
-    if (dbg_oldprep) {
-      HIP_TRY(launch_qk_norm_rope2(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn + 0 * 128, rope_cos,
-                                   rope_sin, B, S, T, H, st));
-      HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
-    } else if (qk_fuse)
+    if (qk_fuse)
       HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
     else
     HIP_TRY(launch_kv_prep(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn, rope_cos, rope_sin, T, QKV + D,
@@ -579,10 +564,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     }
     gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
-    if (dbg_oldprep) {
-      HIP_TRY(launch_qk_norm_rope2(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, B, S, T, H, st));
-      HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
-    } else if (qk_fuse)
+    if (qk_fuse)
       HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
     else
     HIP_TRY(launch_kv_prep(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, T, ws.F + D, 7 * D, ws.Vt, B,
