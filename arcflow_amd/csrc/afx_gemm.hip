@@ -152,7 +152,9 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 // bytes per row and instruction) -- or not: 4 consecutive columns per lane straight from the C^T accumulator, 8-byte accesses,
 // twice the memory instructions but no cross-lane exchange in the dependency chain (the one-wave-per-SIMD kernel has no partner
 // wave to hide that chain's latency behind).
-template <int EPI, int MI, int NJ, bool SWAP>
+// FP8: the product is scaled by a_scale[row] * w_scale[col] first (row-wise activation, per-output-channel weight scales);
+// PRE: a bf16 [M, N] term (GemmProblem::pre, the LoRA-dropout correction) is added before the activation / gate.
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? NJ / 2 : NJ;       // steps per row tile
@@ -185,6 +187,15 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   int gcol[NS];
   uint32_t coff[NS];             // byte offset of the lane's CW columns in a bf16 row, or OOB
   float bias[NS][CW];
+  float wsc[FP8 ? NS : 1][CW];
+  __amdgpu_buffer_rsrc_t rp_ = rc, ra_ = rc;
+  int ldp2 = 0;
+  if constexpr (PRE) {
+    const int64_t ldp = P.ldp;
+    ldp2 = (int)(ldp * 2);
+    rp_ = uniform_rsrc(const_cast<uint16_t*>(P.pre) + (int64_t)row_base * ldp, (int)(rows_ok * ldp * 2));
+  }
+  if constexpr (FP8) ra_ = uniform_rsrc(const_cast<float*>(P.a_scale) + row_base, rows_ok * 4);
   const uint16_t* const biasp = P.bias;
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
@@ -196,6 +207,10 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #endif
 #pragma unroll
     for (int e = 0; e < CW; ++e) bias[st][e] = 0.f;
+    if constexpr (FP8) {
+#pragma unroll
+      for (int e = 0; e < CW; ++e) wsc[st][e] = col_ok ? P.w_scale[gcol[st] + e] : 0.f;
+    }
     if (biasp != nullptr && col_ok) {
       if constexpr (SWAP) {
         unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[st]), bias[st]);
@@ -211,6 +226,24 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   // loaded once when every row of the wave belongs to one batch sample (uniform test; always so for batch 1), per row tile otherwise.
   constexpr int PF = 2;
   uint32_t rw[PF + 1][NS][CW / 2];
+  uint32_t pw[PRE ? PF + 1 : 1][NS][CW / 2];
+  float asc[FP8 ? PF + 1 : 1];
+  auto fetch_pre = [&](int ii) {        // the pre-add words and the activation scale of row tile ii
+    if constexpr (PRE) {
+#pragma unroll
+      for (int st = 0; st < NS; ++st) {
+        const int off = (int)((uint32_t)((ii * 16 + frow) * ldp2) + coff[st]);
+        if constexpr (SWAP) {
+          const u32x4_t w = __builtin_amdgcn_raw_buffer_load_b128(rp_, off, 0, 0);
+          pw[ii % (PF + 1)][st][0] = w[0]; pw[ii % (PF + 1)][st][1] = w[1]; pw[ii % (PF + 1)][st][2] = w[2]; pw[ii % (PF + 1)][st][3] = w[3];
+        } else {
+          const u32x2_t w = __builtin_amdgcn_raw_buffer_load_b64(rp_, off, 0, 0);
+          pw[ii % (PF + 1)][st][0] = w[0]; pw[ii % (PF + 1)][st][1] = w[1];
+        }
+      }
+    }
+    if constexpr (FP8) asc[ii % (PF + 1)] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra_, (ii * 16 + frow) * 4, 0, 0));
+  };
   auto fetch_res = [&](int ii, uint32_t (&r)[NS][CW / 2]) {
 #pragma unroll
     for (int st = 0; st < NS; ++st) {
@@ -237,6 +270,10 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   };
   float g1[NS][CW];
   bool single = true;
+  if constexpr (PRE || FP8) {
+#pragma unroll
+    for (int ii = 0; ii < PF && ii < MI; ++ii) fetch_pre(ii);
+  }
   if constexpr (EPI == EPI_GATE_RES) {
 #pragma unroll
     for (int ii = 0; ii < PF && ii < MI; ++ii) fetch_res(ii, rw[ii % (PF + 1)]);
@@ -248,6 +285,9 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
     float gi[NS][CW];
+    if constexpr (PRE || FP8) {
+      if (ii + PF < MI) fetch_pre(ii + PF);
+    }
     if constexpr (EPI == EPI_GATE_RES) {
       if (ii + PF < MI) fetch_res(ii + PF, rw[(ii + PF) % (PF + 1)]);
 #pragma unroll
@@ -276,8 +316,19 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[ii][st][e];
       }
+      if constexpr (FP8) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] *= asc[ii % (PF + 1)] * wsc[st][e];
+      }
 #pragma unroll
       for (int e = 0; e < CW; ++e) v[e] += bias[st][e];
+      if constexpr (PRE) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+          const uint32_t w = pw[ii % (PF + 1)][st][e >> 1];
+          v[e] += __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
+        }
+      }
       if constexpr (EPI == EPI_GELU) {
         if (gcol[st] >= gelu_col0) {
 #pragma unroll
@@ -305,7 +356,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 }
 
 // (uniform) the forward's epilogue modes: bf16 out, no fp8 scales / convolution border / pre-add
-AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.fp8 == 0 && P.conv_wp == 0 && P.pre == nullptr; }
+AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.conv_wp == 0; }
 
 // Keys / queries of a fused k|v|q projection (GemmProblem::qk_D): the wave's 128 columns are one head.  After the permlane
 // exchange lane (frow, fq) owns, for row ii*16 + frow, the 8-column chunks 4 st + 2 (fq & 1) + (fq >> 1), st = 0..3, of that head:
@@ -393,24 +444,30 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
   }
 }
 
-template <int MI, int NJ, bool SWAP>
+template <int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
 AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
-  if constexpr (NJ == 8 && SWAP) {
+  if constexpr (NJ == 8 && SWAP && !FP8 && !PRE) {
     if (P.qk_D > 0) {                                            // (uniform) which 128-column head of k | v | q (| mlp) is this wave's?
       const int region = col_base / P.qk_D;
       if (region == 0) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
       if (region == 2) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
     }
   }
-  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
-  else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
-  else epi_store_fast<EPI_NONE, MI, NJ, SWAP>(P, acc, row_base, col_base, frow, fq);
+  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+  else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+  else epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
 }
 
+template <bool FP8K = false>
 AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
-  if (epi_is_fast(P)) {
-    epi_store_fast_any<8, 4, true>(P, acc, row_base, col_base, frow, fq);
-    return;
+  if (epi_is_fast(P)) {                                          // bf16 output without a convolution border: straight-line code
+    if constexpr (FP8K) {
+      if (P.pre == nullptr) { epi_store_fast_any<8, 4, true, true, false>(P, acc, row_base, col_base, frow, fq); return; }
+    } else {
+      if (P.pre != nullptr) epi_store_fast_any<8, 4, true, false, true>(P, acc, row_base, col_base, frow, fq);
+      else epi_store_fast_any<8, 4, true, false, false>(P, acc, row_base, col_base, frow, fq);
+      return;
+    }
   }
   const bool first_chunk = chunk == 0;
   float wsc[2][8];            // fp8: per-output-channel weight scales of this lane's 2 x 8 columns
@@ -951,7 +1008,13 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
   }
 
   // ---- epilogue: straight from the (transposed) accumulators ------------------------------------
-  epi_store_direct(P, acc, m0 + wr * 128, n0 + wc * 64, frow, fq, chunk);
+  {   // lane constants of the epilogue from an OPAQUE copy of threadIdx: otherwise its column / row offsets are hoisted above the
+      // main loop, where every register is spoken for (the fp8 instance spilled inside the loop: 158 -> 187 us at N = 9216)
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
+    epi_store_direct<FP8>(P, acc, m0 + (wave2 >> 2) * 128, n0 + (wave2 & 3) * 64, lane2 & 15, lane2 >> 4, chunk);
+  }
 #ifdef AFX_GEMM_TRACE
   AFX_TRC(21)
   tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
