@@ -75,6 +75,8 @@ struct afx_ctx {
   uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
   bool fp8 = false;            // block linears on the fp8 MFMA (afx_set_fp8_linear)
   const float* temb_override = nullptr;   // optional [B, D] f32 replacing timestep_embedder(t) (training student with its LoRA pair)
+  // conditioning of several denoising steps prepared in one pass over the stacked modulation matrix (afx_mmdit_prepare_steps)
+  int prep_steps = 0, prep_B = 0, prep_use = -1;
   // optional per-launch-class timing (HIP events on the forward's stream)
   bool prof_on = false;
   struct ProfRec { hipEvent_t a, b; int klass; double flops; };
@@ -129,11 +131,14 @@ struct ModLayout {
   int64_t total() const { return (int64_t)nd * 12 * D + (int64_t)ns * 3 * D + 2 * D; }
 };
 
+constexpr int AFX_PREP_ROWS = 8;      // (steps x samples) one modulation pass can serve: the GEMV's batch limit
+
 struct Workspace {
   uint32_t* sk_flags;   // stream-K GEMM tail (afx_gemm.hip): 1024 flag words at offset 0 (zeroed by afx_set_workspace, re-armed by the kernel)
   float* sk_slab;       //   + 256 fp32 accumulator slabs of one 256x256 tile each
   uint16_t *X, *Xn, *F, *Vt, *head;
   float *sincos, *tmp, *temb, *semb, *mod, *pooled;
+  float *prep_temb, *prep_semb, *prep_mod;   // [AFX_PREP_ROWS][D], [..][D], [..][n_mod]: prepared steps (step-major, then sample)
   uint8_t* q8;     // fp8 mode: the quantised A operand of the GEMM about to run [R, <= 5D]
   float* qs;       //           its per-row scales [R]
   int64_t total;
@@ -150,6 +155,9 @@ Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
   };
   w.sk_flags = (uint32_t*)take(GEMM_SK_FLAG_BYTES);          // FIRST: its offset must not depend on the shape
   w.sk_slab = (float*)take(GEMM_SK_SLAB_BYTES);
+  w.prep_temb = (float*)take((int64_t)AFX_PREP_ROWS * D * 4);       // (shape-independent offsets: they outlive a forward)
+  w.prep_semb = (float*)take((int64_t)AFX_PREP_ROWS * D * 4);
+  w.prep_mod = (float*)take((int64_t)AFX_PREP_ROWS * c->n_mod * 4);
   w.X = (uint16_t*)take(R * D * 2);
   w.Xn = (uint16_t*)take(R * D * 2);
   w.F = (uint16_t*)take(R * 7 * D * 2);   // single: fused [k|v|q|mlp]; double: [QKV 3D] then [H 4D]
@@ -325,6 +333,8 @@ int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes) {
   HIP_TRY(hipMemset(dptr, 0, GEMM_SK_FLAG_BYTES));          // stream-K hand-off flags start cleared (the kernel re-arms them)
   ctx->ws = (char*)dptr;
   ctx->ws_bytes = bytes;
+  ctx->prep_steps = 0;                                       // prepared steps lived in the old workspace
+  ctx->prep_use = -1;
   return AFX_OK;
 }
 
@@ -380,7 +390,17 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   const int64_t ldm = c->n_mod;
   int overlap_join_block = -1;          // >= 0: the side-stream modulation GEMV must be joined in front of this block
 
-  if (stage != 2) {
+  const bool use_prep = c->prep_use >= 0 && c->prep_use < c->prep_steps && c->prep_B == B && stage != 2 && c->temb_override == nullptr;
+  const int prep_k = c->prep_use;
+  if (stage != 2) c->prep_use = -1;                              // one-shot
+  if (use_prep) {
+    // the modulation vectors (and temb, for afx_mmdit_export) of this step were computed by afx_mmdit_prepare_steps
+    const int64_t r0 = (int64_t)prep_k * B;
+    HIP_TRY(hipMemcpyAsync(ws.mod, ws.prep_mod + r0 * ldm, (size_t)B * ldm * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ws.temb, ws.prep_temb + r0 * D, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(ws.semb, ws.prep_semb + r0 * D, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+  }
+  if (stage != 2 && !use_prep) {
   // ---- conditioning: temb = t_mlp(sincos(1000 t)) [+ g_mlp(sincos(1000 g))] [+ p_mlp(pooled)] ------
   if (c->temb_override != nullptr) {
     HIP_TRY(hipMemcpyAsync(ws.temb, c->temb_override, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
@@ -438,7 +458,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   if (overlap_join_block < 0 && W16(c, "mod_final.weight") != nullptr)
     HIP_TRY(launch_gemv(ws.semb, W16(c, "mod_final.weight"), W16(c, "mod_final.bias"), ws.mod + ml.fin(0), B, (int)(2 * D),
                         (int)D, 0, 0, st, ldm));
-
+  }   // conditioning
+  if (stage != 2) {
   // ---- embedders into the joint layout X[b][text T | image N] ---------------------------------------
   const uint16_t* ctx_src = (const uint16_t*)ctx_emb;
   if (d.family == 1) {   // Qwen: RMSNorm(joint_dim) on the text states before txt_in (arcqwen.py:129)
@@ -610,6 +631,64 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   if (d.head_mode == 0)
     HIP_TRY(launch_head_split(ws.head, c->head_n, (uint16_t*)means, (uint16_t*)logw, (uint16_t*)logg, (int64_t)B * N,
                               d.num_gaussians, d.in_channels, d.logweights_channels, st));
+  return AFX_OK;
+}
+
+int afx_mmdit_prepare_steps(afx_ctx* c, const void* pooled, const float* t_steps, const float* g, int32_t B, int32_t nsteps,
+                            void* stream_) {
+  if (!c || !t_steps) return fail(AFX_E_INVALID, "null argument to afx_mmdit_prepare_steps");
+  if (!c->finalized) return fail(AFX_E_MISSING, "afx_finalize() has not succeeded on this context");
+  const afx_model_desc& d = c->d;
+  if (B < 1 || nsteps < 1 || B > AFX_MAX_MICRO_BATCH || (int64_t)B * nsteps > AFX_PREP_ROWS)
+    return fail(AFX_E_INVALID, "afx_mmdit_prepare_steps: batch <= 4 and batch * steps <= %d", AFX_PREP_ROWS);
+  if (d.guidance_embeds && !g) return fail(AFX_E_INVALID, "guidance vector required");
+  if (d.pooled_dim > 0 && !pooled) return fail(AFX_E_INVALID, "pooled projections required");
+  if (c->temb_override) return fail(AFX_E_INVALID, "afx_mmdit_prepare_steps: not with a timestep-embedding override");
+  Workspace ws = carve(c, c->ws, 1, 1, 1);                       // (only the shape-independent head of the workspace is used)
+  if (!c->ws || ws.total > c->ws_bytes) return fail(AFX_E_WORKSPACE, "workspace not set / too small");
+  hipStream_t st = (hipStream_t)stream_;
+  const int64_t D = c->D, ldm = c->n_mod;
+  const int rows = B * nsteps;
+  c->prep_steps = 0;
+  c->prep_use = -1;
+  // temb of every (step, sample): the same three tiny MLPs as the forward, B rows at a time into row block k
+  float* sc = ws.prep_semb;                                      // scratch: sincos / hidden rows live in the semb block until the SiLU
+  for (int k = 0; k < nsteps; ++k) {
+    float* temb = ws.prep_temb + (int64_t)k * B * D;
+    float* hid = sc + (int64_t)k * B * D;                        // [B, D] hidden of the current MLP (overwritten by the SiLU below)
+    float* sin_ = ws.prep_mod;                                   // [B, 256] / [B, pooled_dim]: free until the big pass
+    HIP_TRY(launch_sincos(t_steps + (int64_t)k * B, 1000.0f, sin_, B, st));
+    HIP_TRY(launch_gemv(sin_, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), hid, B, (int)D, 256, 1, 0, st));
+    HIP_TRY(launch_gemv(hid, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), temb, B, (int)D, (int)D, 0, 0, st));
+    if (d.guidance_embeds) {
+      HIP_TRY(launch_sincos(g, 1000.0f, sin_, B, st));
+      HIP_TRY(launch_gemv(sin_, W16(c, "temb.g.l1.weight"), W16(c, "temb.g.l1.bias"), hid, B, (int)D, 256, 1, 0, st));
+      HIP_TRY(launch_gemv(hid, W16(c, "temb.g.l2.weight"), W16(c, "temb.g.l2.bias"), temb, B, (int)D, (int)D, 0, 1, st));
+    }
+    if (d.pooled_dim > 0) {
+      HIP_TRY(launch_bf16_to_f32((const uint16_t*)pooled, sin_, (int64_t)B * d.pooled_dim, st));
+      HIP_TRY(launch_gemv(sin_, W16(c, "temb.p.l1.weight"), W16(c, "temb.p.l1.bias"), hid, B, (int)D, d.pooled_dim, 1, 0, st));
+      HIP_TRY(launch_gemv(hid, W16(c, "temb.p.l2.weight"), W16(c, "temb.p.l2.bias"), temb, B, (int)D, (int)D, 0, 1, st));
+    }
+  }
+  HIP_TRY(launch_silu(ws.prep_temb, ws.prep_semb, (int64_t)rows * D, st));
+  // ONE pass over the stacked [n_mod, D] matrix for all steps: the matrix (6.5 GB for FLUX) is what the time goes into, the
+  // number of right-hand sides is free up to the GEMV's 8
+  HIP_TRY(launch_gemv(ws.prep_semb, W16(c, "mod.weight"), W16(c, "mod.bias"), ws.prep_mod, rows, (int)c->n_mod, (int)D, 0, 0, st, ldm));
+  if (W16(c, "mod_final.weight") != nullptr) {
+    ModLayout ml{D, d.num_double, d.num_single};
+    HIP_TRY(launch_gemv(ws.prep_semb, W16(c, "mod_final.weight"), W16(c, "mod_final.bias"), ws.prep_mod + ml.fin(0), rows, (int)(2 * D),
+                        (int)D, 0, 0, st, ldm));
+  }
+  c->prep_steps = nsteps;
+  c->prep_B = B;
+  return AFX_OK;
+}
+
+int afx_mmdit_use_prepared_step(afx_ctx* c, int32_t k) {
+  if (!c) return fail(AFX_E_INVALID, "null ctx");
+  if (k >= c->prep_steps) return fail(AFX_E_INVALID, "afx_mmdit_use_prepared_step: step %d of %d prepared", k, c->prep_steps);
+  c->prep_use = k < 0 ? -1 : k;
   return AFX_OK;
 }
 

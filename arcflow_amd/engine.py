@@ -148,11 +148,35 @@ class MMDiTEngine:
         _lib.check(self.lib.afx_profile_read(self._ctx, klass, C.byref(ms), C.byref(n), C.byref(fl)))
         return ms.value, n.value, fl.value
 
+    # ------------------------------------------------------------------ conditioning of several steps at once
+    @torch.no_grad()
+    def prepare_steps(self, timesteps, pooled_projections: Optional[torch.Tensor] = None, guidance: Optional[torch.Tensor] = None,
+                      batch: int = 1, n_img: int = 1, n_txt: int = 1) -> bool:
+        """Compute the AdaLN modulation vectors of ALL the sampler's steps in one pass over the stacked modulation matrix
+        (``afx_mmdit_prepare_steps``): ``timesteps`` [nsteps] (shared by the batch) or [nsteps, B] sigmas in [0, 1].  A following
+        ``forward(..., prepared_step=k)`` of the same batch then skips its own pass (1.3 ms of weight streaming per FLUX
+        forward).  Returns False -- and prepares nothing -- when batch > 4 or batch * nsteps > 8 (the plain path then applies)."""
+        ts = torch.as_tensor(timesteps, dtype=torch.float32)
+        if ts.dim() == 1:
+            ts = ts[:, None].expand(-1, batch)
+        nsteps, B = ts.shape
+        if B > 4 or B * nsteps > 8:
+            return False
+        dev = self.device
+        ts = ts.to(dev).contiguous()
+        g = None if guidance is None else guidance.to(dev, torch.float32).expand(B).contiguous()
+        pooled = None if pooled_projections is None else pooled_projections.to(dev, torch.bfloat16).contiguous()
+        self._workspace(B, n_img, n_txt)
+        _lib.check(self.lib.afx_mmdit_prepare_steps(self._ctx, _ptr(pooled), _ptr(ts), _ptr(g), B, nsteps, _stream()))
+        self._prepared = (nsteps, B)
+        return True
+
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
     def forward(self, hidden_states: torch.Tensor, timestep: torch.Tensor, encoder_hidden_states: torch.Tensor,
                 pooled_projections: Optional[torch.Tensor] = None, guidance: Optional[torch.Tensor] = None,
-                height_tokens: Optional[int] = None, width_tokens: Optional[int] = None, stage: int = 0):
+                height_tokens: Optional[int] = None, width_tokens: Optional[int] = None, stage: int = 0,
+                prepared_step: Optional[int] = None):
         """hidden_states [B,N,C] packed latents; timestep [B] sigma in [0,1]; encoder_hidden_states [B,T,joint];
         returns ArcFlowModelOutput (student) or the velocity [B,N,C] (teacher head).
         stage 1 / 2 (B <= 4): conditioning + embedders only / norm_out + head only -- the caller runs the blocks in between
@@ -171,7 +195,11 @@ class MMDiTEngine:
         g = None if guidance is None else guidance.to(dev, torch.float32).expand(B).contiguous()
         pooled = None if pooled_projections is None else pooled_projections.to(dev, torch.bfloat16).contiguous()
         cos, sin = self.rope_tables(height_tokens, width_tokens, T)
-        self._workspace(min(B, 4), N, T)
+        ws_key_before = self._ws_key
+        self._workspace(min(B, 4), N, T)           # (a grown workspace drops the prepared steps: the plain path applies)
+        if self._ws_key != ws_key_before:
+            self._prepared = None
+        ws_key_before = self._ws_key
         K, L = self.num_gaussians, self.logweights_channels
         if self.teacher_head:
             means = torch.empty(B, N, Cc, dtype=torch.bfloat16, device=dev)
@@ -180,6 +208,9 @@ class MMDiTEngine:
             means = torch.empty(B, N, K, Cc, dtype=torch.bfloat16, device=dev)
             logw = torch.empty(B, N, K, L, dtype=torch.bfloat16, device=dev)
             logg = torch.empty(B, N, K - 1, L, dtype=torch.bfloat16, device=dev)
+        if prepared_step is not None and getattr(self, '_prepared', None) is not None and self._prepared[1] == B \
+                and 0 <= prepared_step < self._prepared[0] and stage == 0 and self._ws_key == ws_key_before:
+            _lib.check(self.lib.afx_mmdit_use_prepared_step(self._ctx, prepared_step))
         _lib.check(self.lib.afx_mmdit_forward_stage(self._ctx, _ptr(x), _ptr(ctx), _ptr(pooled), _ptr(t), _ptr(g), _ptr(cos),
                                                     _ptr(sin), B, N, T, _ptr(means), _ptr(logw), _ptr(logg), stage, _stream()))
         if self.teacher_head:

@@ -115,7 +115,7 @@ class _PipelineBase(ArcFlowLoaderMixin):
         return packed.contiguous(), hp, wp
 
     def _denoise(self, latents, hp, wp, num_inference_steps, total_substeps, timestep_ratio, fwd,
-                 callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds):
+                 callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds, prepare=None):
         device = self._device
         raw, per_step, total = retrieve_raw_timesteps(num_inference_steps, total_substeps, timestep_ratio)
         timesteps = self._retrieve_timesteps(raw, device, latents.shape[1])
@@ -124,6 +124,10 @@ class _PipelineBase(ArcFlowLoaderMixin):
         self.scheduler.set_begin_index(0)
         ntt = self.scheduler.config.num_train_timesteps
         ts_host = timesteps.float().cpu().tolist()          # 128 floats, once per call
+        # every step's source timestep is known here: the AdaLN modulation vectors of ALL steps (functions of t, guidance and the
+        # pooled text only) come out of one pass over the stacked modulation matrix instead of one pass per transformer call
+        starts = [sum(per_step[:i]) for i in range(num_inference_steps)]
+        prepared = bool(prepare([ts_host[j] / 1000.0 for j in starts])) if prepare is not None and not self.interrupt else False
         tid = 0
         for i in range(num_inference_steps):
             if self.interrupt:
@@ -131,7 +135,8 @@ class _PipelineBase(ArcFlowLoaderMixin):
             t_src = ts_host[tid]
             sigma_src = t_src / ntt
             self._current_timestep = t_src
-            out = fwd(latents.to(torch.bfloat16), torch.full((latents.shape[0],), t_src / 1000.0, device=device), prompt_embeds)
+            out = fwd(latents.to(torch.bfloat16), torch.full((latents.shape[0],), t_src / 1000.0, device=device), prompt_embeds,
+                      i if prepared else None)
             tid += per_step[i]
             sigma_end = (ts_host[tid] / ntt) if tid < len(ts_host) else 0.0
             latents = ops.arcflow_step(latents, out.means, out.logweights, out.loggammas,
@@ -298,10 +303,13 @@ class ArcFluxPipeline(_PipelineBase):
         guidance = torch.full((B,), guidance_scale, device=device, dtype=torch.float32) \
             if self.transformer.guidance_embeds else None
 
-        def fwd(x, t, pe):
-            return self.transformer(x, t, pe.to(device, torch.bfloat16), pooled, guidance, hp, wp)
+        def fwd(x, t, pe, prepared_step=None):
+            return self.transformer(x, t, pe.to(device, torch.bfloat16), pooled, guidance, hp, wp, prepared_step=prepared_step)
+
+        def prepare(sigmas):
+            return self.transformer.prepare_steps(sigmas, pooled, guidance, B, hp * wp, prompt_embeds.shape[1])
         latents = self._denoise(latents, hp, wp, num_inference_steps, total_substeps, timestep_ratio, fwd,
-                                callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds)
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds, prepare)
         if output_type == 'latent':
             image = latents
         else:

@@ -136,10 +136,13 @@ class ArcQwenImagePipeline(_PipelineBase):
         B = prompt_embeds.shape[0]
         latents, hp, wp = self._prepare_latents(B, height, width, generator, latents)
 
-        def fwd(x, t, pe):
-            return self.transformer(x, t, pe.to(device, torch.bfloat16), None, None, hp, wp)
+        def fwd(x, t, pe, prepared_step=None):
+            return self.transformer(x, t, pe.to(device, torch.bfloat16), None, None, hp, wp, prepared_step=prepared_step)
+
+        def prepare(sigmas):
+            return self.transformer.prepare_steps(sigmas, None, None, B, hp * wp, prompt_embeds.shape[1])
         latents = self._denoise(latents, hp, wp, num_inference_steps, total_substeps, timestep_ratio, fwd,
-                                callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds)
+                                callback_on_step_end, callback_on_step_end_tensor_inputs, prompt_embeds, prepare)
         if output_type == 'latent':
             image = latents
         else:

@@ -221,6 +221,7 @@ def parse_args(argv=None):
                                                            '1 = the canonical line, 2 fills the under-filled last rounds: +3.8 % (r02)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--no-prepare-steps', action='store_true', help='recompute the AdaLN conditioning inside every transformer call (A/B)')
     ap.add_argument('--fp8', action='store_true', help='OPTIONAL reduced-precision mode: block linears on the fp8 MFMA (not the headline: the line says dtype fp8)')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launch (default: derived from the pid)')
     args = ap.parse_args(argv)
@@ -308,8 +309,11 @@ def main(argv=None):
         n_img[0] += 1
         with torch.cuda.stream(streams[k]):
             x = lat
+            # as the pipeline's loop does (arcflow_amd/pipelines/arcflux_pipeline.py::_denoise): the conditioning of both steps in
+            # one pass over the modulation matrix -- per image, inside the timed region
+            prep = engines[k].prepare_steps(sig[:2], pooled, guidance, 1, N_IMG, int(ctx.shape[1])) if not args.no_prepare_steps else False
             for i in range(2):
-                out = engines[k](x.bfloat16(), tvec[i], ctx, pooled, guidance, hp, wp)
+                out = engines[k](x.bfloat16(), tvec[i], ctx, pooled, guidance, hp, wp, prepared_step=i if prep else None)
                 x = ops.arcflow_step(x, out.means, out.logweights, out.loggammas, sig[i], sig[i], sig[i + 1])
         return x
 

@@ -110,6 +110,19 @@ int afx_mmdit_forward(afx_ctx* ctx, const void* x, const void* ctx_emb, const vo
                       int32_t batch, int32_t n_img, int32_t n_txt,
                       void* means, void* logw, void* logg, void* stream);
 
+/* The conditioning of SEVERAL denoising steps in one pass.  The AdaLN modulation vectors of a forward depend only on (t, guidance,
+ * pooled text) -- the reference recomputes them inside every transformer call (arcflux.py:134-257: time_text_embed, then each
+ * block's norm1 / norm linear) -- and computing them means streaming the stacked modulation matrix (6.5 GB for FLUX, 1.3 ms)
+ * once per forward.  A sampler knows all its timesteps up front (arcflux_pipeline.py:455-467), so:
+ *   afx_mmdit_prepare_steps(ctx, pooled, t_steps [nsteps][batch] f32, g, batch, nsteps, stream)   batch <= 4, batch * nsteps <= 8
+ * streams the matrix ONCE for all steps, and afx_mmdit_use_prepared_step(ctx, k) makes the NEXT afx_mmdit_forward (same batch)
+ * take step k's vectors instead of recomputing them (one-shot; k = -1 cancels; the t / g / pooled arguments of that forward are
+ * not looked at for the conditioning).  Results are bit-identical to the plain call.  The prepared vectors live in the workspace:
+ * a new afx_set_workspace or a changed pooled / guidance needs a new prepare. */
+int afx_mmdit_prepare_steps(afx_ctx* ctx, const void* pooled, const float* t_steps, const float* g, int32_t batch, int32_t nsteps,
+                            void* stream);
+int afx_mmdit_use_prepared_step(afx_ctx* ctx, int32_t k);
+
 /* Gradient checkpointing (arcflux.py:181-189,315-316 checkpoint every block): when a buffer of
  * (num_double + num_single) x [B*(T+N), D] bf16 is set, afx_mmdit_forward stores every block's input token matrix
  * there; the training trunk recomputes one block at a time from it.  NULL switches it off. */

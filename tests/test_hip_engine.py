@@ -70,6 +70,35 @@ def test_flux_forward_8phase_gemm_and_separate_qk_prep_launch():
     assert not torch.equal(fused.means, plain.means)          # (they ARE different code paths)
 
 
+def test_prepared_steps_are_bit_identical_to_the_plain_forward():
+    """afx_mmdit_prepare_steps: the modulation vectors of several steps from ONE pass over the stacked modulation matrix.  A forward
+    that takes a prepared step must equal the plain forward at that timestep bit for bit (same kernels, same operands), for
+    every step and sample, and fall back to the plain path when nothing matching is prepared."""
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=1, num_single_layers=1, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=6)
+    B = 2
+    hid, ctx, pooled = _inputs(B, 8, 8, 9, 128, 64, seed=7)
+    gd = torch.full((B,), 3.5)
+    sig = [1.0, 0.7619, 0.3]
+    eng = MMDiTEngine('flux', 1, 1, heads=2, joint_dim=128, pooled_dim=64)
+    eng.load_state_dict(w)
+    plain = [eng(hid.cuda(), torch.full((B,), s).cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8) for s in sig]
+    assert eng.prepare_steps(sig, pooled, gd, B, 64, 9)
+    for k in (2, 0, 1):                                  # any order
+        out = eng(hid.cuda(), torch.zeros(B).cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8, prepared_step=k)    # (t argument unused)
+        for name in ('means', 'logweights', 'loggammas'):
+            assert torch.equal(getattr(out, name), getattr(plain[k], name)), (k, name)
+    # one-shot: the next plain call recomputes from its own t
+    again = eng(hid.cuda(), torch.full((B,), sig[1]).cuda(), ctx.cuda(), pooled.cuda(), gd.cuda(), 8, 8)
+    assert torch.equal(again.means, plain[1].means)
+    # a batch that was not prepared falls back to the plain path (and is right)
+    one = eng(hid[:1].cuda(), torch.full((1,), sig[0]).cuda(), ctx[:1].cuda(), pooled[:1].cuda(), gd[:1].cuda(), 8, 8, prepared_step=0)
+    assert torch.equal(one.means, plain[0].means[:1])
+    assert not eng.prepare_steps([0.5] * 5, pooled, gd, B, 64, 9)       # 5 steps x 2 samples > 8 rows: nothing prepared
+
+
 def test_flux_teacher_head():
     from arcflow_amd import MMDiTEngine
     from oracle import dit_ref as D
