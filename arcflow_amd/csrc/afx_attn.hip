@@ -193,6 +193,9 @@ struct AttnExt {            // EXT = true only
   int kv_group;             // query heads per KV head (1 = MHA)
 };
 
+#ifdef AFX_ATTN_TRACE
+__device__ unsigned g_attn_trace4[2 * 4 * 4];
+#endif
 template <int HD, bool EXT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
@@ -220,6 +223,9 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
   const int qrow = min(q0 + ql, S - 1);
   int ntiles = S_pad / KVB;
   int hk = h, Hk = H;
+#ifdef AFX_ATTN_TRACE
+  const unsigned tr_c0 = (unsigned)__builtin_readcyclecounter(), tr_r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
   if (EXT) {
     hk = h / ext.kv_group;
     Hk = H / ext.kv_group;
@@ -426,6 +432,15 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
         *reinterpret_cast<u32x2_t*>(op + d * 32 + g * 8 + hi * 4) = w;
       }
   }
+#ifdef AFX_ATTN_TRACE
+  if (!EXT && lane == 0 && (blockIdx.x == 0 || blockIdx.x == 700)) {      // whole-work-group stamps: shader cycles, 100 MHz ticks, KV tiles
+    unsigned* t4 = g_attn_trace4 + ((blockIdx.x ? 1 : 0) * 4 + wave) * 4;
+    t4[0] = (unsigned)__builtin_readcyclecounter() - tr_c0;
+    t4[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - tr_r0;
+    t4[2] = (unsigned)ntiles;
+    t4[3] = tr_c0;
+  }
+#endif
 }
 
 
@@ -713,6 +728,14 @@ static unsigned* pp_trace_buffer() {
   return buf;
 #else
   return nullptr;
+#endif
+}
+extern "C" int afx_debug_attn_trace4(unsigned* host_out) {      // 4-wave kernel: [2 blocks][4 waves][cycles, 100 MHz ticks, tiles, start]
+#ifdef AFX_ATTN_TRACE
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_trace4), 2 * 4 * 4 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
+#else
+  (void)host_out;
+  return -1;
 #endif
 }
 extern "C" int afx_debug_attn_trace(unsigned* host_out) {

@@ -24,3 +24,16 @@ for blk in range(2):
         t = [buf[(blk * 8 + w) * 8 + i] for i in range(8)]
         d = [(t[i + 1] - t[i]) & 0xffffffff for i in range(7)]
         print(f'  w{w}: M {d[0]:5d} {d[1]:5d} {d[2]:5d} | S {d[3]:5d} {d[4]:5d} {d[5]:5d} {d[6]:5d} | total {sum(d):6d}   (start {t[0] - buf[(blk*8)*8]:+d})')
+
+# ---- 4-wave kernel (the default): whole-work-group cycles and the shader clock it ran at, after a settled run of launches
+if hasattr(lib, 'afx_debug_attn_trace4'):
+    for _ in range(200):
+        ops.attention(q, k, v)
+    torch.cuda.synchronize()
+    b4 = (C.c_uint * 32)()
+    if lib.afx_debug_attn_trace4(b4) == 0:
+        for blk in range(2):
+            for w in range(4):
+                cyc, ticks, tiles, _ = (b4[(blk * 4 + w) * 4 + i] for i in range(4))
+                print(f'4-wave kernel block {"0" if blk == 0 else "700"} w{w}: {cyc} cycles for {tiles} KV tiles = {cyc / max(tiles, 1):.0f} / tile'
+                      f' (MFMA floor 1024), {ticks} ticks of 10 ns -> shader clock {100.0 * cyc / max(ticks, 1):.0f} MHz')
