@@ -389,20 +389,27 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
         for (int r = 0; r < 16; ++r) oacc[d][r] *= alpha;
     }
     const float mc = m_run * c;
-    float psum = 0.f;
+    // exponent arguments and row sums on value PAIRS (v_pk_fma_f32 / v_pk_add_f32: one issue slot per two values -- the loop is
+    // bound by the SIMD's issue port, ~1700 issue cycles per wave and tile against 1024 matrix-pipe cycles)
+    const f32x2_t c2 = {c, c}, nmc2 = {-mc, -mc};
+    f32x2_t ps2 = {0.f, 0.f};
     bf16x8_t pf[4];          // [16-key group g = kb*2 + ksub]
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float pv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pv[j] = __builtin_amdgcn_exp2f(sacc[g >> 1][(g & 1) * 8 + j] * c - mc);
-        psum += pv[j];
+      for (int j = 0; j < 8; j += 2) {
+        const f32x2_t s2 = {sacc[g >> 1][(g & 1) * 8 + j], sacc[g >> 1][(g & 1) * 8 + j + 1]};
+        const f32x2_t a2 = __builtin_elementwise_fma(s2, c2, nmc2);
+        const f32x2_t e2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+        ps2 += e2;
+        pv[j] = e2[0];
+        pv[j + 1] = e2[1];
       }
       const u32x4_t w = pack8(pv);
       pf[g] = __builtin_bit_cast(bf16x8_t, w);
     }
-    l_run += psum;
+    l_run += ps2[0] + ps2[1];
     // ---- E ----
     AFX_SYNC_DMA();
     // ---- F ----
