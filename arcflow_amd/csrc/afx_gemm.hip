@@ -1054,7 +1054,7 @@ constexpr int V3_THREADS = 256;
 constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (32 * NJ) * 128; }
 
 template <int MI, int NJ>
-__global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3(const GemmBatch batch) {
+__global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_kernel_v3(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ;
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
   constexpr int NM = MI * NJ;                                  // MFMAs per k-half
@@ -1277,10 +1277,12 @@ bool gemm_qk_fusion_available() {
 }
 void gemm_set_mode(int impl, int tile) {
   gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;
-  gemm_mode().tile = (tile >= 0 && tile <= 3) ? tile : 0;
+  gemm_mode().tile = (tile >= 0 && tile <= 4) ? tile : 0;
 }
 struct TileCfg { int tm, tn, group_m; };
-static const TileCfg kTileCfg[3] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}};
+// {4,4} = 128x128: 64 accumulators and 80 KiB of LDS, TWO work-groups per CU -- for launches that would leave most CUs without a
+// 256x256 tile (the rank-256 LoRA products of the distillation step: N = 256 or M = 256, 12-84 tiles at 256x256)
+static const TileCfg kTileCfg[4] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}, {128, 128, 8}};
 
 static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   int total = 0;
@@ -1369,13 +1371,18 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   if (v3_ok) {
     int best = 0;
     if (qk) best = 0;                                   // one head = one wave's 128 columns: the 256x256 shape only
-    else if (tile_env >= 1 && tile_env <= 3) best = tile_env - 1;
+    else if (tile_env >= 1 && tile_env <= 4) best = tile_env - 1;
     else {
       double best_cost = 0;
-      for (int c = 0; c < 3; ++c) {
+      int tiles256 = 0;
+      for (int c = 0; c < 4; ++c) {
         const int tiles = count_tiles(batch, kTileCfg[c].tm, kTileCfg[c].tn, false);
         if (tiles == 0) return hipSuccess;
-        const int rounds = (tiles + cus - 1) / cus;
+        if (c == 0) tiles256 = tiles;
+        if (c == 3 && tiles256 * 2 > cus) continue;   // 128x128 only where 256x256 leaves half the CUs idle (measured: the 864-tile
+                                                      // mlp GEMM as 3456 small tiles takes 362 us against 287)
+        const int slots = c == 3 ? 2 * cus : cus;
+        const int rounds = (tiles + slots - 1) / slots;
         // 256x256 has the best MFMA : LDS-read ratio (4 : 1 against 3.6 : 1 / 3.75 : 1) and the chip is power-capped: a tile
         // shape that fills the last round only makes every CU clock lower.  Measured with weights streaming from HBM
         // (tools/gemm_trace.hip TRACE_COLD=1, r02s): 288x192 wins 4-6 % at K = 3072 where it saves a round or fills a 216-tile
@@ -1383,6 +1390,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
         double pen = 1.0;
         if (c == 1) pen = batch.p[0].K <= 8192 ? 1.05 : 1.5;
         if (c == 2) pen = 1.10;
+        if (c == 3) pen = 2.0;          // 16 MFMAs per 8 fragment reads and 4 DMA issues per k-half: the loop runs at about half rate
         const double cost = (double)rounds * kTileCfg[c].tm * kTileCfg[c].tn * pen;
         if (c == 0 || cost < best_cost) { best = c; best_cost = cost; }
       }
@@ -1392,7 +1400,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (total == 0) return hipSuccess;
     batch.group_m = group_m_env ? group_m_env : kTileCfg[best].group_m;
     batch.sk_cus = 0;
-    return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream) : launch_v3<10, 6>(batch, total, stream);
+    return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream)
+         : best == 2 ? launch_v3<10, 6>(batch, total, stream) : launch_v3<4, 4>(batch, total, stream);
   }
   int total = count_tiles(batch, BM, BN, true);
   batch.total_tiles = total;
