@@ -355,6 +355,63 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   }
 }
 
+// fp32 output of the weight-gradient products (GemmProblem::out_f32 1: store, 2: C += result; no bias / activation there): 8
+// consecutive columns per lane after the permlane exchange = two 16-byte accesses; rows >= M and masked columns dropped by the
+// bounds check.  The accumulate mode's read of C is requested one row tile ahead.
+template <int MI, int NJ>
+AFX_DEV void epi_store_f32(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+  constexpr int NS = NJ / 2;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int M = P.M, N = P.N;
+  const bool accum = P.out_f32 == 2;
+  const int rows_ok = min(max(M - row_base, 0), MI * 16);
+  const int64_t ldc = P.ldc;
+  float* const Cf = reinterpret_cast<float*>(P.C);
+  __amdgpu_buffer_rsrc_t rc = uniform_rsrc(Cf + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 4));
+  const int ldc4 = (int)(ldc * 4);
+  uint32_t coff[NS];
+  float bias[NS][8];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const int gcol = col_base + (2 * st + (fq & 1)) * 16 + (fq >> 1) * 8;
+    coff[st] = gcol < N ? (uint32_t)gcol * 4u : OOB;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[st][e] = 0.f;
+    if (P.bias != nullptr && gcol < N) unpack8(*reinterpret_cast<const u32x4_t*>(P.bias + gcol), bias[st]);
+  }
+  f32x4_t old[2][NS][2];
+  auto fetch = [&](int ii) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      const int off = (int)((uint32_t)((ii * 16 + frow) * ldc4) + coff[st]);
+      old[ii & 1][st][0] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0));
+      old[ii & 1][st][1] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rc, off + 16, 0, 0));
+    }
+  };
+  if (accum) fetch(0);
+#pragma unroll
+  for (int ii = 0; ii < MI; ++ii) {
+    if (accum && ii + 1 < MI) fetch(ii + 1);
+    const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc4);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      f32x4_t o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        o0[e] = __uint_as_float(sw[0]) + bias[st][e];
+        o1[e] = __uint_as_float(sw[1]) + bias[st][4 + e];
+      }
+      if (accum) {
+        o0 += old[ii & 1][st][0];
+        o1 += old[ii & 1][st][1];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o0), rc, (int)(roff + coff[st]), 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o1), rc, (int)(roff + coff[st]) + 16, 0, 0);
+    }
+  }
+}
+
 // (uniform) the forward's epilogue modes: bf16 out, no fp8 scales / convolution border / pre-add
 AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.conv_wp == 0; }
 
@@ -444,6 +501,9 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
   }
 }
 
+#ifndef V3_F32_EPI
+#define V3_F32_EPI 1
+#endif
 template <int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
 AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   if constexpr (NJ == 8 && SWAP && !FP8 && !PRE) {
@@ -452,6 +512,9 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
       if (region == 0) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
       if (region == 2) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
     }
+  }
+  if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4)) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
+    if (P.out_f32 == 1 || P.out_f32 == 2) { epi_store_f32<MI, NJ>(P, acc, row_base, col_base, frow, fq); return; }
   }
   if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
   else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
@@ -1355,7 +1418,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   bool v3_ok = impl == 3 && sk_env == 0 && batch.sk_force == 0;
   for (int i = 0; i < batch.nprob; ++i) {
     const GemmProblem& p = batch.p[i];
-    v3_ok = v3_ok && p.out_f32 == 0 && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
+    const bool bf16_out = p.out_f32 == 0, f32_out = (p.out_f32 == 1 || p.out_f32 == 2) && p.epi == EPI_NONE;     // (3 = split-K slabs: 8-phase)
+    v3_ok = v3_ok && (bf16_out || f32_out) && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
   }
   bool qk = false;
   for (int i = 0; i < batch.nprob; ++i) {
