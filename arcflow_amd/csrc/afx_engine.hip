@@ -497,6 +497,33 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   // q / k RMSNorm + RoPE inside the epilogue of the k|v|q projections (GemmProblem::qk_D) when the GEMM kernel in use offers it:
   // the separate launch then only transposes V.  Not in fp8 mode (that kernel has no such epilogue).
   const bool qk_fuse = gemm_qk_fusion_available() && !c->fp8;
+  // ... and V^T straight out of the projection (GemmProblem::w_perm16 / bias_rows: the V third computed transposed, A = the V rows
+  // of the weight, W = the tokens) when the 16-key groups of the joint sequence do not straddle the text / image boundary and no
+  // key padding is needed: then no preparation launch is left between the projection and the attention.
+  const int S_pad_ = (int)attn_spad(S);
+  const bool vt_fuse = qk_fuse && T % 16 == 0 && S % 64 == 0 && getenv("AFX_VT_FUSE_OFF") == nullptr;
+  const int64_t vt_sample = (int64_t)H * 128 * S_pad_;           // elements of one sample's V^T
+  // the k, q and transposed-v problems of one k|v|q(|mlp) projection over `rows` joint rows starting at joint row `row0` of sample b
+  auto kqv_problems = [&](GemmBatch& gb, const uint16_t* A, int64_t lda, const LinW& lw, uint16_t* C, int64_t ldc, int64_t row0g,
+                          int rows, int b, int pos0, int period, const float* wq, const float* wk, bool with_v) {
+    for (int part = 0; part < (with_v ? 3 : 2); ++part) {        // 0: k (weight rows 0..D), 1: q (2D..3D), 2: v^T (D..2D)
+      GemmProblem& p = gb.p[gb.nprob++];
+      p = GemmProblem{};
+      p.K = (int)D; p.epi = EPI_NONE;
+      if (part < 2) {
+        const int64_t wrow = part == 0 ? 0 : 2 * D;
+        p.A = A + row0g * lda; p.lda = lda;
+        p.W = lw.w + wrow * D; p.ldw = D; p.bias = lw.b ? lw.b + wrow : nullptr;
+        p.C = C + row0g * ldc + wrow; p.ldc = ldc; p.M = rows; p.N = (int)D;
+        p.qk_D = (int)D; p.qk_wk = part == 0 ? wk : wq; p.qk_wq = p.qk_wk;       // a problem of its own: its columns are "region 0"
+        p.rope_cos = rope_cos; p.rope_sin = rope_sin; p.rope_row0 = pos0; p.rope_period = period; p.rope_rows = (int)S;
+      } else {
+        p.A = lw.w + D * D; p.lda = D; p.bias = lw.b ? lw.b + D : nullptr; p.bias_rows = 1;
+        p.W = A + row0g * lda; p.ldw = lda; p.w_perm16 = 1;
+        p.C = ws.Vt + (int64_t)b * vt_sample + pos0; p.ldc = S_pad_; p.M = (int)D; p.N = rows;
+      }
+    }
+  };
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
                          int blk, int gate_chunk, const float* qkn = nullptr) -> int {
     GemmBatch gb{};
@@ -546,9 +573,19 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if ((rc = join_side(i))) return rc;
     if (c->ckpt) HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)i * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     if ((rc = stream_norm(i, 0, 1))) return rc;
+    if (vt_fuse) {                        // per sample: img k, q, v^T + txt k, q, v^T = 6 problems in one launch
+      for (int b = 0; b < B; ++b) {
+        GemmBatch gb{};
+        for (int s = 0; s < 2; ++s)
+          kqv_problems(gb, ws.Xn, D, bw.qkv[s], QKV, 3 * D, (int64_t)b * S + (s == 0 ? T : 0), s == 0 ? N : T, b, s == 0 ? T : 0, 1 << 30,
+                       qkn + (s == 0 ? 0 : 2) * 128, qkn + (s == 0 ? 1 : 3) * 128, true);
+        { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
+      }
+    } else
     if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr))) return rc;
     // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
-    if (qk_fuse)
+    if (vt_fuse) {
+    } else if (qk_fuse)
       HIP_TRY(launch_v_transpose(QKV + D, 3 * D, ws.Vt, B, H, S, st));
     else
     HIP_TRY(launch_kv_prep(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn, rope_cos, rope_sin, T, QKV + D,
@@ -579,13 +616,29 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));
       f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = bw.fused.wscale;
     }
-    if (qk_fuse) {                      // [q, k][128]; the joint rows of every sample: position = row % S
+    if (vt_fuse && B + 3 <= GEMM_MAX_PROBLEMS) {
+      // k and q over the joint rows of every sample (position = row % S), the mlp columns, one transposed v per sample
+      gb.nprob = 0;
+      kqv_problems(gb, ws.Xn, D, bw.fused, ws.F, 7 * D, 0, (int)R, 0, 0, (int)S, qkn, qkn + 128, false);
+      GemmProblem& m = gb.p[gb.nprob++];
+      m = GemmProblem{};
+      m.A = ws.Xn; m.lda = D; m.W = bw.fused.w + 3 * D * D; m.ldw = D; m.bias = bw.fused.b ? bw.fused.b + 3 * D : nullptr;
+      m.C = ws.F + 3 * D; m.ldc = 7 * D; m.M = (int)R; m.N = (int)(4 * D); m.K = (int)D; m.epi = EPI_GELU; m.gelu_col0 = 0;
+      for (int b = 0; b < B; ++b) {
+        GemmProblem& v = gb.p[gb.nprob++];
+        v = GemmProblem{};
+        v.A = bw.fused.w + D * D; v.lda = D; v.bias = bw.fused.b ? bw.fused.b + D : nullptr; v.bias_rows = 1;
+        v.W = ws.Xn + (int64_t)b * S * D; v.ldw = D; v.w_perm16 = 1;
+        v.C = ws.Vt + (int64_t)b * vt_sample; v.ldc = S_pad_; v.M = (int)D; v.N = (int)S; v.K = (int)D; v.epi = EPI_NONE;
+      }
+    } else if (qk_fuse) {               // [q, k][128]; the joint rows of every sample: position = row % S
       f.qk_D = (int)D; f.qk_wq = qkn; f.qk_wk = qkn + 128;
       f.rope_cos = rope_cos; f.rope_sin = rope_sin; f.rope_row0 = 0; f.rope_period = (int)S; f.rope_rows = (int)S;
     }
     gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
-    if (qk_fuse)
+    if (vt_fuse && B + 3 <= GEMM_MAX_PROBLEMS) {
+    } else if (qk_fuse)
       HIP_TRY(launch_v_transpose(ws.F + D, 7 * D, ws.Vt, B, H, S, st));
     else
     HIP_TRY(launch_kv_prep(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, T, ws.F + D, 7 * D, ws.Vt, B,

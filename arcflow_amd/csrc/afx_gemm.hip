@@ -211,7 +211,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
       for (int e = 0; e < CW; ++e) wsc[st][e] = col_ok ? P.w_scale[gcol[st] + e] : 0.f;
     }
-    if (biasp != nullptr && col_ok) {
+    if (biasp != nullptr && col_ok && !P.bias_rows) {
       if constexpr (SWAP) {
         unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[st]), bias[st]);
       } else {
@@ -281,9 +281,15 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     single = b_first == b_last;
     fetch_gate(b_first, g1);
   }
+  const bool row_bias = biasp != nullptr && P.bias_rows != 0;       // (uniform) bias[row]: the transposed V projection
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
+    float rb = 0.f;
+    if (row_bias) {
+      const int grow = min(row_base + ii * 16 + frow, M - 1);
+      rb = __uint_as_float((uint32_t)biasp[grow] << 16);
+    }
     float gi[NS][CW];
     if constexpr (PRE || FP8) {
       if (ii + PF < MI) fetch_pre(ii + PF);
@@ -321,7 +327,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         for (int e = 0; e < CW; ++e) v[e] *= asc[ii % (PF + 1)] * wsc[st][e];
       }
 #pragma unroll
-      for (int e = 0; e < CW; ++e) v[e] += bias[st][e];
+      for (int e = 0; e < CW; ++e) v[e] += bias[st][e] + rb;
       if constexpr (PRE) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) {
@@ -1160,6 +1166,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #pragma unroll
   for (int i = 0; i < NJ; ++i) {
     int br = n0 + prow + 32 * i;
+    if (P.w_perm16) br = (br & ~15) + 4 * ((br & 15) >> 3) + (br & 3) + 8 * ((br >> 2) & 1);   // key_of_pos: column p <- key of position p
     br = br < P.N ? br : P.N - 1;
     woff[i] = (uint32_t)((int64_t)br * P.ldw * 2 + pc);
   }
@@ -1426,11 +1433,16 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     const GemmProblem& p = batch.p[i];
     if (p.qk_D > 0) {
       qk = true;
-      if (p.qk_D % 128 || p.N < 3 * p.qk_D || !p.qk_wk || !p.qk_wq || !p.rope_cos || !p.rope_sin || p.rope_period < 1 || p.rope_rows < 1 ||
+      if (p.qk_D % 128 || p.N < p.qk_D || !p.qk_wk || !p.qk_wq || !p.rope_cos || !p.rope_sin || p.rope_period < 1 || p.rope_rows < 1 ||
           p.epi == EPI_GATE_RES)
         return hipErrorInvalidValue;
     }
   }
+  for (int i = 0; i < batch.nprob; ++i)
+    if (batch.p[i].w_perm16 || batch.p[i].bias_rows) {
+      qk = true;                                         // same kernel requirement (and the 256x256 shape: tested there)
+      if (batch.p[i].out_f32 != 0 || batch.p[i].epi != EPI_NONE || (batch.p[i].w_perm16 && batch.p[i].N % 16)) return hipErrorInvalidValue;
+    }
   if (qk && !v3_ok) return hipErrorInvalidValue;        // callers ask gemm_qk_fusion_available() first
   if (v3_ok) {
     int best = 0;

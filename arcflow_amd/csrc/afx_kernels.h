@@ -37,6 +37,10 @@ struct GemmProblem {
   const float* rope_cos;
   const float* rope_sin;
   int32_t qk_D, rope_row0, rope_period, rope_rows;
+  // V^T straight out of the projection (one-wave-per-SIMD kernel): the product is computed transposed -- A = the V rows of the
+  // weight, W = the token matrix -- so C [head_dim * heads, keys] IS the attention kernel's V^T operand; w_perm16 loads the W rows
+  // (keys) of every 16-group in the order key_of_pos (afx_attn.hip) wants its columns, bias_rows adds bias[row] instead of bias[col].
+  int32_t w_perm16, bias_rows;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 

@@ -22,7 +22,8 @@ def _inputs(B, hp, wp, T, joint, pooled_dim, seed=1):
 
 
 @pytest.mark.parametrize('B,hp,wp,T,nd,ns', [(1, 8, 8, 16, 2, 2), (2, 6, 10, 7, 1, 3), (1, 16, 16, 77, 1, 0),
-                                             (6, 4, 4, 5, 1, 1)])      # batch 6: two micro-batches (4 + 2) inside the library
+                                             (6, 4, 4, 5, 1, 1),       # batch 6: two micro-batches (4 + 2) inside the library
+                                             (2, 6, 8, 16, 1, 2)])     # T % 16 == 0 and S = 64: V^T comes straight out of the projection
 def test_flux_forward_vs_oracle(B, hp, wp, T, nd, ns):
     from arcflow_amd import MMDiTEngine
     from oracle import dit_ref as D
