@@ -154,7 +154,7 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 // wave to hide that chain's latency behind).
 // FP8: the product is scaled by a_scale[row] * w_scale[col] first (row-wise activation, per-output-channel weight scales);
 // PRE: a bf16 [M, N] term (GemmProblem::pre, the LoRA-dropout correction) is added before the activation / gate.
-template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? NJ / 2 : NJ;       // steps per row tile
@@ -211,7 +211,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
       for (int e = 0; e < CW; ++e) wsc[st][e] = col_ok ? P.w_scale[gcol[st] + e] : 0.f;
     }
-    if (biasp != nullptr && col_ok && !P.bias_rows) {
+    if (biasp != nullptr && col_ok && !ROWB) {
       if constexpr (SWAP) {
         unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol[st]), bias[st]);
       } else {
@@ -281,14 +281,12 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     single = b_first == b_last;
     fetch_gate(b_first, g1);
   }
-  const bool row_bias = biasp != nullptr && P.bias_rows != 0;       // (uniform) bias[row]: the transposed V projection
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
-    float rb = 0.f;
-    if (row_bias) {
-      const int grow = min(row_base + ii * 16 + frow, M - 1);
-      rb = __uint_as_float((uint32_t)biasp[grow] << 16);
+    float rb = 0.f;                                               // ROWB: bias[row] (the transposed V projection)
+    if constexpr (ROWB) {
+      if (biasp != nullptr) rb = __uint_as_float((uint32_t)biasp[min(row_base + ii * 16 + frow, M - 1)] << 16);
     }
     float gi[NS][CW];
     if constexpr (PRE || FP8) {
@@ -327,7 +325,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         for (int e = 0; e < CW; ++e) v[e] *= asc[ii % (PF + 1)] * wsc[st][e];
       }
 #pragma unroll
-      for (int e = 0; e < CW; ++e) v[e] += bias[st][e] + rb;
+      for (int e = 0; e < CW; ++e) v[e] += ROWB ? rb : bias[st][e];
       if constexpr (PRE) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) {
@@ -524,6 +522,7 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
   }
   if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
   else if (P.epi == EPI_GELU) epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+  else if (SWAP && !FP8 && !PRE && !(MI == 8 && NJ == 4) && P.bias_rows) epi_store_fast<EPI_NONE, MI, NJ, SWAP, false, false, true>(P, acc, row_base, col_base, frow, fq);
   else epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
 }
 
