@@ -196,6 +196,16 @@ struct AttnExt {            // EXT = true only
 #ifdef AFX_ATTN_TRACE
 __device__ unsigned g_attn_trace4[2 * 4 * 4];
 #endif
+AFX_DEV uint64_t att_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit value, in an SGPR pair
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// LDS-DMA, 16 bytes per lane: M0 = LDS byte address of the wave's 1 KiB destination, global address = SGPR pair + 32-bit lane offset
+#define ATT_DMA(BASE_U64, VOFF, LDS_PTR)                                                                                            \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"((uint32_t)(uintptr_t)(LDS_PTR)), "v"(VOFF), \
+               "s"(BASE_U64)                                                                                                       \
+               : "memory")
 template <int HD, bool EXT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
@@ -282,10 +292,13 @@ __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
       }
     } else {
+      // SGPR base + 32-bit lane offset, from inline asm: inside the loop hipcc widens the builtin's address to a 64-bit VGPR pair
+      // and a v_lshl_add_u64 per issue (8 VALU + 16 offset registers per tile in a loop bound by the issue port)
+      const uint64_t kt_u = att_uniform_u64((uint64_t)(uintptr_t)kt), vt_u = att_uniform_u64((uint64_t)(uintptr_t)vt_);
 #pragma unroll
       for (int i = 0; i < DT; ++i) {
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(kt + koff[i]), (lds_void_t*)(kd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(vt_ + voff[i]), (lds_void_t*)(vd + (i * ATT_THREADS + wave_u * 64) * 16), 16, 0, 0);
+        ATT_DMA(kt_u, koff[i], kd + (i * ATT_THREADS + wave_u * 64) * 16);
+        ATT_DMA(vt_u, voff[i], vd + (i * ATT_THREADS + wave_u * 64) * 16);
       }
     }
   };
