@@ -154,7 +154,8 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 // wave to hide that chain's latency behind).
 // FP8: the product is scaled by a_scale[row] * w_scale[col] first (row-wise activation, per-output-channel weight scales);
 // PRE: a bf16 [M, N] term (GemmProblem::pre, the LoRA-dropout correction) is added before the activation / gate.
-template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false>
+// CONV: the rows are pixels of a zero-bordered [conv_hp][conv_wp] grid (implicit 3x3 convolution): border pixels are stored as zero.
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? NJ / 2 : NJ;       // steps per row tile
@@ -284,6 +285,14 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
+    bool border = false;
+    if constexpr (CONV) {
+      const int grow = row_base + ii * 16 + frow, wp = P.conv_wp;
+      int yy = (int)((float)grow * (1.0f / (float)wp));           // grow / wp up to +-1: fix up exactly
+      int xx = grow - yy * wp;
+      if (xx < 0) { xx += wp; --yy; } else if (xx >= wp) { xx -= wp; ++yy; }
+      border = yy == 0 || yy == P.conv_hp - 1 || xx == 0 || xx == wp - 1;
+    }
     float rb = 0.f;                                               // ROWB: bias[row] (the transposed V projection)
     if constexpr (ROWB) {
       if (biasp != nullptr) rb = __uint_as_float((uint32_t)biasp[min(row_base + ii * 16 + frow, M - 1)] << 16);
@@ -345,6 +354,10 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
           const float rr = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
           v[e] = rr + (has_gate ? gi[st][e] : 1.0f) * v[e];       // no gate: plain residual add
         }
+      }
+      if constexpr (CONV) {
+#pragma unroll
+        for (int e = 0; e < CW; ++e) v[e] = border ? 0.f : v[e];
       }
       if constexpr (SWAP) {
         float v8[8];
@@ -528,6 +541,13 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
 
 template <bool FP8K = false>
 AFX_DEV void epi_store_direct(const GemmProblem& P, f32x4_t (&acc)[8][4], int row_base, int col_base, int frow, int fq, int chunk) {
+  if constexpr (!FP8K) {
+    if (P.conv_wp > 0 && P.out_f32 == 0 && P.pre == nullptr && P.fp8 == 0 && P.epi != EPI_GELU) {       // the VAE's convolutions
+      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, 8, 4, true, false, false, false, true>(P, acc, row_base, col_base, frow, fq);
+      else epi_store_fast<EPI_NONE, 8, 4, true, false, false, false, true>(P, acc, row_base, col_base, frow, fq);
+      return;
+    }
+  }
   if (epi_is_fast(P)) {                                          // bf16 output without a convolution border: straight-line code
     if constexpr (FP8K) {
       if (P.pre == nullptr) { epi_store_fast_any<8, 4, true, true, false>(P, acc, row_base, col_base, frow, fq); return; }
