@@ -205,7 +205,8 @@ AFX_DEV uint64_t att_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit val
 #define ATT_DMA(BASE_U64, VOFF, LDS_PTR)                                                                                            \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"((uint32_t)(uintptr_t)(LDS_PTR)), "v"(VOFF), \
                "s"(BASE_U64)                                                                                                       \
-               : "memory")
+               : "memory", "m0")     /* m0 is compiler-reserved: the entry only draws a warning, but it records the write for the */ \
+                                     /* builtin LDS-DMA of the ragged tail (never leave the M0 write invisible)       */
 template <int HD, bool EXT>
 __global__ __launch_bounds__(ATT_THREADS, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk,
@@ -775,18 +776,31 @@ extern "C" int afx_debug_attn_trace(unsigned* host_out) {
 #endif
 }
 
+static int& attn_impl() {
+  static int impl = -1;
+  return impl;
+}
+void attn_set_impl(int impl) { attn_impl() = (impl >= 0 && impl <= 3) ? impl : 0; }
+
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
                             hipStream_t stream, float* lse) {
   const int S_pad = (int)attn_spad(S);
   const int heads_per_xcd = (H + 7) / 8;
-  static int impl = -1;
+  int& impl = attn_impl();
+  static bool attr = false;
   if (impl < 0) {
-    const char* e = getenv("AFX_ATTN_IMPL");               // 2: the 8-wave ping-pong kernel (experimental, see its header), default: 4-wave
-    impl = (e && e[0] == '2') ? 2 : 1;
+    // AFX_ATTN_IMPL / attn_set_impl: 0 (default) = the one-wave-per-SIMD kernel (afx_attn3.hip) where eligible, else the 4-wave kernel;
+    // 1 = 4-wave kernel always; 2 = the 8-wave ping-pong kernel (experimental, see its header); 3 = as 0
+    const char* e = getenv("AFX_ATTN_IMPL");
+    impl = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
+  }
+  if (!attr) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(attention_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP_LDS_BYTES);
     if (r != hipSuccess) return r;
+    attr = true;
   }
+  if ((impl == 0 || impl == 3) && attention_v3_eligible(S)) return launch_attention_v3(q, ldq, k, ldk, vt, o, ldo, B, H, S, stream, lse);
   if (impl == 2 && S >= 2 * PP_QB) {
     const int nq8 = (S + PP_QB - 1) / PP_QB;
     dim3 grid8(8 * heads_per_xcd * nq8 * B);

@@ -1,0 +1,284 @@
+// Joint flash attention forward for gfx950 -- ONE wave per SIMD, 64 queries per wave, hand-placed instruction stream.
+// head_dim 128, bf16 in / out, no mask, S a multiple of 64.  The MMDiT product path (afx_attn.hip's 4-wave kernel stays for
+// ragged sequences and the text encoders' EXT variants; launch_attention dispatches).
+//
+// Same mathematics and operand layouts as attention_kernel (afx_attn.hip): both products transposed on v_mfma_f32_32x32x16_bf16,
+//     S^T = K . Q^T   D[key][query]         O^T = V^T . P^T   D[d][query]
+// so lane (q, hi) owns query q of a 32-query slab in both, the softmax row is lane-local, and the exponentiated scores are
+// already the B operand of the second product given the key permutation baked into V^T (key_of_pos).
+//
+// What is different -- the structure DESIGN.md 4.2 / 12.1 asked for (round 2 measured two compiler-scheduled waves per SIMD
+// over-subscribing the issue port: ~1550 issue cycles per wave and tile beside 1024 matrix-pipe cycles):
+//   * a work-group = 4 waves = one 256-query block, one wave per SIMD with the whole 512-register file:
+//       accumulator file: O^T 2 slabs x 4 d-tiles x 16 = 128 | Q^T fragments 2 x 8 x 4 = 64 | K fragments 2 x 8 x 4 = 64
+//       arch VGPRs:       S^T 2 slabs x 2 key blocks x 16 = 64 | P^T 2 x 16 | V^T fragments 64 | addresses, m, l
+//     K / V^T fragments are read ONCE per 64 queries (32 + 32 ds_read_b128 per 64 MFMAs; the 4-wave kernel: per 32).
+//   * the two 32-query slabs A, B of a wave run half a tile apart: while the matrix pipe does slab A's 32 MFMAs of a tile
+//     (S_A^T(t+1) = K(t+1) Q_A^T, then O_A^T += V^T(t) P_A^T(t)), the VALU does slab B's softmax of tile t, and vice versa --
+//     the overlap two independent work-groups per CU gave by accident, now by construction inside one in-order wave.
+//   * every instruction of the loop is an `asm volatile` statement, so the source order IS the issue order: after each MFMA
+//     at most one memory instruction (ds_read_b128 or LDS-DMA) and 4-5 VALU (MI355X_MICROARCH: <= 5 single-issue fillers hide
+//     in a 32-cycle MFMA gap of a lone wave).  The stream is GENERATED (tools/gen_attn3.py -> gen/a3_*.inc, committed) and all
+//     wide operands are ASM-OWNED: literal register names in the instruction text (map in the generator's header), while
+//     `amdgpu_num_vgpr(192)` confines hipcc's own allocation to v[0:95].  Left to allocate 461 of 512 registers itself hipcc
+//     split live ranges and spilled (464 registers, 2600 accumulator moves in the first build; the generator's header lists
+//     what else was tried).  hipcc inserts no waits and no hazard padding inside this stream, so every dependency is kept
+//     >= 16 MFMAs apart by the phase structure or carries an explicit s_nop / s_waitcnt; arcflow_amd/build.py audits the ISA
+//     after every build (no accumulator move, no scratch access outside the asm statements).
+//   * K and V^T tiles stream by LDS-DMA into two 4-slot rings (128 KiB): K(t+4) and V^T(t+2) are issued in iteration t, ONE
+//     `s_waitcnt vmcnt(8)` + s_barrier per tile retires everything issued two iterations ago (K(t+2), V^T(t)): two tile times
+//     of lead for the K read at the end of iteration t, and never vmcnt(0) in the loop.  The loop is unrolled x4 so that ring
+//     slots are immediates of the ds_read / M0 offsets (no address arithmetic in the loop).
+//   * the O rescale is deferred (row max grown by more than 2^5, as in the 4-wave kernel) and lives on a cold path
+//     (accumulator-file reads / writes with explicit wait states).
+#include <cstdlib>
+
+#include <hip/hip_ext.h>
+
+#include "afx_common.h"
+#include "afx_kernels.h"
+
+namespace afx {
+namespace a3 {
+
+constexpr int KVB = 64;                 // keys per tile
+constexpr int QBLK = 256;               // queries per work-group (4 waves x 2 slabs x 32)
+constexpr int THREADS = 256;
+constexpr int TILE_BYTES = KVB * 128 * 2;            // 16 KiB: K tile [64 keys][128 d] or V^T tile [128 d][64 keys]
+constexpr int SLOTS = 4;
+constexpr int V_BASE = SLOTS * TILE_BYTES;           // V^T ring behind the K ring
+constexpr int LDS_BYTES = 2 * SLOTS * TILE_BYTES;    // 131072
+constexpr float RESCALE_LOG2 = 5.0f;
+
+#ifdef AFX_ATTN_TRACE
+__device__ unsigned g_attn3_trace[2 * 4 * 16];
+#endif
+
+AFX_DEV uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+#include "gen/a3_rescale.inc"
+#include "gen/a3_readout.inc"
+
+// One tile = iteration t with ring slot J = t & 3 (gen/a3_body{J}.inc):
+//   phase A   MFMA: S_A^T(t+1) (16), O_A^T += V^T(t) P_A^T(t) (16)   VALU: softmax of S_B(t)     LDS: V^T(t) fragments | DMA K(t+4)
+//   phase B   MFMA: S_B^T(t+1) (16), O_B^T += V^T(t) P_B^T(t) (16)   VALU: softmax of S_A(t+1)   DMA V^T(t+2) | LDS: K(t+2) fragments
+// Softmax of one slab and tile = 134 instructions (gen_attn3.softmax_ops): two interleaved v_max3 chains, the xor-32 exchange,
+// the rescale decision (cold branch), then per score fma / exp2 / row-sum add and per pair cvt_pk, software-pipelined so that a
+// v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
+__global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+                                                                  int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
+                                                                  int64_t ldo, int H, int S, int nqb, int B, float* __restrict__ lse, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ql = lane & 31, hi = lane >> 5;
+  // head -> XCD affinity as in the 4-wave kernel: XCD x owns heads x, x + 8, ...
+  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+  const int per_head = nqb * B;
+  const int h = xcd + 8 * (slot_id / per_head);
+  if (h >= H) return;
+  const int rem = slot_id % per_head;
+  const int b = rem / nqb;
+  const int q0 = (rem % nqb) * QBLK + wave * 64;
+  const int ntiles = S / KVB;                                    // S % 64 == 0 (launcher)
+  const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
+  const float neg_c = -c;
+  const float thr = RESCALE_LOG2 / c;
+
+  // bring-up aid (AFX_ATTN3_DBG=n, 0 in production): the whole work-group leaves after stage n with everything drained
+#define A3_DBG(n)                                                      \
+  if (dbg == (n)) {                                                    \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+    return;                                                            \
+  }
+  A3_DBG(1)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  const uint32_t wave_lds = lds0 + wave * 1024;
+
+  // ---- lane constants ---------------------------------------------------------------------------------------------------------
+  // fragment read addresses inside a slot (swizzles as the DMA sources below): K row ql (+32 kb), chunk (2s + hi) ^ (row & 15);
+  // V^T row ql (+32 d), chunk (2g + hi) ^ ((row >> 1) & 7)
+#define A3_KADDR(s) (lds0 + ql * 256 + (((2 * (s) + hi) ^ (ql & 15)) << 4))
+#define A3_VADDR(g) (lds0 + V_BASE + ql * 128 + (((2 * (g) + hi) ^ ((ql >> 1) & 7)) << 4))
+  const uint32_t kaddr0 = A3_KADDR(0), kaddr1 = A3_KADDR(1), kaddr2 = A3_KADDR(2), kaddr3 = A3_KADDR(3), kaddr4 = A3_KADDR(4),
+                 kaddr5 = A3_KADDR(5), kaddr6 = A3_KADDR(6), kaddr7 = A3_KADDR(7);
+  const uint32_t vaddr0 = A3_VADDR(0), vaddr1 = A3_VADDR(1), vaddr2 = A3_VADDR(2), vaddr3 = A3_VADDR(3);
+  // DMA sources: K piece i = rows 16 i + tid / 16, physical chunk tid % 16; V^T piece i = rows 32 i + tid / 8, physical chunk tid % 8
+  const int dk_r = tid >> 4, dk_c = ((tid & 15) ^ (dk_r & 15)) << 3;
+  const int dv_r = tid >> 3, dv_c = ((tid & 7) ^ ((dv_r >> 1) & 7)) << 3;
+#define A3_KOFF(i) ((uint32_t)(((int64_t)(dk_r + 16 * (i)) * ldk + dk_c) * 2))
+#define A3_VOFF(i) ((uint32_t)(((int64_t)(dv_r + 32 * (i)) * S + dv_c) * 2))
+  const uint32_t koff0 = A3_KOFF(0), koff1 = A3_KOFF(1), koff2 = A3_KOFF(2), koff3 = A3_KOFF(3);
+  const uint32_t voff0 = A3_VOFF(0), voff1 = A3_VOFF(1), voff2 = A3_VOFF(2), voff3 = A3_VOFF(3);
+  const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * S * ldk + h * 128);
+  const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S);
+  const int64_t ktile_bytes = (int64_t)KVB * ldk * 2;
+  // tiles past the end re-fetch the last one into a free slot: the DMA count per iteration stays 8
+  auto k_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(kbase + tt * ktile_bytes)); };
+  auto v_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(vbase + (int64_t)tt * (KVB * 2))); };
+
+#include "gen/a3_init.inc"
+  float mA = -INFINITY, lA0 = 0.f, lA1 = 0.f, mB = -INFINITY, lB0 = 0.f, lB1 = 0.f;
+  float rs_tmp;
+  (void)rs_tmp;
+  // cold path: advance the running max of a slab and rescale its l and O^T (O^T: gen/a3_rescale.inc)
+#define A3_RESCALE_A(M_NEW)                                        \
+  const float alpha = __builtin_amdgcn_exp2f((mA - (M_NEW)) * c); \
+  mA = (M_NEW);                                                    \
+  lA0 *= alpha;                                                    \
+  lA1 *= alpha;                                                    \
+  A3_OSCALE_A
+#define A3_RESCALE_B(M_NEW)                                        \
+  const float alpha = __builtin_amdgcn_exp2f((mB - (M_NEW)) * c); \
+  mB = (M_NEW);                                                    \
+  lB0 *= alpha;                                                    \
+  lB1 *= alpha;                                                    \
+  A3_OSCALE_B
+
+  // ---- prologue: Q fragments (accumulator file), K(0..3), V^T(0..1) ------------------------------------------------------------
+  {
+    const int r0 = min(q0 + ql, S - 1), r1 = min(q0 + 32 + ql, S - 1);
+    const bf16_t* qptr0 = q + ((int64_t)b * S + r0) * ldq + h * 128 + hi * 8;
+    const bf16_t* qptr1 = q + ((int64_t)b * S + r1) * ldq + h * 128 + hi * 8;
+#include "gen/a3_qload.inc"
+  }
+#include "gen/a3_prologue_dma.inc"
+  A3_DBG(2)
+
+#ifdef AFX_ATTN_TRACE
+  unsigned tr[16];
+  const unsigned tr_c0 = (unsigned)__builtin_readcyclecounter(), tr_r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#define A3_TR(i) if (t == 36) tr[i] = (unsigned)__builtin_readcyclecounter();
+#else
+#define A3_TR(i)
+#endif
+
+  // tile 0, not pipelined: K(0) fragments, S^T(0) of both slabs, slab A's softmax, K(1) fragments
+#include "gen/a3_tile0.inc"
+  A3_DBG(3)
+
+  int t = 0;
+  if (ntiles > 1) {
+#pragma unroll 1
+    for (;;) {
+      {
+#include "gen/a3_body0.inc"
+      }
+      A3_DBG(4)
+      if (++t == ntiles - 1) break;
+      {
+#include "gen/a3_body1.inc"
+      }
+      if (++t == ntiles - 1) break;
+      {
+#include "gen/a3_body2.inc"
+      }
+      if (++t == ntiles - 1) break;
+      {
+#include "gen/a3_body3.inc"
+      }
+      if (++t == ntiles - 1) break;
+    }
+  }
+  A3_DBG(5)
+  // ---- last tile t = ntiles - 1: V^T(t) fragments | softmax of S_B(t) | O_A^T += ..., O_B^T += ... ---------------------------
+  {
+    const uint32_t vs = (uint32_t)(t & 3) * TILE_BYTES;
+#include "gen/a3_final.inc"
+  }
+  A3_DBG(6)
+  // every DMA piece must have landed before this work-group's LDS can be handed to another one; MFMA -> accumulator-read wait states
+  A3_DRAIN
+  A3_DBG(7)
+  // lane constants of the epilogue from an OPAQUE copy of threadIdx: computed before the loop they would have to live through it
+  int tid2 = threadIdx.x;
+  asm volatile("" : "+v"(tid2));
+  const int ql2 = tid2 & 31, hi2 = (tid2 >> 5) & 1;
+  const int q02 = (rem % nqb) * QBLK + __builtin_amdgcn_readfirstlane(tid2 >> 6) * 64;
+
+  // ---- normalise and store, one 32-row tile of O^T at a time: lane (q, hi) holds O[q][32 d + 8 g + 4 hi + 0..3] in ox[4 g + 0..3].
+  // One permlane32 exchange per register pairs the two half-waves' 8-byte pieces into 16 contiguous bytes per lane (8 instead of
+  // 16 stores per slab).
+  float ox[16];
+  auto store_tile = [&](int sl, int d, float inv, int row, bf16_t* op) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int g0 = 2 * kk, g1 = 2 * kk + 1;
+      const uint32_t ax = pack_bf16x2(ox[4 * g0 + 0] * inv, ox[4 * g0 + 1] * inv);
+      const uint32_t ay = pack_bf16x2(ox[4 * g0 + 2] * inv, ox[4 * g0 + 3] * inv);
+      const uint32_t bx = pack_bf16x2(ox[4 * g1 + 0] * inv, ox[4 * g1 + 1] * inv);
+      const uint32_t by = pack_bf16x2(ox[4 * g1 + 2] * inv, ox[4 * g1 + 3] * inv);
+      const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      if (row < S) *reinterpret_cast<u32x4_t*>(op + d * 32 + kk * 16) = (u32x4_t){rx[0], ry[0], rx[1], ry[1]};
+    }
+  };
+#define A3_STORE_SLAB(SL, LSUM, MRUN)                                                                              \
+  {                                                                                                                \
+    const float lsum = (LSUM);                                                                                     \
+    const float l_tot = lsum + __shfl_xor(lsum, 32, 64);                                                           \
+    const float inv = 1.0f / l_tot;                                                                                \
+    const int row = q02 + (SL) * 32 + ql2;                                                                         \
+    if (lse != nullptr && hi2 == 0 && row < S) lse[((int64_t)b * H + h) * S + row] = (MRUN) * c + __log2f(l_tot); \
+    bf16_t* op = o + ((int64_t)b * S + row) * ldo + h * 128 + hi2 * 8;                                             \
+    A3_READ_##SL##_0 store_tile(SL, 0, inv, row, op);                                                              \
+    A3_READ_##SL##_1 store_tile(SL, 1, inv, row, op);                                                              \
+    A3_READ_##SL##_2 store_tile(SL, 2, inv, row, op);                                                              \
+    A3_READ_##SL##_3 store_tile(SL, 3, inv, row, op);                                                              \
+  }
+  A3_STORE_SLAB(0, lA0 + lA1, mA)
+  A3_STORE_SLAB(1, lB0 + lB1, mB)
+#ifdef AFX_ATTN_TRACE
+  if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300)) {
+    unsigned* t4 = g_attn3_trace + ((blockIdx.x ? 1 : 0) * 4 + wave) * 16;
+    t4[0] = (unsigned)__builtin_readcyclecounter() - tr_c0;
+    t4[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - tr_r0;
+    t4[2] = (unsigned)ntiles;
+    t4[3] = tr[1] - tr[0];
+    t4[4] = tr[2] - tr[1];
+  }
+#endif
+}
+
+}  // namespace a3
+
+extern "C" int afx_debug_attn3_trace(unsigned* host_out) {      // [2 blocks][4 waves][16]
+#ifdef AFX_ATTN_TRACE
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(a3::g_attn3_trace), 2 * 4 * 16 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
+#else
+  (void)host_out;
+  return -1;
+#endif
+}
+
+bool attention_v3_eligible(int S) { return S % a3::KVB == 0 && S >= 2 * a3::KVB; }
+
+hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
+                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(a3::attention_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       a3::LDS_BYTES);
+    if (r != hipSuccess) return r;
+    attr = true;
+  }
+  const int nqb = (S + a3::QBLK - 1) / a3::QBLK;
+  const dim3 grid(8 * ((H + 7) / 8) * nqb * B);
+  static int dbg = -1;
+  if (dbg < 0) {
+    const char* e = getenv("AFX_ATTN3_DBG");
+    dbg = e ? atoi(e) : 0;
+  }
+  if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
+                          q, ldq, k, ldk, vt, o, ldo, H, S, nqb, B, lse, dbg);
+  else
+    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, nqb, B, lse, dbg);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -1248,8 +1248,8 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #define V3_DMA(BASE_U64, VOFF, LDS_PTR)                                                                                            \
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"((uint32_t)(uintptr_t)(LDS_PTR)), "v"(VOFF), \
                "s"(BASE_U64)                                                                                                       \
-               : "memory")      /* M0 is a reserved register (a clobber entry is ignored with a warning): no compiler-emitted M0 user \
-                                  -- its own LDS-DMA builtins re-load M0 before every use -- sits between these statements */
+               : "memory", "m0")   /* M0 is compiler-reserved (the clobber entry draws a warning and is otherwise recorded as an   \
+                                     implicit def): the prologue's builtin LDS-DMAs must never see a stale M0 */
   // MFMA m of a k-half: A row tile m / NJ, W column tile m % NJ (operands swapped: the accumulator holds C^T, see epi_store_fast)
 #define V3_MFMA_AT(m, AF, BF) V3_ONE(acc[(m) / NJ][(m) % NJ], BF[(m) % NJ], AF[(m) / NJ])
 

@@ -66,6 +66,12 @@ def set_gemm_mode(impl: int = 3, tile: int = 0) -> None:
     _lib.check(_lib.load().afx_gemm_set_mode(impl, tile))
 
 
+def set_attn_impl(impl: int = 0) -> None:
+    """Kernel choice of the joint attention (``afx_attn_set_impl``): 0 = one-wave-per-SIMD kernel where eligible (default), 1 = 4-wave
+    kernel always, 2 = 8-wave ping-pong kernel (experimental)."""
+    _lib.check(_lib.load().afx_attn_set_impl(impl))
+
+
 def stream_k_workspace(device='cuda') -> torch.Tensor:
     """Zero-initialised workspace for ``linear(..., sk_ws=)`` (hand-off flags + fp32 accumulator slabs of the stream-K tail)."""
     lib = _lib.load()

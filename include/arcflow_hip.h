@@ -358,6 +358,10 @@ int64_t afx_linear_sk_ws_bytes(void);
  * 2: 288x192, 3: 320x192, 4: 128x128); impl 2 = 8-phase 256x256 kernel for everything; impl 1 = simple reference kernel.  Same meaning as the
  * AFX_GEMM_IMPL / AFX_GEMM_TILE environment variables, which it overrides.  Returns 0. */
 int afx_gemm_set_mode(int32_t impl, int32_t tile);
+/* Kernel choice of every joint attention launch (process-wide; same meaning as AFX_ATTN_IMPL, which it overrides): 0 (default) = the
+ * one-wave-per-SIMD kernel (afx_attn3.hip: 64 queries per wave, S % 64 == 0) where eligible, else the 4-wave kernel; 1 = 4-wave kernel
+ * always; 2 = 8-wave ping-pong kernel (experimental).  For A/B runs and the parity tests.  Returns 0. */
+int afx_attn_set_impl(int32_t impl);
 int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                        void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
                        int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
