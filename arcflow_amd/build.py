@@ -16,6 +16,9 @@ LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libarcflow_hip.so'
 SOURCES = ['afx_gemm.hip', 'afx_attn.hip', 'afx_attn3.hip', 'afx_attn_bwd.hip', 'afx_elementwise.hip', 'afx_train.hip', 'afx_vae.hip', 'afx_text.hip', 'afx_engine.hip']
 HEADERS = ['afx_common.h', 'afx_kernels.h', 'afx_api_util.h', os.path.join('..', '..', 'include', 'arcflow_hip.h')]
+HEADERS += [os.path.join('gen', f) for f in sorted(os.listdir(os.path.join(CSRC, 'gen'))) if f.endswith('.inc')]
+# sources whose kernels OWN registers by literal name (tools/gen_attn3.py): their ISA is audited after every build
+ASM_OWNED = {'afx_attn3.hip': 'attention_v3_kernel'}
 
 
 def lib_path() -> str:
@@ -38,6 +41,30 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def audit_asm_owned(asm_path: str, kernel_substr: str) -> None:
+    """A kernel whose registers are asm-owned must contain no compiler-generated accumulator move and no scratch access: hipcc only
+    emits them to spill, and it would spill INTO registers it cannot know are in use (silent corruption).  Raises on a violation."""
+    in_kernel = in_asm = False
+    bad = []
+    with open(asm_path) as f:
+        for n, line in enumerate(f, 1):
+            t = line.strip()
+            if t.endswith(':') and not t.startswith('.L') and not t.startswith(';'):
+                in_kernel = kernel_substr in t
+            if not in_kernel:
+                continue
+            if 'ASMSTART' in t:
+                in_asm = True
+            elif 'ASMEND' in t:
+                in_asm = False
+            elif not in_asm and (t.startswith('v_accvgpr') or t.startswith('scratch_') or t.startswith('buffer_') and 'offen' in t):
+                bad.append(f'{n}: {t}')
+            if '.private_segment_fixed_size' in t or 'ScratchSize' in t:
+                pass
+    if bad:
+        raise RuntimeError(f'{asm_path}: compiler-generated spill code in an asm-owned kernel ({kernel_substr}):\n' + '\n'.join(bad[:20]))
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Compile every HIP source for gfx950 and link the shared library.  Returns its path."""
     out = lib_path()
@@ -55,6 +82,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(obj)
         cmd = [hipcc, *flags, '-c', os.path.join(CSRC, src), '-o', obj]
+        if src in ASM_OWNED:
+            cmd += ['-save-temps=obj', '-Wno-inline-asm']      # keeps the .s next to the object for the audit below
         if verbose:
             print('[arcflow_amd.build]', ' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -64,6 +93,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f'hipcc failed on {src}:\n{log}')
         if verbose and log.strip():
             print(log)
+        if src in ASM_OWNED:
+            audit_asm_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ASM_OWNED[src])
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out]
     if verbose:
         print('[arcflow_amd.build]', ' '.join(cmd), flush=True)
@@ -73,5 +104,39 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return out
 
 
+def build_variant(name: str, extra_flags, sources) -> str:
+    """lib/libarcflow_hip_<name>.so = the standard objects with `sources` recompiled under `extra_flags` (trace / A-B builds that
+    travel next to the product library; select with ARCFLOW_HIP_LIB=<path>)."""
+    build(verbose=False)
+    objdir = os.path.join(LIBDIR, 'obj')
+    vdir = os.path.join(LIBDIR, 'obj_' + name)
+    os.makedirs(vdir, exist_ok=True)
+    hipcc = _hipcc()
+    flags = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-function', '-Wno-inline-asm', *extra_flags]
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(objdir, src.replace('.hip', '.o'))
+        if src in sources:
+            obj = os.path.join(vdir, src.replace('.hip', '.o'))
+            r = subprocess.run([hipcc, *flags, '-c', os.path.join(CSRC, src), '-o', obj, '-save-temps=obj'], stdout=subprocess.PIPE,
+                               stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f'hipcc failed on {src} ({name}):\n{r.stdout}')
+            if src in ASM_OWNED:
+                audit_asm_owned(os.path.join(vdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ASM_OWNED[src])
+        objs.append(obj)
+    out = os.path.join(LIBDIR, f'libarcflow_hip_{name}.so')
+    r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout}')
+    return out
+
+
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv))
+    if '--variant' in sys.argv:         # python -m arcflow_amd.build --variant trace -DAFX_ATTN_TRACE -- afx_attn3.hip
+        i = sys.argv.index('--variant')
+        j = sys.argv.index('--')
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:j], sys.argv[j + 1:]))
+    else:
+        print(build(force='--force' in sys.argv))

@@ -152,7 +152,12 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
 #ifdef AFX_ATTN_TRACE
   unsigned tr[16];
   const unsigned tr_c0 = (unsigned)__builtin_readcyclecounter(), tr_r0 = (unsigned)__builtin_amdgcn_s_memrealtime();
-#define A3_TR(i) if (t == 36) tr[i] = (unsigned)__builtin_readcyclecounter();
+#define A3_TR(i)                                                                        \
+  if (t == 36) {                                                                        \
+    uint64_t st_;                                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_)::"memory");        \
+    tr[i] = (unsigned)st_;                                                              \
+  }
 #else
 #define A3_TR(i)
 #endif
@@ -238,8 +243,10 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
     t4[0] = (unsigned)__builtin_readcyclecounter() - tr_c0;
     t4[1] = (unsigned)__builtin_amdgcn_s_memrealtime() - tr_r0;
     t4[2] = (unsigned)ntiles;
-    t4[3] = tr[1] - tr[0];
-    t4[4] = tr[2] - tr[1];
+    t4[3] = tr[4] - tr[3];      // wait for the DMA of two iterations ago + own LDS reads
+    t4[4] = tr[0] - tr[4];      // barrier
+    t4[5] = tr[1] - tr[0];      // phase A
+    t4[6] = tr[2] - tr[1];      // phase B
   }
 #endif
 }

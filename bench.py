@@ -375,7 +375,7 @@ def main(argv=None):
             if att_n:
                 a2 = att_fl / (att_ms * 1e-3) / 1e12
                 line['roofline_attention'] = {
-                    'bound': 'mfma', 'kernel': 'afx::attention_kernel<128, false>', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
+                    'bound': 'mfma', 'kernel': 'afx::a3::attention_v3_kernel', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
                     'unit': 'TFLOP/s', 'frac': a2 / MFMA_BF16_PEAK_TF, 'launches': att_n,
                     'avg_launch_us': att_ms * 1e3 / att_n, 'share_of_step_time': att_ms * 1e-3 / dt}
         if not args.no_cpu_baseline and world == 1:

@@ -104,34 +104,130 @@ def test_linear_gate_residual_inplace(ops, gemm_mode):
 
 
 # ------------------------------------------------------------------------------------------ attention
-@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2), (1, 129, 1)])
-def test_attention(ops, B, S, H):
+# afx_attn_set_impl: 0 = the one-wave-per-SIMD kernel (afx_attn3.hip; S % 64 == 0, otherwise the launcher falls back to the 4-wave
+# kernel), 1 = the 4-wave kernel always.  Both must match fp32 softmax on the same bf16 inputs.
+@pytest.fixture(params=[0, 1], ids=['v3-wave64q', '4wave'])
+def attn_impl(request, ops):
+    ops.set_attn_impl(request.param)
+    yield request.param
+    ops.set_attn_impl(0)
+
+
+def _sdpa_ref(q, k, v):
+    B, S, H, _ = q.shape
+    return torch.nn.functional.scaled_dot_product_attention(
+        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2).reshape(B, S, H * 128)
+
+
+@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2), (1, 129, 1), (1, 128, 1), (1, 192, 2), (2, 320, 3),
+                                   (1, 576, 9), (1, 2048, 4)])
+def test_attention(ops, attn_impl, B, S, H):
+    """S = 128 (two KV tiles: prologue + last-tile code only), 192 (one loop iteration), 320 / 576 (partly filled 256-query blocks,
+    2-4 loop iterations: every ring slot), H = 9 (heads -> XCD map with an incomplete last group), ragged S (4-wave kernel)."""
     g = torch.Generator().manual_seed(S)
     q = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
     k = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
     v = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
     out = ops.attention(q, k, v)
-    ref = torch.nn.functional.scaled_dot_product_attention(
-        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2).reshape(B, S, H * 128)
+    ref = _sdpa_ref(q, k, v)
     assert rel_l2(out, ref) < 1.2e-2           # P is rounded to bf16 before P.V, output bf16
     assert torch.isfinite(out.float()).all()
 
 
-def test_attention_spiked_rows(ops):
-    """One key dominating a query row late in the sequence forces a large online-softmax rescale."""
+@pytest.mark.parametrize('S', [320, 1024])
+def test_attention_spiked_rows(ops, attn_impl, S):
+    """One key dominating a query row late in the sequence forces the online-softmax rescale (the cold path of the one-wave-per-SIMD
+    kernel: accumulator-file reads / writes with hand-placed wait states) in both slabs of a wave and at an early and a late tile."""
     g = torch.Generator().manual_seed(3)
-    B, S, H = 1, 320, 1
+    B, H = 1, 2
     q = torch.randn(B, S, H, 128, generator=g)
     k = torch.randn(B, S, H, 128, generator=g)
     v = torch.randn(B, S, H, 128, generator=g)
-    k[0, 300, 0] = q[0, 7, 0] * 3.0
-    k[0, 10, 0] = q[0, 100, 0] * 3.0
+    k[0, S - 20, 0] = q[0, 7, 0] * 3.0            # slab A of wave 0, last tile
+    k[0, 10, 0] = q[0, 100, 0] * 3.0              # slab B of wave 1, first tile
+    k[0, 200, 1] = q[0, 40, 1] * 4.0              # slab B of wave 0, a middle tile
+    k[0, 130, 1] = q[0, S - 1, 1] * 4.0
     q, k, v = (bf(t).to(dev()) for t in (q, k, v))
     out = ops.attention(q, k, v)
-    ref = torch.nn.functional.scaled_dot_product_attention(
-        q.float().transpose(1, 2), k.float().transpose(1, 2), v.float().transpose(1, 2)).transpose(1, 2).reshape(B, S, 128)
+    ref = _sdpa_ref(q, k, v)
     assert (out.float() - ref).abs().max().item() < 0.06
     assert rel_l2(out, ref) < 1.2e-2
+
+
+def test_attention_growing_scores_every_tile(ops, attn_impl):
+    """Keys whose scores grow along the sequence: the running max of EVERY row outgrows the deferral threshold (2^5) again and again,
+    so the rescale branch runs many times per work-group and must leave l, O and the later P on one scale."""
+    g = torch.Generator().manual_seed(11)
+    B, S, H = 1, 1024, 1
+    q = torch.randn(B, S, H, 128, generator=g)
+    base = torch.randn(128, generator=g)
+    base = base / base.norm()
+    q = q + 6.0 * base                                            # every query has a large component along `base`
+    k = torch.randn(B, S, H, 128, generator=g) + (torch.arange(S).float() / S * 60.0).view(1, S, 1, 1) * base
+    v = torch.randn(B, S, H, 128, generator=g)
+    q, k, v = (bf(t).to(dev()) for t in (q, k, v))
+    out = ops.attention(q, k, v)
+    ref = _sdpa_ref(q, k, v)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) < 1.2e-2
+
+
+def test_attention_kernels_bit_identical(ops):
+    """Same mathematics, same operation order per query: the two kernels agree bit for bit (S % 64 == 0)."""
+    g = torch.Generator().manual_seed(5)
+    q, k, v = (bf(torch.randn(1, 768, 3, 128, generator=g)).to(dev()) for _ in range(3))
+    ops.set_attn_impl(1)
+    a = ops.attention(q, k, v)
+    ops.set_attn_impl(0)
+    b = ops.attention(q, k, v)
+    assert (a.float() - b.float()).abs().max().item() < 4e-3      # row sums are accumulated in a different order (two partial sums)
+
+
+def test_attention_lse_matches_between_kernels(ops):
+    g = torch.Generator().manual_seed(6)
+    q, k, v = (bf(torch.randn(1, 384, 2, 128, generator=g)).to(dev()) for _ in range(3))
+    ops.set_attn_impl(1)
+    o1, l1 = ops.attention_fwd_lse(q, k, v)
+    ops.set_attn_impl(0)
+    o0, l0 = ops.attention_fwd_lse(q, k, v)
+    assert (l0 - l1).abs().max().item() < 2e-3
+    s = torch.einsum('bqhd,bkhd->bhqk', q.float(), k.float()) * (128 ** -0.5) * 1.4426950408889634
+    ref = torch.logsumexp(s * 0.6931471805599453, dim=-1) * 1.4426950408889634          # log2-domain log-sum-exp
+    assert (l0 - ref).abs().max().item() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------ races / determinism (tools/race_probe*.py)
+def _count_nonidentical(fn, reps, junk):
+    ref = fn().clone()
+    bad = 0
+    for i in range(reps):
+        if i % 3 == 0:
+            junk.normal_()                     # 256 MB of writes: evicts L2 / Infinity Cache, shifts the timing of the next launch
+        bad += int(not torch.equal(fn(), ref))
+    return bad
+
+
+@pytest.mark.parametrize('S', [4608, 4173])
+def test_attention_race_probe(ops, S):
+    """100+ launches on fixed inputs with cache-disturbing work in between: every output bit-identical.  This is the probe that found
+    the compiler-dropped DMA wait of round 2; S = 4608 runs the one-wave-per-SIMD kernel (hand-counted vmcnt / lgkmcnt
+    waits, LDS rings), S = 4173 the 4-wave kernel's ragged path."""
+    g = torch.Generator(device='cuda').manual_seed(0)
+    q, k, v = (torch.randn(1, S, 24, 128, generator=g, device='cuda').bfloat16() for _ in range(3))
+    junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    ops.set_attn_impl(0)
+    assert _count_nonidentical(lambda: ops.attention(q, k, v), 120, junk) == 0
+
+
+@pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 9216, 3072), (4608, 3072, 15360), (512, 9216, 3072)])
+def test_gemm_race_probe(ops, M, N, K):
+    g = torch.Generator(device='cuda').manual_seed(0)
+    a = torch.randn(M, K, generator=g, device='cuda').bfloat16()
+    w = (torch.randn(N, K, generator=g, device='cuda') * 0.02).bfloat16()
+    b = torch.randn(N, generator=g, device='cuda').bfloat16()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+    junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    assert _count_nonidentical(lambda: ops.linear(a, w, b, out=out), 100, junk) == 0
 
 
 # ------------------------------------------------------------------------------------------ norms / rope / gemv

@@ -37,3 +37,18 @@ if hasattr(lib, 'afx_debug_attn_trace4'):
                 cyc, ticks, tiles, _ = (b4[(blk * 4 + w) * 4 + i] for i in range(4))
                 print(f'4-wave kernel block {"0" if blk == 0 else "700"} w{w}: {cyc} cycles for {tiles} KV tiles = {cyc / max(tiles, 1):.0f} / tile'
                       f' (MFMA floor 1024), {ticks} ticks of 10 ns -> shader clock {100.0 * cyc / max(ticks, 1):.0f} MHz')
+
+# ---- one-wave-per-SIMD kernel (afx_attn3.hip): iteration 36 of two work-groups
+if hasattr(lib, 'afx_debug_attn3_trace'):
+    ops.set_attn_impl(0)
+    for _ in range(200):
+        ops.attention(q, k, v)
+    torch.cuda.synchronize()
+    b3 = (C.c_uint * 128)()
+    if lib.afx_debug_attn3_trace(b3) == 0:
+        for blk in range(2):
+            for w in range(4):
+                x = [b3[(blk * 4 + w) * 16 + i] for i in range(8)]
+                cyc, ticks, tiles = x[0], x[1], x[2]
+                print(f'v3 kernel block {"0" if blk == 0 else "300"} w{w}: {cyc} cycles for {tiles} KV tiles = {cyc / max(tiles, 1):.0f} / tile (MFMA floor 2048),'
+                      f' clock {100.0 * cyc / max(ticks, 1):.0f} MHz | iteration 36: wait {x[3]} barrier {x[4]} phase A {x[5]} phase B {x[6]}')

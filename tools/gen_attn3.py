@@ -216,7 +216,10 @@ def tile0():
 
 def body(J):
     out = [f'// generated by tools/gen_attn3.py -- iteration t, ring slot J = t & 3 = {J}']
-    out.append(wait('s_waitcnt vmcnt(8) lgkmcnt(0)\\n\\ts_barrier', own=True))
+    out.append('A3_TR(3)')
+    out.append(wait('s_waitcnt vmcnt(8) lgkmcnt(0)', own=True))
+    out.append('A3_TR(4)')
+    out.append(wait('s_barrier'))
     out.append('A3_TR(0)')
     out.append('{ const uint64_t ksrc = k_src(t + 4), vsrc = v_src(t + 2);')
     # phase A: S_A(t+1), O_A += V(t) P_A(t) | softmax of S_B(t) | V(t) fragments, DMA K(t+4) -> slot J
