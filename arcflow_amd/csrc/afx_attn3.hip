@@ -60,8 +60,15 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
-#include "gen/a3_rescale.inc"
-#include "gen/a3_readout.inc"
+// the generated pieces: gen/ by default; -DA3_GEN=<dir> selects another output of tools/gen_attn3.py (timing ablations)
+#ifndef A3_GEN
+#define A3_GEN gen
+#endif
+#define A3_XSTR(x) #x
+#define A3_STR(x) A3_XSTR(x)
+#define A3_INC(name) A3_STR(A3_GEN/name)
+#include A3_INC(a3_rescale.inc)
+#include A3_INC(a3_readout.inc)
 
 // One tile = iteration t with ring slot J = t & 3 (gen/a3_body{J}.inc):
 //   phase A   MFMA: S_A^T(t+1) (16), O_A^T += V^T(t) P_A^T(t) (16)   VALU: softmax of S_B(t)     LDS: V^T(t) fragments | DMA K(t+4)
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
   auto k_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(kbase + tt * ktile_bytes)); };
   auto v_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(vbase + (int64_t)tt * (KVB * 2))); };
 
-#include "gen/a3_init.inc"
+#include A3_INC(a3_init.inc)
   float mA = -INFINITY, lA0 = 0.f, lA1 = 0.f, mB = -INFINITY, lB0 = 0.f, lB1 = 0.f;
   float rs_tmp;
   (void)rs_tmp;
@@ -144,9 +151,9 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
     const int r0 = min(q0 + ql, S - 1), r1 = min(q0 + 32 + ql, S - 1);
     const bf16_t* qptr0 = q + ((int64_t)b * S + r0) * ldq + h * 128 + hi * 8;
     const bf16_t* qptr1 = q + ((int64_t)b * S + r1) * ldq + h * 128 + hi * 8;
-#include "gen/a3_qload.inc"
+#include A3_INC(a3_qload.inc)
   }
-#include "gen/a3_prologue_dma.inc"
+#include A3_INC(a3_prologue_dma.inc)
   A3_DBG(2)
 
 #ifdef AFX_ATTN_TRACE
@@ -163,7 +170,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
 #endif
 
   // tile 0, not pipelined: K(0) fragments, S^T(0) of both slabs, slab A's softmax, K(1) fragments
-#include "gen/a3_tile0.inc"
+#include A3_INC(a3_tile0.inc)
   A3_DBG(3)
 
   int t = 0;
@@ -171,20 +178,20 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
 #pragma unroll 1
     for (;;) {
       {
-#include "gen/a3_body0.inc"
+#include A3_INC(a3_body0.inc)
       }
       A3_DBG(4)
       if (++t == ntiles - 1) break;
       {
-#include "gen/a3_body1.inc"
+#include A3_INC(a3_body1.inc)
       }
       if (++t == ntiles - 1) break;
       {
-#include "gen/a3_body2.inc"
+#include A3_INC(a3_body2.inc)
       }
       if (++t == ntiles - 1) break;
       {
-#include "gen/a3_body3.inc"
+#include A3_INC(a3_body3.inc)
       }
       if (++t == ntiles - 1) break;
     }
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
   // ---- last tile t = ntiles - 1: V^T(t) fragments | softmax of S_B(t) | O_A^T += ..., O_B^T += ... ---------------------------
   {
     const uint32_t vs = (uint32_t)(t & 3) * TILE_BYTES;
-#include "gen/a3_final.inc"
+#include A3_INC(a3_final.inc)
   }
   A3_DBG(6)
   // every DMA piece must have landed before this work-group's LDS can be handed to another one; MFMA -> accumulator-read wait states

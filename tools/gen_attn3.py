@@ -34,7 +34,12 @@ It writes arcflow_amd/csrc/gen/a3_*.inc (committed; the build does not run this 
     a3_readout.inc   accumulator file -> VGPR scalars, one 32-row tile of O^T at a time (macros for the epilogue)
 Usage: python tools/gen_attn3.py
 """
+import argparse
 import os
+
+# ablation switches (timing experiments only -- results are wrong): see main()
+ABL = set()
+MERGE = False       # --merge: all VALU instructions of an MFMA gap in one asm statement
 
 TILE = 16384
 V_BASE = 4 * TILE
@@ -121,38 +126,90 @@ def dma(kind, slot, piece):
 
 
 # ---- the softmax of one slab and one tile as an instruction list --------------------------------------------------------------
+class Op:
+    """one VALU instruction: text with {0}, {1}, ... for its operands = [(variable, 'w' | 'r' | 'rw', 'v' | 's')], or raw C++"""
+
+    def __init__(self, text, operands=(), raw=None):
+        self.text, self.operands, self.raw = text, list(operands), raw
+
+
+def emit(ops):
+    """C++ for a run of Ops.  Consecutive instructions go into ONE asm statement: hipcc pads every boundary between two asm
+    statements whose registers overlap with an s_nop (its hazard recogniser cannot look inside), ~45 issue slots per tile."""
+    out, group = [], []
+
+    def flush():
+        if not group:
+            return
+        names, mode, cls = [], {}, {}
+        for op in group:
+            for v, m, c in op.operands:
+                if v not in mode:
+                    names.append(v)
+                    cls[v] = c
+                    mode[v] = {'w': 'ew', 'r': 'r', 'rw': 'rw'}[m]            # ew: written before any read -> early clobber
+                elif m != 'r' and mode[v] == 'r':
+                    mode[v] = 'rw'
+        outs = [v for v in names if mode[v] != 'r']
+        ins = [v for v in names if mode[v] == 'r']
+        idx = {v: i for i, v in enumerate(outs + ins)}
+        lines = [op.text.format(*[f'%{idx[v]}' for v, _, _ in op.operands]) for op in group]
+        o = ', '.join(f'"{"=&" if mode[v] == "ew" else "+"}{cls[v]}"({v})' for v in outs)
+        i = ', '.join(f'"{cls[v]}"({v})' for v in ins)
+        out.append(asm('\\n\\t'.join(lines), o, i))
+        group.clear()
+
+    for op in ops:
+        if op.raw is not None:
+            flush()
+            out.append(op.raw)
+        else:
+            group.append(op)
+            if not MERGE:
+                flush()
+    flush()
+    return out
+
+
 def softmax_ops(sl):
-    """C++ statements, one instruction each (the decision is plain C++ with a cold branch).  State: m / l0 / l1 of the slab."""
+    """The stream as Ops, one instruction each (the decision is plain C++ with a cold branch).  State: m / l0 / l1 of the slab."""
     X = 'AB'[sl]
     t0, t1, mb, nmc = f't{X}0', f't{X}1', f'mb{X}', f'nmc{X}'
     ops = []
-    ops.append(asm(f'v_max3_f32 %0, {Sx(sl, 0)}, {Sx(sl, 1)}, {Sx(sl, 2)}', f'"=v"({t0})'))
-    ops.append(asm(f'v_max3_f32 %0, {Sx(sl, 16)}, {Sx(sl, 17)}, {Sx(sl, 18)}', f'"=v"({t1})'))
+    ops.append(Op(f'v_max3_f32 {{0}}, {Sx(sl, 0)}, {Sx(sl, 1)}, {Sx(sl, 2)}', [(t0, 'w', 'v')]))
+    ops.append(Op(f'v_max3_f32 {{0}}, {Sx(sl, 16)}, {Sx(sl, 17)}, {Sx(sl, 18)}', [(t1, 'w', 'v')]))
     for j in range(6):
-        ops.append(asm(f'v_max3_f32 %0, %0, {Sx(sl, 3 + 2 * j)}, {Sx(sl, 4 + 2 * j)}', f'"+v"({t0})'))
-        ops.append(asm(f'v_max3_f32 %0, %0, {Sx(sl, 19 + 2 * j)}, {Sx(sl, 20 + 2 * j)}', f'"+v"({t1})'))
-    ops.append(asm(f'v_max_f32 %0, %0, {Sx(sl, 15)}', f'"+v"({t0})'))
-    ops.append(asm(f'v_max_f32 %0, %0, {Sx(sl, 31)}', f'"+v"({t1})'))
-    ops.append(asm('v_max_f32 %0, %0, %1', f'"+v"({t0})', f'"v"({t1})'))
-    ops.append(asm('v_mov_b32 %0, %1', f'"=v"({mb})', f'"v"({t0})'))
+        ops.append(Op(f'v_max3_f32 {{0}}, {{0}}, {Sx(sl, 3 + 2 * j)}, {Sx(sl, 4 + 2 * j)}', [(t0, 'rw', 'v')]))
+        ops.append(Op(f'v_max3_f32 {{0}}, {{0}}, {Sx(sl, 19 + 2 * j)}, {Sx(sl, 20 + 2 * j)}', [(t1, 'rw', 'v')]))
+    ops.append(Op(f'v_max_f32 {{0}}, {{0}}, {Sx(sl, 15)}', [(t0, 'rw', 'v')]))
+    ops.append(Op(f'v_max_f32 {{0}}, {{0}}, {Sx(sl, 31)}', [(t1, 'rw', 'v')]))
+    ops.append(Op('v_max_f32 {0}, {0}, {1}', [(t0, 'rw', 'v'), (t1, 'r', 'v')]))
+    ops.append(Op('v_mov_b32 {0}, {1}', [(mb, 'w', 'v'), (t0, 'r', 'v')]))
     # t0.hi <-> mb.lo: t0 = [lo, lo], mb = [hi, hi]   (VALU write -> permlane read: 2 wait states)
-    ops.append(asm('s_nop 1\\n\\tv_permlane32_swap_b32 %0, %1', f'"+v"({t0}), "+v"({mb})'))
-    ops.append(asm('v_max_f32 %0, %0, %1', f'"+v"({t0})', f'"v"({mb})'))
-    ops.append(f'{{ const float m_new = fmaxf(m{X}, {t0}); '
-               f'if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new - m{X} > thr) != 0, 0)) {{ A3_RESCALE_{X}(m_new) }} }}')
-    ops.append(asm('v_mul_f32 %0, %1, %2', f'"=v"({nmc})', f'"s"(neg_c), "v"(m{X})'))
+    ops.append(Op('s_nop 1\\n\\tv_permlane32_swap_b32 {0}, {1}', [(t0, 'rw', 'v'), (mb, 'rw', 'v')]))
+    ops.append(Op('v_max_f32 {0}, {0}, {1}', [(t0, 'rw', 'v'), (mb, 'r', 'v')]))
+    ops.append(Op('', raw=f'{{ const float m_new = fmaxf(m{X}, {t0}); '
+                          f'if (__builtin_expect(__builtin_amdgcn_ballot_w64(m_new - m{X} > thr) != 0, 0)) {{ A3_RESCALE_{X}(m_new) }} }}'))
+    ops.append(Op('v_mul_f32 {0}, {1}, {2}', [(nmc, 'w', 'v'), ('neg_c', 'r', 's'), (f'm{X}', 'r', 'v')]))
     for k in range(32 + 5):
         if k < 32:
-            ops.append(asm(f'v_fma_f32 %0, {Sx(sl, k)}, %1, %2', f'"=v"(e{X}{k})', f'"s"(c), "v"({nmc})'))
+            ops.append(Op(f'v_fma_f32 {{0}}, {Sx(sl, k)}, {{1}}, {{2}}', [(f'e{X}{k}', 'w', 'v'), ('c', 'r', 's'), (nmc, 'r', 'v')]))
         if 0 <= k - 2 < 32:
             i = k - 2
-            ops.append(asm('v_exp_f32 %0, %1', f'"=v"(p{X}{i})', f'"v"(e{X}{i})'))
+            ops.append(Op('v_exp_f32 {0}, {1}', [(f'p{X}{i}', 'w', 'v'), (f'e{X}{i}', 'r', 'v')]))
         if 0 <= k - 4 < 32:
             i = k - 4
-            ops.append(asm('v_add_f32 %0, %0, %1', f'"+v"(l{X}{i & 1})', f'"v"(p{X}{i})'))
+            ops.append(Op('v_add_f32 {0}, {0}, {1}', [(f'l{X}{i & 1}', 'rw', 'v'), (f'p{X}{i}', 'r', 'v')]))
             if i & 1:
-                ops.append(asm(f'v_cvt_pk_bf16_f32 {W(sl, i >> 1)}, %0, %1', '', f'"v"(p{X}{i - 1}), "v"(p{X}{i})'))
+                ops.append(Op(f'v_cvt_pk_bf16_f32 {W(sl, i >> 1)}, {{0}}, {{1}}', [(f'p{X}{i - 1}', 'r', 'v'), (f'p{X}{i}', 'r', 'v')]))
     assert len(ops) == 134
+    if 'noadd' in ABL:
+        ops = [o for o in ops if 'v_add_f32' not in o.text]
+    if 'noexp' in ABL:
+        for o in ops:
+            o.text = o.text.replace('v_exp_f32', 'v_mov_b32')
+    if 'novalu' in ABL:
+        ops = [o for o in ops if o.raw is not None or any(x in o.text for x in ('v_max', 'permlane', 'v_mov', 'v_mul'))]
     return ops
 
 
@@ -210,7 +267,7 @@ def tile0():
     out += [qk(1, m) for m in range(16)]
     out.append(wait('s_waitcnt vmcnt(16)\\n\\ts_barrier'))          # K(1) landed everywhere; all reads of slot 0 retired (lgkmcnt(0) above)
     out += [read_k(i, 1) for i in range(16)]
-    out += softmax_ops(0)
+    out += emit(softmax_ops(0))
     return out
 
 
@@ -230,16 +287,17 @@ def body(J):
     for m in range(32):
         if m < 16:
             out.append(qk(0, m))
-            out.append(read_v(m, J))
+            if 'nolds' not in ABL:
+                out.append(read_v(m, J))
         else:
             if m in (16, 20, 24, 28):
                 out.append(wait(f's_waitcnt lgkmcnt({12 - (m - 16)})'))
             out.append(pv(0, m - 16))
-            if m % 4 == 2:
+            if m % 4 == 2 and 'nodma' not in ABL:
                 out.append(dma('k', J, (m - 16) // 4))
-        out += sm[k:k + cnt[m]]
+        out += emit(sm[k:k + cnt[m]])
         k += cnt[m]
-    assert k >= len(sm)
+    assert k >= len(sm) or ABL
     out.append('A3_TR(1)')
     # phase B: S_B(t+1), O_B += V(t) P_B(t) | softmax of S_A(t+1) | DMA V(t+2) -> slot J+2, K(t+2) fragments from slot J+2
     sm = softmax_ops(0)
@@ -249,14 +307,15 @@ def body(J):
     for m in range(32):
         if m < 16:
             out.append(qk(1, m))
-            if m % 4 == 2:
+            if m % 4 == 2 and 'nodma' not in ABL:
                 out.append(dma('v', (J + 2) & 3, m // 4))
         else:
             out.append(pv(1, m - 16))
-            out.append(read_k(m - 16, (J + 2) & 3))
-        out += sm[k:k + cnt[m]]
+            if 'nolds' not in ABL:
+                out.append(read_k(m - 16, (J + 2) & 3))
+        out += emit(sm[k:k + cnt[m]])
         k += cnt[m]
-    assert k >= len(sm)
+    assert k >= len(sm) or ABL
     out.append('}')
     out.append('A3_TR(2)')
     return out
@@ -266,7 +325,7 @@ def final():
     out = ['// generated by tools/gen_attn3.py -- last tile t = ntiles - 1 (runtime ring slot: vs = (t & 3) * 16384)']
     out.append(wait('s_waitcnt vmcnt(8) lgkmcnt(0)\\n\\ts_barrier', own=True))
     out += [read_v(i, 0, 'vs') for i in range(16)]
-    out += softmax_ops(1)
+    out += emit(softmax_ops(1))
     out.append(wait('s_waitcnt lgkmcnt(0)\\n\\ts_nop 3'))
     out += [pv(0, m) for m in range(16)]
     out += [pv(1, m) for m in range(16)]
@@ -298,7 +357,15 @@ def readout():
 
 
 def main():
-    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'arcflow_amd', 'csrc', 'gen')
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn3.hip includes A3_GEN/..., default gen)')
+    ap.add_argument('--merge', action='store_true', help='one asm statement per MFMA gap for the VALU instructions')
+    ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, noadd, noexp, novalu: timing experiments, WRONG results')
+    a = ap.parse_args()
+    ABL.update(x for x in a.ablate.split(',') if x)
+    global MERGE
+    MERGE = a.merge
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'arcflow_amd', 'csrc', a.out)
     os.makedirs(root, exist_ok=True)
     files = {'a3_init.inc': decl(), 'a3_qload.inc': q_loads(), 'a3_tile0.inc': tile0(), 'a3_final.inc': final(),
              'a3_rescale.inc': rescale(0) + rescale(1), 'a3_readout.inc': readout(), 'a3_prologue_dma.inc': prologue_dma()}

@@ -1,7 +1,8 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for i in 1 2; do
-for impl in 1 0; do
-AFX_ATTN_IMPL=$impl timeout 300 python bench.py --steps 12 --warmup 3 2>/dev/null | python tools/bench_brief.py "attn_impl=$impl" >> gpurun_out/ab_attn.log 2>&1
-done; done
-cat gpurun_out/ab_attn.log
+: > gpurun_out/attn3_ablate.log
+for v in trace t_merge t_nodma t_mergenodma t_nolds t_noadd t_noexp t_novalu trace; do
+echo "== $v" >> gpurun_out/attn3_ablate.log
+ARCFLOW_HIP_LIB=$PWD/arcflow_amd/lib/libarcflow_hip_$v.so timeout 120 python tools/attn3_trace.py 2>&1 | grep "block 0 w0\|block 300 w0" >> gpurun_out/attn3_ablate.log
+done
+cat gpurun_out/attn3_ablate.log
