@@ -129,3 +129,106 @@ def write_flux_adapter(root, subfolder, snap, rank=16, seed=5):
     acfg.update({'_class_name': 'ArcFluxTransformer2DModel', 'num_gaussians': 16, 'logweights_channels': 4})
     json.dump(acfg, open(os.path.join(d, 'config.json'), 'w'))
     return ad, lora
+
+
+# ---------------------------------------------------------------------------------------------------------------- Qwen-Image
+def _qwen_tokenizer(folder, max_len=2048):
+    """A word-level fast tokenizer that knows the chat-template markers of the Qwen-Image prompt template (right padding)."""
+    from tokenizers import Tokenizer, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    words = ('system user assistant Describe the image by detailing color shape size texture quantity text spatial relationships of '
+             'objects and background a semi realistic fantasy illustration featuring split composition two young men in profile facing '
+             'away from each other on left pale man with sharp features black hair wears dark coat right tan blue tunic red teal '
+             'painterly brushstrokes cat dog').split()
+    vocab = {'<|endoftext|>': 0, '<unk>': 1, '<|im_start|>': 2, '<|im_end|>': 3, ',': 4, ':': 5, '.': 6}
+    for w in words:
+        vocab.setdefault(w, len(vocab))
+    tok = Tokenizer(models.WordLevel(vocab, unk_token='<unk>'))
+    tok.pre_tokenizer = pre_tokenizers.Sequence([pre_tokenizers.Split('<|im_start|>', 'isolated'), pre_tokenizers.Split('<|im_end|>', 'isolated'),
+                                                 pre_tokenizers.Whitespace()])
+    fast = PreTrainedTokenizerFast(tokenizer_object=tok, pad_token='<|endoftext|>', unk_token='<unk>', model_max_length=max_len,
+                                   padding_side='right')
+    fast.save_pretrained(folder)
+    return len(vocab)
+
+
+def write_qwen_snapshot(root, num_layers=2, heads=2, joint_dim=128, vae_dim=32, with_text=True, with_vae=True, seed=0):
+    """Synthetic Qwen/Qwen-Image snapshot in the layout inference_qwen.py:5-8 loads: transformer/ (QwenImageTransformer2DModel:
+    sharded safetensors + index + config.json), vae/ (AutoencoderKLQwenImage), text_encoder/ (Qwen2_5_VLForConditionalGeneration),
+    tokenizer/, scheduler/.  -> dict of what was written."""
+    from oracle import dit_ref as D
+    from oracle import vae_qwen_ref as V
+    cfg = D.QwenCfg(num_layers=num_layers, heads=heads, joint_dim=joint_dim)
+    w = D.make_qwen_weights(cfg, seed=seed)
+    g = torch.Generator().manual_seed(seed + 11)
+    teacher = {k: v for k, v in w.items() if not k.startswith('proj_out_')}
+    teacher['proj_out.weight'] = (torch.randn(cfg.in_channels, cfg.dim, generator=g) * 0.02).bfloat16()       # the base model's velocity head
+    teacher['proj_out.bias'] = (torch.randn(cfg.in_channels, generator=g) * 0.02).bfloat16()
+    tdir = os.path.join(root, 'transformer')
+    _save_sharded(teacher, tdir, nshards=3)
+    tcfg = {'_class_name': 'QwenImageTransformer2DModel', '_diffusers_version': '0.35.1', 'attention_head_dim': 128,
+            'axes_dims_rope': [16, 56, 56], 'guidance_embeds': False, 'in_channels': 64, 'joint_attention_dim': joint_dim,
+            'num_attention_heads': heads, 'num_layers': num_layers, 'out_channels': 16, 'patch_size': 2}
+    json.dump(tcfg, open(os.path.join(tdir, 'config.json'), 'w'))
+    os.makedirs(os.path.join(root, 'scheduler'), exist_ok=True)
+    json.dump({'_class_name': 'FlowMatchEulerDiscreteScheduler', '_diffusers_version': '0.35.1', 'base_image_seq_len': 256,
+               'base_shift': 0.5, 'max_image_seq_len': 8192, 'max_shift': 0.9, 'num_train_timesteps': 1000, 'shift': 1.0,
+               'shift_terminal': 0.02, 'use_dynamic_shifting': True}, open(os.path.join(root, 'scheduler', 'scheduler_config.json'), 'w'))
+    out = dict(cfg=cfg, transformer_cfg=tcfg, transformer_sd=dict(w, **{k: teacher[k] for k in ('proj_out.weight', 'proj_out.bias')}))
+    if with_vae:
+        from safetensors.torch import save_file
+        vw = V.make_decoder_weights(dim=vae_dim, seed=seed + 1)
+        mean = (torch.randn(16, generator=g) * 0.3).tolist()
+        std = (1.0 + 0.5 * torch.rand(16, generator=g)).tolist()
+        os.makedirs(os.path.join(root, 'vae'), exist_ok=True)
+        save_file({k: v.contiguous() for k, v in vw.items()}, os.path.join(root, 'vae', 'diffusion_pytorch_model.safetensors'))
+        json.dump({'_class_name': 'AutoencoderKLQwenImage', 'base_dim': vae_dim, 'dim_mult': [1, 2, 4, 4], 'num_res_blocks': 2, 'z_dim': 16,
+                   'latents_mean': mean, 'latents_std': std, 'temperal_downsample': [False, True, True]},
+                  open(os.path.join(root, 'vae', 'config.json'), 'w'))
+        out.update(vae_sd=vw, latents_mean=mean, latents_std=std)
+    if with_text:
+        from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
+        torch.manual_seed(seed + 2)
+        nv = _qwen_tokenizer(os.path.join(root, 'tokenizer'))
+        text = dict(vocab_size=nv, hidden_size=joint_dim, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+                    max_position_embeddings=2048, rope_theta=1e6, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                    rope_scaling=dict(type='mrope', mrope_section=[16, 24, 24]))
+        vis = dict(depth=1, hidden_size=64, intermediate_size=128, num_heads=2, out_hidden_size=joint_dim)
+        try:
+            mcfg = Qwen2_5_VLConfig(text_config=text, vision_config=vis)
+        except TypeError:
+            mcfg = Qwen2_5_VLConfig(vision_config=vis, **text)
+        lm = Qwen2_5_VLForConditionalGeneration(mcfg).eval()
+        for p in lm.parameters():
+            p.data = p.data.bfloat16().float()
+        lm.save_pretrained(os.path.join(root, 'text_encoder'), safe_serialization=True)
+        out.update(lm=lm)
+    return out
+
+
+def write_qwen_adapter(root, subfolder, snap, rank=16, seed=5):
+    """ArcFlow-Qwen adapter directory (export_arcflow_to_diffusers.py:100-127; LoRA targets of configs/qwen/arcqwen_2nfe_k16.py:47-58:
+    img_mlp of every block, txt_mlp of every block but the last, the timestep-embedder pair).  -> (adapter state dict, LoRA dict)"""
+    from safetensors.torch import save_file
+    w, cfg = snap['transformer_sd'], snap['cfg']
+    g = torch.Generator().manual_seed(seed)
+    ad = {k: v.clone() for k, v in w.items() if k.startswith(('proj_out_', 'norm_out.'))}
+    ad['norm_out.linear.weight'] = (ad['norm_out.linear.weight'].float() + 0.01 * torch.randn(ad['norm_out.linear.weight'].shape, generator=g)).bfloat16()
+    targets = [f'transformer_blocks.{i}.img_mlp.{n}' for i in range(cfg.num_layers) for n in ('net.0.proj', 'net.2')]
+    targets += [f'transformer_blocks.{i}.txt_mlp.{n}' for i in range(cfg.num_layers - 1) for n in ('net.0.proj', 'net.2')]
+    targets += ['time_text_embed.timestep_embedder.linear_1', 'time_text_embed.timestep_embedder.linear_2']
+    lora = {}
+    for t in targets:
+        o, i = w[t + '.weight'].shape
+        lora[t + '.lora_A.weight'] = (torch.randn(rank, i, generator=g) / rank).bfloat16()
+        lora[t + '.lora_B.weight'] = (torch.randn(o, rank, generator=g) * 0.02).bfloat16()
+    d = os.path.join(root, subfolder)
+    os.makedirs(d, exist_ok=True)
+    full = dict(ad)
+    full.update(lora)
+    save_file({k: v.contiguous() for k, v in full.items()}, os.path.join(d, 'diffusion_pytorch_model.safetensors'),
+              metadata={'policy_config': json.dumps({'type': 'ArcFlow'})})
+    acfg = dict(snap['transformer_cfg'])
+    acfg.update({'_class_name': 'ArcQwenImageTransformer2DModel', 'num_gaussians': 16, 'logweights_channels': 4})
+    json.dump(acfg, open(os.path.join(d, 'config.json'), 'w'))
+    return ad, lora

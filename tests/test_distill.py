@@ -469,6 +469,80 @@ def test_qwen_distill_step_with_true_cfg_teacher():
 
 
 @pytest.mark.gpu
+def test_qwen_fp8_teacher_true_cfg_step_is_baseline_configs4():
+    """BASELINE.json configs[4] in its stated combination: Qwen-Image family x true-CFG teacher (negative prompt, scale 4.0:
+    configs/qwen/arcqwen_2nfe_k16.py:100) x ``teacher_fp8`` (both teacher forwards of every state on the e4m3 MFMA; student forward,
+    gradients and optimizer bf16 / fp32).  Stated tolerance: against the bf16-teacher step on the same draws the loss moves by < 6 %
+    and the flat gradient by < 0.3 rel-L2 (CFG amplifies the teacher's quantisation noise by the guidance scale); against the fp32
+    CPU oracle chain (LoRA folded in, same draws) the loss is within 8 %."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from oracle import arcflow_ref as R
+    from oracle import dit_ref as D
+    cfg = D.QwenCfg(num_layers=2, heads=2, joint_dim=192)
+    w = D.make_qwen_weights(cfg, seed=21)
+    g = torch.Generator().manual_seed(22)
+    w['proj_out.weight'] = (torch.randn(64, 256, generator=g) * 0.05).bfloat16()
+    w['proj_out.bias'] = (torch.randn(64, generator=g) * 0.02).bfloat16()
+    B, hp, wp, T, r = 1, 8, 8, 64, 32
+    pe = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+    ne = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+    x0 = torch.randn(B, hp * wp, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    cond = dict(prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), hp=hp, wp=wp)
+    Bs, res = None, {}
+    for fp8 in (False, True):
+        dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r,
+                           teacher_guidance_scale=4.0, teacher_fp8=fp8)
+        dist = ArcFlowDistiller('qwen', dict(num_double=2, heads=2, joint_dim=192), w, dc)
+        tr = dist.trunk
+        if Bs is None:
+            Bs = {sp.name: (torch.randn(sp.out_f, r, generator=g) * 0.02) for sp in tr.specs}
+        AB = {}
+        for sp in tr.specs:
+            tr.B(sp).copy_(Bs[sp.name].cuda())
+            AB[sp.name] = (tr.A(sp).cpu().clone(), tr.B(sp).cpu().clone())
+        tr.refresh()
+        if fp8:
+            assert dist.teacher._weights.get('d0.img_qkv.weight_q') is not None
+        dist.iteration = 2
+        info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+        res[fp8] = (info, dist.grads[0].clone(), dist.last_x.clone(), AB)
+    (i16, g16, x16, AB), (i8, g8, x8, _) = res[False], res[True]
+    assert not i8['skipped'] and i8['loss'] != i16['loss']                  # the fp8 teacher really ran
+    assert abs(i8['loss'] - i16['loss']) < 6e-2 * abs(i16['loss']), (i8['loss'], i16['loss'])
+    assert ((g8 - g16).norm() / g16.norm()).item() < 0.3
+    assert ((x8 - x16).norm() / x16.norm()).item() < 4e-2
+    # ---- fp32 CPU oracle, loss only ----------------------------------------------------------------------------------------
+    wt = {k: v.float() for k, v in w.items()}
+    ws = dict(wt)
+    for name, (a, b) in AB.items():
+        ws[name + '.weight'] = (wt[name + '.weight'] + b.bfloat16().float() @ a.bfloat16().float()).bfloat16().float()
+
+    def teacher_u(ctx, x_tok, t):
+        wv = dict(wt)
+        wv['proj_out_means.weight'] = torch.cat([wt['proj_out.weight']] + [torch.zeros(64, 256)] * 15)
+        wv['proj_out_means.bias'] = torch.cat([wt['proj_out.bias']] + [torch.zeros(64)] * 15)
+        return D.qwen_forward(wv, cfg, x_tok, ctx, t, hp, wp)[0][:, :, 0]
+
+    def teacher(x_lat, t):
+        xt = R.pack_latents(x_lat).bfloat16().float()
+        pos, neg = teacher_u(pe.float(), xt, t).bfloat16().float(), teacher_u(ne.float(), xt, t).bfloat16().float()
+        return R.unpack_latents(pos + R.cfg_bias(pos, neg, 4.0), hp, wp)
+    with torch.no_grad():
+        x, raw, total = x0.clone(), torch.ones(B), 0.0
+        for step in range(2):
+            m, lw, lg = D.qwen_forward(ws, cfg, x.bfloat16().float(), pe.float(), R.shift_sigma(raw), hp, wp)
+            ml, lwl, lgl = R.unpack_mixture(m.bfloat16().float(), lw.bfloat16().float(), lg.bfloat16().float(), hp, wp)
+            u_drop, u_stu, u_tea = draws[step]
+            mask = R.gm_dropout_mask(u_drop.reshape(B, 16, 1, 1, 1), 0.1)
+            loss, x_dst, raw = R.segment_distill(teacher, R.unpack_latents(x, hp, wp), ml, lwl, lgl, raw, 0.5, 0.5, u_stu, u_tea, drop_mask=mask)
+            total += float(loss) * 0.5
+            x = R.pack_latents(x_dst)
+    assert abs(i16['loss'] - total) < 3e-2 * abs(total) + 1e-4, (i16['loss'], total)
+    assert abs(i8['loss'] - total) < 8e-2 * abs(total), (i8['loss'], total)
+
+
+@pytest.mark.gpu
 def test_lora_dropout_masks_and_kernel_modes():
     from arcflow_amd import ops
     g = torch.Generator().manual_seed(0)
