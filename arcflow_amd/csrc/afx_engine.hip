@@ -74,6 +74,7 @@ struct afx_ctx {
   int head_n = 0;          // padded head width
   uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
   bool fp8 = false;            // block linears on the fp8 MFMA (afx_set_fp8_linear)
+  bool sk_flags_dirty = false; // a new workspace was bound: its stream-K flag words are cleared on the next forward's stream
   const float* temb_override = nullptr;   // optional [B, D] f32 replacing timestep_embedder(t) (training student with its LoRA pair)
   // conditioning of several denoising steps prepared in one pass over the stacked modulation matrix (afx_mmdit_prepare_steps)
   int prep_steps = 0, prep_B = 0, prep_use = -1;
@@ -330,7 +331,10 @@ int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes) {
   if (!ctx || !dptr || bytes <= 0) return fail(AFX_E_INVALID, "bad workspace");
   if (((uintptr_t)dptr & 255) != 0) return fail(AFX_E_INVALID, "workspace must be 256-byte aligned");
   if (bytes < GEMM_SK_FLAG_BYTES) return fail(AFX_E_WORKSPACE, "workspace too small");
-  HIP_TRY(hipMemset(dptr, 0, GEMM_SK_FLAG_BYTES));          // stream-K hand-off flags start cleared (the kernel re-arms them)
+  // The stream-K hand-off flags at the head of the workspace must start cleared (the kernel re-arms them).  The clear is issued on
+  // the stream of the NEXT forward (sk_flags_dirty), not here on the NULL stream: torch side streams are non-blocking, so a memset
+  // here would be unordered against a kernel still using a recycled allocator block and against the first forward.
+  ctx->sk_flags_dirty = true;
   ctx->ws = (char*)dptr;
   ctx->ws_bytes = bytes;
   ctx->prep_steps = 0;                                       // prepared steps lived in the old workspace
@@ -383,6 +387,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     return fail(AFX_E_WORKSPACE, "workspace too small: need %lld bytes, have %lld", (long long)ws.total,
                 (long long)c->ws_bytes);
   hipStream_t st = (hipStream_t)stream_;
+  if (c->sk_flags_dirty) {
+    HIP_TRY(hipMemsetAsync(c->ws, 0, GEMM_SK_FLAG_BYTES, st));
+    c->sk_flags_dirty = false;
+  }
   const int64_t D = c->D;
   const int H = d.heads, S = N + T;
   const int64_t R = (int64_t)B * S;
@@ -937,6 +945,7 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
 }
 
 int64_t afx_linear_sk_ws_bytes(void) { return GEMM_SK_FLAG_BYTES + GEMM_SK_SLAB_BYTES; }
+int afx_linear_sk_last_split(void) { return last_sk_cus(); }
 int afx_gemm_set_mode(int32_t impl, int32_t tile) {
   gemm_set_mode(impl, tile);
   return 0;

@@ -1344,6 +1344,10 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   }
 }
 
+int& last_sk_cus() {           // CUs per XCD the last 8-phase launch split its tail over (0: plain launch) -- read by the stream-K tests
+  static thread_local int v = 0;
+  return v;
+}
 LaunchTimer& launch_timer() {
   static thread_local LaunchTimer t;
   return t;
@@ -1527,7 +1531,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount >= 8)
       cus_per_xcd = prop.multiProcessorCount / 8;
   }
-  if (sk_mode && use == 2 && !conv && batch.sk_slab != nullptr && batch.sk_flags != nullptr && total % 8 == 0 && cus_per_xcd <= 32) {
+  // (the gate used to read sk_mode only, so afx_linear_bf16_sk -- sk_force -- compared the plain kernel with itself)
+  if ((sk_mode || batch.sk_force) && use == 2 && !conv && batch.sk_slab != nullptr && batch.sk_flags != nullptr && total % 8 == 0 && cus_per_xcd <= 32) {
     bool ok = true;
     for (int i = 0; i < batch.nprob; ++i)
       ok = ok && batch.p[i].out_f32 == 0 && batch.p[i].split_k == 1 && batch.p[i].K == batch.p[0].K && batch.p[i].fp8 == batch.p[0].fp8;
@@ -1545,6 +1550,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
       total = 8 * (full + C);
     }
   }
+  last_sk_cus() = batch.sk_cus;
   if (fp8 && launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(gemm_kernel_v2<true>, dim3(total), dim3(GEMM_THREADS), GEMM_LDS_BYTES, stream, launch_timer().start,
                           launch_timer().stop, 0, batch);

@@ -68,6 +68,7 @@ constexpr int64_t GEMM_SK_SLAB_BYTES = 256ll * 256 * 256 * 4;      // 256 work-g
 // ProfScope sets and clears them; a plain hipEventRecord pair costs a barrier packet each: ~2 % of the forward).
 struct LaunchTimer { hipEvent_t start = nullptr, stop = nullptr; };
 LaunchTimer& launch_timer();
+int& last_sk_cus();
 
 // ---- attention ------------------------------------------------------------------------------
 // vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)

@@ -156,7 +156,14 @@ def load_checkpoint(distiller, path: str, strict: bool = True) -> dict:
         distiller.opt8.clear()
         distiller._small.clear()
         distiller.opt_steps = 0
-        if isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw8bit':
+        want = {(a, b) for a, b, _ in distiller.optimizer_groups()}
+        have = set(opt.get('groups8', {})) | set(opt.get('groups32', {})) if isinstance(opt, dict) else set()
+        if isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw8bit' and not have <= want:
+            # written under another layout (lora_rank, block count, pre-round-3 per-learning-rate grouping): the (a, b) ranges do not
+            # describe this distiller's tensors -- restoring them would pair moments with the wrong parameters
+            warnings.warn(f'{path}: 8-bit optimizer state was written for a different parameter layout '
+                          f'({len(have - want)} of {len(have)} ranges unknown here): moments restart at zero')
+        elif isinstance(opt, dict) and opt.get('format') == 'arcflow_amd.flat_adamw8bit':
             for (a, b), sd in opt['groups8'].items():
                 st = ops.AdamW8bitState(b - a, distiller.device)
                 st.load_state_dict(sd)

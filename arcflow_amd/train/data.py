@@ -113,6 +113,14 @@ def _load_item(path: str):
         return pickle.load(f)
 
 
+def _is_rank0() -> bool:
+    try:
+        import torch.distributed as dist
+        return not (dist.is_available() and dist.is_initialized()) or dist.get_rank() == 0
+    except Exception:
+        return int(os.environ.get('RANK', '0')) == 0
+
+
 class PromptEmbedCache:
     """Items: ``{'ids', 'name', 'prompt_embed_kwargs': {...}, 'latent_size'}`` (image_prompts.py:357-383)."""
     LEGACY = {'prompt_embeds': 'encoder_hidden_states', 'prompt_embeds_scale': 'encoder_hidden_states_scale',
@@ -139,23 +147,31 @@ class PromptEmbedCache:
             known = {}
             if os.path.exists(index_path):
                 import json
-                with open(index_path) as f:
-                    known = {k: tuple(v) for k, v in json.load(f).items()}
+                try:
+                    with open(index_path) as f:
+                        known = {k: tuple(v) for k, v in json.load(f).items()}
+                except (ValueError, OSError, AttributeError, TypeError):
+                    known = {}             # torn / foreign file (a killed job, another writer): rescan, rewrite below
             sizes, scanned = [], False
             for fn in self.files:
                 if fn not in known:
                     known[fn] = tuple(_load_item(os.path.join(cache_dir, fn)).get('latent_size', self.latent_size))
                     scanned = True
                 sizes.append(known[fn])
-            if scanned and size_index is None:
+            if scanned and size_index is None and _is_rank0():
+                # rank 0 only, temp file + os.replace: every rank of a data-parallel job constructs this dataset at the same moment, and
+                # a reader must never see a half-written index
                 try:
                     import json
-                    with open(index_path, 'w') as f:
+                    tmp = f'{index_path}.tmp{os.getpid()}'
+                    with open(tmp, 'w') as f:
                         json.dump({k: list(v) for k, v in known.items()}, f)
+                    os.replace(tmp, index_path)
                 except OSError:
                     pass               # read-only cache directory: scan again next time
             order = {s: i for i, s in enumerate(sorted(set(sizes)))}
             self.bucket_ids = [order[s] for s in sizes]
+            self._index_sizes, self._index_path = sizes, index_path
 
     def __len__(self):
         return len(self.files)
@@ -191,6 +207,10 @@ class PromptEmbedCache:
         raw = _load_item(os.path.join(self.cache_dir, self.files[i]))
         item = dict(ids=i, name=raw.get('prompt', ''), prompt_embed_kwargs=self._parse(raw),
                     latent_size=tuple(raw.get('latent_size', self.latent_size)))
+        known = getattr(self, '_index_sizes', None)
+        if known is not None and tuple(known[i]) != item['latent_size']:      # the index is never invalidated: a replaced item shows up here
+            raise RuntimeError(f'{self.files[i]}: latent_size {item["latent_size"]} but the bucket index {self._index_path} says '
+                               f'{tuple(known[i])} -- the cache changed after the index was written: delete the index and restart')
         if self.negative_prompt_embed_kwargs is not None:
             item['negative_prompt_embed_kwargs'] = self.negative_prompt_embed_kwargs
         return item

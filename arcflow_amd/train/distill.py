@@ -74,7 +74,7 @@ def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
 
 class ArcFlowDistiller:
     def __init__(self, family: str, engine_kwargs: dict, state_dict: Optional[Dict[str, torch.Tensor]], cfg: DistillConfig,
-                 device='cuda', process_group=None, packed: Optional[Dict[str, torch.Tensor]] = None):
+                 device='cuda', process_group=None, packed: Optional[Dict[str, torch.Tensor]] = None, init_seed: int = 1234):
         """state_dict: diffusers keys of the teacher (with ``proj_out``) plus the student heads ``proj_out_*``.
         Alternatively ``packed``: an already fused weight set on the device (arcflow_amd.weights.random_packed) that
         also carries ``teacher_head.{weight,bias}`` and ``norm_out.{weight,bias}`` -- synthetic-weight benchmarks."""
@@ -140,19 +140,62 @@ class ArcFlowDistiller:
         self.trunk = None
         if cfg.lora_rank > 0:      # adapted weights get private merged copies inside `packed` (teacher keeps the frozen ones)
             self.trunk = LoraTrunk(self.student, packed, cfg.lora_rank, self.params, self._off[4],
-                                   generator=torch.Generator(device=self.device).manual_seed(1234))
+                                   generator=torch.Generator(device=self.device).manual_seed(init_seed))
             self.ema[self._off[4]:].copy_(self.params[self._off[4]:])
         self.student.bind_packed(packed)
         self._ckpt = None
         self.reducer = GradReducer(process_group)
+        self.sync_module_states()
         self.iteration = 0
         self.opt_steps = 0
         self._norm_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
         self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.device)
 
     # ------------------------------------------------------------------ helpers
+    def sync_module_states(self, src: int = 0) -> None:
+        """Data parallel: every rank takes rank `src`'s trainables (flat fp32 buffer; EMA and optimizer state follow), as torch
+        DDP broadcasts the wrapped module's state at construction (lakonlab/parallel/ddp_wrapper.py:19-25).  Then the bf16 working
+        copies / merged LoRA weights are rebuilt and the ranks' buffers are checksummed against each other.  No-op on one rank.
+        Call again after loading a checkpoint on one rank only."""
+        red = self.reducer
+        if red.world == 1:
+            return
+        red.broadcast_(self.params, src)
+        red.broadcast_(self.ema, src)
+        self._sync_working_copies()
+        if self.trunk is not None:
+            self.trunk.refresh()
+        red.check_consistent(self.params)
+
     def _view(self, flat: torch.Tensor, i: int) -> torch.Tensor:
         return flat[self._off[i]:self._off[i + 1]]
+
+    def optimizer_groups(self):
+        """[(a, b, is_loggamma)]: ranges of the flat buffer the optimizer treats as units.  fp32 AdamW is element-wise, so only the
+        learning-rate split matters there (5 ranges).  adamw8bit follows bitsandbytes' granularity -- one state PER PARAMETER TENSOR
+        (optimizer/builder.py:11-24): its 256-value absmax blocks start at tensor starts and never straddle two tensors, and a tensor
+        below 4096 values (min_8bit_size: every bias of the heads / norm_out) keeps fp32 moments.  Cached: the layout is fixed."""
+        if getattr(self, '_opt_groups', None) is not None:
+            return self._opt_groups
+        K, C, L, D = self.K, self.C, self.L, self.D
+        n1, n2 = K * C, K * C + K * L                              # head rows: means | logweights | loggamma
+        hw, hb = self._off[0], self._off[1]
+        if self.cfg.optimizer != 'adamw8bit':
+            g = [(hw, hw + n2 * D, False), (hw + n2 * D, self._off[1], True), (hb, hb + n2, False), (hb + n2, self._off[2], True),
+                 (self._off[2], self.params.numel(), False)]
+        else:
+            g = [(hw, hw + n1 * D, False), (hw + n1 * D, hw + n2 * D, False), (hw + n2 * D, self._off[1], True),
+                 (hb, hb + n1, False), (hb + n1, hb + n2, False), (hb + n2, self._off[2], True),
+                 (self._off[2], self._off[3], False), (self._off[3], self._off[4], False)]
+            if self.trunk is not None:
+                r = self.trunk.r
+                for sp in self.trunk.specs:
+                    g += [(sp.off_a, sp.off_a + r * sp.in_f, False), (sp.off_b, sp.off_b + sp.out_f * r, False)]
+            g.sort()
+            assert g[0][0] == 0 and g[-1][1] == self.params.numel() and all(x[1] == y[0] for x, y in zip(g, g[1:])), \
+                'optimizer groups must tile the flat buffer'
+        self._opt_groups = [x for x in g if x[1] > x[0]]
+        return self._opt_groups
 
     def _sync_working_copies(self):
         ops.cast_bf16(self._view(self.params, 0), self.w_head.view(-1))
@@ -411,12 +454,7 @@ class ArcFlowDistiller:
             if it >= c.grad_clip_begin_iter and c.grad_clip > 0 and grad_norm > c.grad_clip:
                 scale *= c.grad_clip / (grad_norm + 1e-6)
             self.opt_steps += 1
-            K, C, L = self.K, self.C, self.L
-            n2 = K * C + K * L                                 # head rows below n2: means + logweights; then loggamma
-            hw, hb = self._off[0], self._off[1]
-            groups = [(hw, hw + n2 * self.D, lr), (hw + n2 * self.D, self._off[1], lr * c.loggamma_lr_mult),
-                      (hb, hb + n2, lr), (hb + n2, self._off[2], lr * c.loggamma_lr_mult),
-                      (self._off[2], self.params.numel(), lr)]
+            groups = [(a, b, lr * (c.loggamma_lr_mult if lg else 1.0)) for a, b, lg in self.optimizer_groups()]
             for a, b, glr in groups:
                 if b <= a:
                     continue

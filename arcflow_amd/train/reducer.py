@@ -75,6 +75,36 @@ class GradReducer:
         self._ev = None
         return self.last_exposed_ms
 
+    def broadcast_(self, flat: torch.Tensor, src: int = 0) -> torch.Tensor:
+        """Overwrite `flat` on every rank with rank `src`'s values -- what DDP does with the module state at construction
+        (``_sync_module_states``, reached through lakonlab/parallel/ddp_wrapper.py:19-25): ranks must start from identical trainables,
+        identical seeds alone do not guarantee it (a resumed rank, a different library build)."""
+        if self.dist is None or self.world == 1:
+            return flat
+        if flat.is_cuda and self.backend == 'gloo':
+            host = flat.detach().to('cpu', copy=True)
+            self.dist.broadcast(host, src=src, group=self.group)
+            flat.copy_(host)
+        else:
+            self.dist.broadcast(flat, src=src, group=self.group)
+        return flat
+
+    def check_consistent(self, flat: torch.Tensor, what: str = 'trainable parameters') -> None:
+        """Raise when the ranks do not hold the same values in `flat` (three fp64 checksums over different index subsets, MIN / MAX
+        over ranks; no temporary of the buffer's size: the FLUX trainable set is 650 M values).  Called after the construction
+        broadcast and by tools/train.py at every checkpoint interval."""
+        if self.dist is None or self.world == 1:
+            return
+        x = flat.detach().flatten()
+        sums = torch.stack([x.sum(dtype=torch.float64), x[::2].sum(dtype=torch.float64), x[1::3].sum(dtype=torch.float64)])
+        dev = 'cpu' if self.backend == 'gloo' else flat.device
+        lo, hi = sums.to(dev).clone(), sums.to(dev).clone()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        if not torch.equal(lo, hi):
+            raise RuntimeError(f'data-parallel ranks disagree on the {what}: checksums min {lo.tolist()} max {hi.tolist()} '
+                               f'(rank {self.rank} has {sums.tolist()})')
+
     def all_reduce_max(self, value: float, device) -> float:
         if self.dist is None or self.world == 1:
             return value

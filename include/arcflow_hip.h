@@ -353,6 +353,9 @@ int afx_linear_bf16_pre(const void* A, int64_t lda, const void* W, int64_t ldw, 
  * afx_linear_sk_ws_bytes() bytes, 256-byte aligned, whose first 4096 bytes were zeroed ONCE by the caller (hand-off flags; the
  * kernel re-arms them).  When the launch's tile count does not leave an under-filled last round the call is a plain GEMM. */
 int64_t afx_linear_sk_ws_bytes(void);
+/* CUs per XCD over which the calling thread's last afx_linear_bf16_sk launch split its under-filled last round (0: it ran as a plain
+ * GEMM) -- lets a test assert that the stream-K path really executed. */
+int afx_linear_sk_last_split(void);
 /* Tuning / test knob of every bf16 GEMM in the library (process-wide, not thread-safe against running launches): impl 3 (default) =
  * one-wave-per-SIMD kernel for the bf16 epilogue modes with the tile shape picked per launch (tile 0) or forced (1: 256x256,
  * 2: 288x192, 3: 320x192, 4: 128x128); impl 2 = 8-phase 256x256 kernel for everything; impl 1 = simple reference kernel.  Same meaning as the

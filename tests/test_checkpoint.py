@@ -120,6 +120,14 @@ def test_adamw8bit_distiller_first_step_equals_fp32_and_resumes_exactly(tmp_path
     a.train_step(_cond(), 2, rng=ra)
     f.train_step(_cond(), 2, rng=rf)
     assert a.exp_avg is None and a.opt8 and all(b - a_ >= 4096 for a_, b in a.opt8) and all(b - a_ < 4096 for a_, b in a._small)
+    # bitsandbytes granularity: one state per parameter TENSOR -- every LoRA A / B matrix, the three head matrices and
+    # norm_out.linear.weight are their own 8-bit groups (absmax blocks start at tensor starts), every bias keeps fp32 moments
+    groups = {(x, y) for x, y, _ in a.optimizer_groups()}
+    assert groups == set(a.opt8) | set(a._small)
+    for sp in a.trunk.specs:
+        assert (sp.off_a, sp.off_a + a.trunk.r * sp.in_f) in groups and (sp.off_b, sp.off_b + sp.out_f * a.trunk.r) in groups
+    assert (a._off[3], a._off[4]) in a._small and (a._off[2], a._off[3]) in a.opt8            # norm_out bias fp32, weight 8 bit
+    assert sum(1 for x, y in a._small if a._off[1] <= x < a._off[2]) == 3                       # the three head biases
     assert torch.allclose(a.params, f.params, rtol=0, atol=1e-7)        # (gradients of two runs differ by ~1e-10: atomics)
     a.train_step(_cond(seed=6), 2, rng=ra)
     f.train_step(_cond(seed=6), 2, rng=rf)
@@ -138,6 +146,16 @@ def test_adamw8bit_distiller_first_step_equals_fp32_and_resumes_exactly(tmp_path
     a.train_step(_cond(seed=4), 2, rng=r1)
     b.train_step(_cond(seed=4), 2, rng=r2)
     assert torch.allclose(a.params, b.params, rtol=0, atol=1e-7)
+    # a state written for another layout (ranges that are not this distiller's tensors) is refused with a warning, not mis-applied
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    g8 = ck['optimizer']['diffusion']['groups8']
+    k0 = sorted(g8)[0]
+    g8[(k0[0] + 128, k0[1] + 128)] = g8.pop(k0)
+    torch.save(ck, str(tmp_path / 'other_layout.pth'))
+    c, _ = _tiny_distiller(optimizer='adamw8bit')
+    with pytest.warns(UserWarning, match='different parameter layout'):
+        CK.load_checkpoint(c, str(tmp_path / 'other_layout.pth'))
+    assert not c.opt8 and c.opt_steps == 0
 
 
 @pytest.mark.gpu

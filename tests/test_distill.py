@@ -179,7 +179,19 @@ def _dp_worker(rank, world, port, tmp):
     assert red.bytes_launched == buf.numel() * 4        # every byte exactly once per iteration
     scale = red.finish()
     assert scale == 1.0 / world and red.bytes_launched == 0
-    torch.save(dict(local=local, reduced=buf, mx=red.all_reduce_max(float(rank + 1), 'cpu')), os.path.join(tmp, f'r{rank}.pt'))
+    # construction-time state sync (DDP's _sync_module_states): ranks start from different values, a mismatch is detected, the
+    # broadcast makes them rank 0's
+    state = torch.randn(1000, generator=torch.Generator().manual_seed(7 + rank))
+    mine = state.clone()
+    caught = False
+    try:
+        red.check_consistent(state)
+    except RuntimeError as e:
+        caught = 'disagree' in str(e)
+    red.broadcast_(state)
+    red.check_consistent(state)
+    torch.save(dict(local=local, reduced=buf, mx=red.all_reduce_max(float(rank + 1), 'cpu'), caught=caught, state=state, mine=mine),
+               os.path.join(tmp, f'r{rank}.pt'))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -192,6 +204,9 @@ def test_grad_reducer_gloo_world2(tmp_path):
     expect = r0['local'] + r1['local']
     assert torch.allclose(r0['reduced'], expect) and torch.allclose(r1['reduced'], expect)
     assert r0['mx'] == 2.0 and r1['mx'] == 2.0
+    # DDP-style state sync: the mismatch was detected on both ranks, then everybody holds rank 0's values
+    assert r0['caught'] and r1['caught'] and not torch.equal(r0['mine'], r1['mine'])
+    assert torch.equal(r0['state'], r0['mine']) and torch.equal(r1['state'], r0['mine'])
     red_single = __import__('arcflow_amd.train.reducer', fromlist=['GradReducer']).GradReducer()
     assert red_single.world == 1 and red_single.finish() == 1.0
 
@@ -228,8 +243,12 @@ def _dp_train_worker(rank, world, port, tmp):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from arcflow_amd.train import ArcFlowDistiller
     st = torch.load(os.path.join(tmp, 'setup.pt'), weights_only=False)
-    dd = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), st['w'], st['dc'])
+    # every rank draws its adapter initialisation from a DIFFERENT seed: the construction-time broadcast (sync_module_states,
+    # DDP's _sync_module_states) must leave all of them with rank 0's trainables
+    dd = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), st['w'], st['dc'],
+                          init_seed=1234 + 17 * rank)
     assert dd.reducer.world == world and dd.reducer.rank == rank
+    torch.save(dd.params.cpu(), os.path.join(tmp, f'init{rank}.pt'))
     for sp in dd.trunk.specs:
         dd.trunk.B(sp).copy_(st['B'][sp.name].cuda())
     dd.trunk.refresh()
@@ -272,6 +291,8 @@ def test_two_rank_train_step_equals_single_process_batch(tmp_path):
     mp.spawn(_dp_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     r0, r1 = (torch.load(os.path.join(tmp_path, f'dp{i}.pt'), weights_only=False) for i in range(2))
     assert torch.equal(r0['grad'], r1['grad']) and torch.equal(r0['params'], r1['params'])      # ranks stay in lock-step
+    i0, i1 = (torch.load(os.path.join(tmp_path, f'init{i}.pt')) for i in range(2))
+    assert torch.equal(i0, i1)                                   # rank 1 drew seed 1251 and was overwritten with rank 0's (seed 1234) state
     ref_g, ref_p = single.grad.cpu(), single.params.cpu()
     got_g = r0['grad'] * 0.5                                    # the exchanged SUM x 1/world
     rel = ((got_g - ref_g).norm() / ref_g.norm()).item()

@@ -420,9 +420,14 @@ def test_linear_stream_k_tail(ops, M, N, K):
     plain = ops.linear(a, w, b, epilogue='gelu', gelu_col0=N // 2)
     ref = a.float() @ w.float().t() + b.float()
     ref[:, N // 2:] = torch.nn.functional.gelu(ref[:, N // 2:], approximate='tanh')
+    from arcflow_amd import _lib
+    split_expected = (M, N, K) != (2048, 1024, 512)          # 32 tiles: no under-filled last round worth splitting -> plain launch
     for rep in range(2):
         out = ops.linear(a, w, b, epilogue='gelu', gelu_col0=N // 2, sk_ws=ws)
         torch.cuda.synchronize()
+        # the split path must really have run (the launcher used to ignore sk_force and these tests compared the plain
+        # kernel with itself); afx_linear_sk_last_split = CUs per XCD the tail was split over, 0 = plain launch
+        assert (_lib.load().afx_linear_sk_last_split() > 0) == split_expected
         assert rel_l2(out, ref) < 4e-3, rep
         assert rel_l2(out, plain) < 1e-3, rep
         assert (out.float() - plain.float()).abs().max().item() < 0.05 * plain.float().abs().max().item()
@@ -442,4 +447,6 @@ def test_linear_stream_k_gate_residual_inplace(ops):
     ref = x.float() + gate * (a.float() @ w.float().t() + b.float())
     ws = ops.stream_k_workspace()
     out = ops.linear(a, w, b, epilogue='gate_res', gate=gate, residual=x, rows_per_batch=M, out=x, sk_ws=ws)
+    from arcflow_amd import _lib
+    assert _lib.load().afx_linear_sk_last_split() > 0
     assert rel_l2(out, ref) < 4e-3

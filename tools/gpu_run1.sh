@@ -1,8 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-: > gpurun_out/attn3_ablate.log
-for v in trace t_merge t_nodma t_mergenodma t_nolds t_noadd t_noexp t_novalu trace; do
-echo "== $v" >> gpurun_out/attn3_ablate.log
-ARCFLOW_HIP_LIB=$PWD/arcflow_amd/lib/libarcflow_hip_$v.so timeout 120 python tools/attn3_trace.py 2>&1 | grep "block 0 w0\|block 300 w0" >> gpurun_out/attn3_ablate.log
-done
-cat gpurun_out/attn3_ablate.log
+timeout 1200 python -m pytest tests/test_inference_script.py tests/test_checkpoint.py tests/test_distill.py "tests/test_hip_kernels.py::test_linear_stream_k_tail" "tests/test_hip_kernels.py::test_linear_stream_k_gate_residual_inplace" -x -q -m gpu > gpurun_out/t_new.log 2>&1; tail -30 gpurun_out/t_new.log
