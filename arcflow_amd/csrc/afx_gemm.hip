@@ -158,7 +158,8 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
-  constexpr int NS = SWAP ? NJ / 2 : NJ;       // steps per row tile
+  constexpr int NS = SWAP ? (NJ + 1) / 2 : NJ; // steps per row tile (SWAP with an odd NJ: the last step pairs the lone column tile with
+                                               // nothing -- the lanes that would own the missing tile's columns are masked out)
   constexpr uint32_t OOB = 0x80000000u;        // a byte offset past every buffer below: the hardware drops the access
   typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
   const int M = P.M, N = P.N;
@@ -201,7 +202,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
   for (int st = 0; st < NS; ++st) {
     gcol[st] = SWAP ? col_base + (2 * st + (fq & 1)) * 16 + (fq >> 1) * 8 : col_base + st * 16 + fq * 4;
-    const bool col_ok = gcol[st] < N;
+    const bool col_ok = gcol[st] < N && (!SWAP || 2 * st + (fq & 1) < NJ);
     coff[st] = col_ok ? (uint32_t)gcol[st] * 2u : OOB;
 #ifdef AFX_GEMM_TRACE
     if (EPI == EPI_NONE && P.gelu_col0 == -12345) coff[st] = OOB;     // tools/gemm_trace.hip TRACE_NOSTORE: epilogue without write traffic
@@ -321,7 +322,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       if constexpr (SWAP) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), 2 * st + 1 < NJ ? __float_as_uint(acc[ii][(2 * st + 1) % NJ][e]) : 0u, false, false);
           v[e] = __uint_as_float(sw[0]);
           v[4 + e] = __uint_as_float(sw[1]);
         }
@@ -530,7 +531,7 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
       if (region == 2) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
     }
   }
-  if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4)) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
+  if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4) && NJ % 2 == 0) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
     if (P.out_f32 == 1 || P.out_f32 == 2) { epi_store_f32<MI, NJ>(P, acc, row_base, col_base, frow, fq); return; }
   }
   if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
@@ -1147,7 +1148,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
   constexpr int NM = MI * NJ;                                  // MFMAs per k-half
   constexpr int W_SP = (NM / 2) / NJ, A_SP = (NM / 2) / MI;    // MFMAs between two DMA issues in the second half of a phase
-  static_assert(4 * MI * NJ <= 256 && NJ % 2 == 0 && 2 * (MI + NJ) <= NM && W_SP >= 2 && A_SP >= 2, "v3 tile shape");
+  static_assert(4 * MI * NJ <= 256 && 2 * (MI + NJ) <= NM && W_SP >= 2 && A_SP >= 2, "v3 tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const smem_w = smem + 2 * A_SLOT;
   const int tid = threadIdx.x;
@@ -1371,12 +1372,15 @@ bool gemm_qk_fusion_available() {
 }
 void gemm_set_mode(int impl, int tile) {
   gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;
-  gemm_mode().tile = (tile >= 0 && tile <= 4) ? tile : 0;
+  gemm_mode().tile = (tile >= 0 && tile <= 5) ? tile : 0;
 }
 struct TileCfg { int tm, tn, group_m; };
 // {4,4} = 128x128: 64 accumulators and 80 KiB of LDS, TWO work-groups per CU -- for launches that would leave most CUs without a
 // 256x256 tile (the rank-256 LoRA products of the distillation step: N = 256 or M = 256, 12-84 tiles at 256x256)
-static const TileCfg kTileCfg[4] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}, {128, 128, 8}};
+// {8,7} = 256x224: the shape that makes the forward's N = 3072 launches (18 row tiles of the 4096 + 512 row problems x 14 column
+// tiles = 252) and the N = 12288 launch (990 tiles = 3.87 rounds of 7/8-size tiles) fill their last round -- what hipBLASLt's
+// MT256x224 kernels do for these shapes (1295 vs 1161 TF at 4608 x 3072 x 3072 in profiles/r02s_microbench.log)
+static const TileCfg kTileCfg[5] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}, {128, 128, 8}, {256, 224, GROUP_M}};
 
 static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   int total = 0;
@@ -1470,12 +1474,19 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   if (qk && !v3_ok) return hipErrorInvalidValue;        // callers ask gemm_qk_fusion_available() first
   if (v3_ok) {
     int best = 0;
+    bool f32_any = false;                               // fp32-output launches: the shapes with an even number of column tiles per wave only
+    for (int i = 0; i < batch.nprob; ++i) f32_any = f32_any || batch.p[i].out_f32 != 0;
     if (qk) best = 0;                                   // one head = one wave's 128 columns: the 256x256 shape only
-    else if (tile_env >= 1 && tile_env <= 4) best = tile_env - 1;
+    else if (tile_env >= 1 && tile_env <= 5) best = (tile_env == 5 && f32_any) ? 0 : tile_env - 1;
     else {
       double best_cost = 0;
       int tiles256 = 0;
-      for (int c = 0; c < 4; ++c) {
+      static double pen_224 = -1;
+      if (pen_224 < 0) {
+        const char* e = getenv("AFX_GEMM_PEN224");       // A/B knob: cost factor of the 256x224 shape (1e9 = never pick it)
+        pen_224 = e ? atof(e) : 1.03;
+      }
+      for (int c = 0; c < 5; ++c) {
         const int tiles = count_tiles(batch, kTileCfg[c].tm, kTileCfg[c].tn, false);
         if (tiles == 0) return hipSuccess;
         if (c == 0) tiles256 = tiles;
@@ -1491,6 +1502,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
         if (c == 1) pen = batch.p[0].K <= 8192 ? 1.05 : 1.5;
         if (c == 2) pen = 1.10;
         if (c == 3) pen = 2.0;          // 16 MFMAs per 8 fragment reads and 4 DMA issues per k-half: the loop runs at about half rate
+        if (c == 4) pen = f32_any ? 1e9 : pen_224;   // 56 MFMAs per 15 fragment reads (256x256: 64 per 16); bf16 epilogues only
         const double cost = (double)rounds * kTileCfg[c].tm * kTileCfg[c].tn * pen;
         if (c == 0 || cost < best_cost) { best = c; best_cost = cost; }
       }
@@ -1501,7 +1513,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     batch.group_m = group_m_env ? group_m_env : kTileCfg[best].group_m;
     batch.sk_cus = 0;
     return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream)
-         : best == 2 ? launch_v3<10, 6>(batch, total, stream) : launch_v3<4, 4>(batch, total, stream);
+         : best == 2 ? launch_v3<10, 6>(batch, total, stream) : best == 3 ? launch_v3<4, 4>(batch, total, stream)
+         : launch_v3<8, 7>(batch, total, stream);
   }
   int total = count_tiles(batch, BM, BN, true);
   batch.total_tiles = total;

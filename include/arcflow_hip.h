@@ -358,7 +358,7 @@ int64_t afx_linear_sk_ws_bytes(void);
 int afx_linear_sk_last_split(void);
 /* Tuning / test knob of every bf16 GEMM in the library (process-wide, not thread-safe against running launches): impl 3 (default) =
  * one-wave-per-SIMD kernel for the bf16 epilogue modes with the tile shape picked per launch (tile 0) or forced (1: 256x256,
- * 2: 288x192, 3: 320x192, 4: 128x128); impl 2 = 8-phase 256x256 kernel for everything; impl 1 = simple reference kernel.  Same meaning as the
+ * 2: 288x192, 3: 320x192, 4: 128x128, 5: 256x224); impl 2 = 8-phase 256x256 kernel for everything; impl 1 = simple reference kernel.  Same meaning as the
  * AFX_GEMM_IMPL / AFX_GEMM_TILE environment variables, which it overrides.  Returns 0. */
 int afx_gemm_set_mode(int32_t impl, int32_t tile);
 /* Kernel choice of every joint attention launch (process-wide; same meaning as AFX_ATTN_IMPL, which it overrides): 0 (default) = the

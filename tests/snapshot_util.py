@@ -152,7 +152,7 @@ def _qwen_tokenizer(folder, max_len=2048):
     return len(vocab)
 
 
-def write_qwen_snapshot(root, num_layers=2, heads=2, joint_dim=128, vae_dim=32, with_text=True, with_vae=True, seed=0):
+def write_qwen_snapshot(root, num_layers=2, heads=2, joint_dim=256, vae_dim=32, with_text=True, with_vae=True, seed=0):
     """Synthetic Qwen/Qwen-Image snapshot in the layout inference_qwen.py:5-8 loads: transformer/ (QwenImageTransformer2DModel:
     sharded safetensors + index + config.json), vae/ (AutoencoderKLQwenImage), text_encoder/ (Qwen2_5_VLForConditionalGeneration),
     tokenizer/, scheduler/.  -> dict of what was written."""
@@ -190,7 +190,8 @@ def write_qwen_snapshot(root, num_layers=2, heads=2, joint_dim=128, vae_dim=32, 
         from transformers import Qwen2_5_VLConfig, Qwen2_5_VLForConditionalGeneration
         torch.manual_seed(seed + 2)
         nv = _qwen_tokenizer(os.path.join(root, 'tokenizer'))
-        text = dict(vocab_size=nv, hidden_size=joint_dim, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, num_key_value_heads=1,
+        assert joint_dim % 128 == 0           # the language model's head dim must be 128 (mrope_section [16, 24, 24])
+        text = dict(vocab_size=nv, hidden_size=joint_dim, intermediate_size=256, num_hidden_layers=2, num_attention_heads=joint_dim // 128, num_key_value_heads=1,
                     max_position_embeddings=2048, rope_theta=1e6, rms_norm_eps=1e-6, tie_word_embeddings=False,
                     rope_scaling=dict(type='mrope', mrope_section=[16, 24, 24]))
         vis = dict(depth=1, hidden_size=64, intermediate_size=128, num_heads=2, out_hidden_size=joint_dim)

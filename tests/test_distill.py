@@ -504,7 +504,7 @@ def test_qwen_fp8_teacher_true_cfg_step_is_baseline_configs4():
     g = torch.Generator().manual_seed(22)
     w['proj_out.weight'] = (torch.randn(64, 256, generator=g) * 0.05).bfloat16()
     w['proj_out.bias'] = (torch.randn(64, generator=g) * 0.02).bfloat16()
-    B, hp, wp, T, r = 1, 8, 8, 64, 32
+    B, hp, wp, T, r = 1, 8, 8, 64, 64
     pe = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
     ne = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
     x0 = torch.randn(B, hp * wp, 64, generator=g)
