@@ -7,16 +7,16 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O && mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_under_rocprof.log 2>/dev/null
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.log 2>/dev/null
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
 for tpw in 1 2 4; do
   AFX_STEP_TPW=$tpw rocprofv3 --kernel-trace --stats --output-format csv -d $O/step_tpw$tpw -- python $R/tools/step_bench.py > $O/step_tpw$tpw.log 2>/dev/null
 done
 cd $R
 python bench.py --steps 10 --warmup 2 > $O/bench_flux.json 2>/dev/null
 python bench.py --model qwen --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_qwen.json 2>/dev/null
-python bench.py --streams 2 --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_flux_2streams.json 2>/dev/null
+python bench.py --streams 2 --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $O/bench_flux_2streams.json 2>/dev/null
 python bench.py --train --steps 2 --warmup 1 > $O/bench_train_flux.json 2>$O/bench_train_flux.err
 python bench.py --train --model qwen --steps 2 --warmup 1 > $O/bench_train_qwen.json 2>$O/bench_train_qwen.err
 python bench.py --train --model qwen --teacher-fp8 --steps 2 --warmup 1 > $O/bench_train_qwen_fp8.json 2>$O/bench_train_qwen_fp8.err
