@@ -1,6 +1,6 @@
 // Joint flash attention forward for gfx950 -- ONE wave per SIMD, 64 queries per wave, hand-placed instruction stream.
-// head_dim 128, bf16 in / out, no mask, S a multiple of 64.  The MMDiT product path (afx_attn.hip's 4-wave kernel stays for
-// ragged sequences and the text encoders' EXT variants; launch_attention dispatches).
+// head_dim 128, bf16 in / out, no mask, any S >= 128.  The MMDiT product path (afx_attn.hip's 4-wave kernel stays for shorter
+// sequences and the text encoders' EXT variants; launch_attention dispatches).
 //
 // Same mathematics and operand layouts as attention_kernel (afx_attn.hip): both products transposed on v_mfma_f32_32x32x16_bf16,
 //     S^T = K . Q^T   D[key][query]         O^T = V^T . P^T   D[d][query]
@@ -78,7 +78,7 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 // v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
 __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                   int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
-                                                                  int64_t ldo, int H, int S, int nqb, int B, float* __restrict__ lse, int dbg) {
+                                                                  int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
   const int rem = slot_id % per_head;
   const int b = rem / nqb;
   const int q0 = (rem % nqb) * QBLK + wave * 64;
-  const int ntiles = S / KVB;                                    // S % 64 == 0 (launcher)
+  const int ntiles = S_pad / KVB;                                // >= 2 (launcher); S_pad = roundup(S, 64), V^T is zero-padded to it
   const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
   const float neg_c = -c;
   const float thr = RESCALE_LOG2 / c;
@@ -118,11 +118,34 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
   const int dk_r = tid >> 4, dk_c = ((tid & 15) ^ (dk_r & 15)) << 3;
   const int dv_r = tid >> 3, dv_c = ((tid & 7) ^ ((dv_r >> 1) & 7)) << 3;
 #define A3_KOFF(i) ((uint32_t)(((int64_t)(dk_r + 16 * (i)) * ldk + dk_c) * 2))
-#define A3_VOFF(i) ((uint32_t)(((int64_t)(dv_r + 32 * (i)) * S + dv_c) * 2))
+#define A3_VOFF(i) ((uint32_t)(((int64_t)(dv_r + 32 * (i)) * S_pad + dv_c) * 2))
   const uint32_t koff0 = A3_KOFF(0), koff1 = A3_KOFF(1), koff2 = A3_KOFF(2), koff3 = A3_KOFF(3);
   const uint32_t voff0 = A3_VOFF(0), voff1 = A3_VOFF(1), voff2 = A3_VOFF(2), voff3 = A3_VOFF(3);
+  // Ragged S: the K rows of the LAST tile past the end are clamped to row S - 1 (finite data; their scores start from -inf, below),
+  // so the last tile's DMA pieces use their own per-lane offsets; tiles past the end re-fetch the last one.
+  const int last0 = (ntiles - 1) * KVB;
+#define A3_KOFFL(i) ((uint32_t)(((int64_t)(min(last0 + dk_r + 16 * (i), S - 1) - last0) * ldk + dk_c) * 2))
+  const uint32_t koffl0 = A3_KOFFL(0), koffl1 = A3_KOFFL(1), koffl2 = A3_KOFFL(2), koffl3 = A3_KOFFL(3);
+#define A3_KOFS(TILE)                                                                                                     \
+  const bool klast_ = (TILE) >= ntiles - 1;                                                                               \
+  const uint32_t kofs0 = klast_ ? koffl0 : koff0, kofs1 = klast_ ? koffl1 : koff1, kofs2 = klast_ ? koffl2 : koff2,       \
+                 kofs3 = klast_ ? koffl3 : koff3;
+  // Key mask = the C operand of the first k-step of every S^T tile: zeros, except for the ragged last tile where keys >= S start
+  // from -inf (their exp2 is 0: no weight, no row-sum contribution).  MFMA row r of key block kb = key (r&3) + 8 (r>>2) + 4 hi.
+  f32x16_t kmask0, kmask1;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kmask0[r] = kmask1[r] = 0.f;
+#define A3_MASK_LAST(TILE)                                                                                                \
+  if (S != S_pad && (TILE) == ntiles - 1) {                                                                               \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                      \
+      const int key_ = last0 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                                           \
+      kmask0[r] = key_ >= S ? -INFINITY : 0.f;                                                                            \
+      kmask1[r] = key_ + 32 >= S ? -INFINITY : 0.f;                                                                       \
+    }                                                                                                                     \
+    asm volatile("s_nop 7" : "+v"(kmask0), "+v"(kmask1)); /* VALU write -> MFMA SrcC read wait states */                  \
+  }
   const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * S * ldk + h * 128);
-  const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S);
+  const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S_pad);
   const int64_t ktile_bytes = (int64_t)KVB * ldk * 2;
   // tiles past the end re-fetch the last one into a free slot: the DMA count per iteration stays 8
   auto k_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(kbase + tt * ktile_bytes)); };
@@ -235,7 +258,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
     const float l_tot = lsum + __shfl_xor(lsum, 32, 64);                                                           \
     const float inv = 1.0f / l_tot;                                                                                \
     const int row = q02 + (SL) * 32 + ql2;                                                                         \
-    if (lse != nullptr && hi2 == 0 && row < S) lse[((int64_t)b * H + h) * S + row] = (MRUN) * c + __log2f(l_tot); \
+    if (lse != nullptr && hi2 == 0 && row < S) lse[((int64_t)b * H + h) * S_pad + row] = (MRUN) * c + __log2f(l_tot); \
     bf16_t* op = o + ((int64_t)b * S + row) * ldo + h * 128 + hi2 * 8;                                             \
     A3_READ_##SL##_0 store_tile(SL, 0, inv, row, op);                                                              \
     A3_READ_##SL##_1 store_tile(SL, 1, inv, row, op);                                                              \
@@ -269,7 +292,7 @@ extern "C" int afx_debug_attn3_trace(unsigned* host_out) {      // [2 blocks][4 
 #endif
 }
 
-bool attention_v3_eligible(int S) { return S % a3::KVB == 0 && S >= 2 * a3::KVB; }
+bool attention_v3_eligible(int S) { return S > a3::KVB; }        // >= 2 KV tiles (the pipeline's tile 0 is never the last one)
 
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
                                int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse) {
@@ -281,6 +304,7 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
     attr = true;
   }
   const int nqb = (S + a3::QBLK - 1) / a3::QBLK;
+  const int S_pad = (int)attn_spad(S);
   const dim3 grid(8 * ((H + 7) / 8) * nqb * B);
   static int dbg = -1;
   if (dbg < 0) {
@@ -289,9 +313,9 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
-                          q, ldq, k, ldk, vt, o, ldo, H, S, nqb, B, lse, dbg);
+                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg);
   else
-    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, nqb, B, lse, dbg);
+    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg);
   return hipGetLastError();
 }
 

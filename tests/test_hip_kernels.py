@@ -104,8 +104,8 @@ def test_linear_gate_residual_inplace(ops, gemm_mode):
 
 
 # ------------------------------------------------------------------------------------------ attention
-# afx_attn_set_impl: 0 = the one-wave-per-SIMD kernel (afx_attn3.hip; S % 64 == 0, otherwise the launcher falls back to the 4-wave
-# kernel), 1 = the 4-wave kernel always.  Both must match fp32 softmax on the same bf16 inputs.
+# afx_attn_set_impl: 0 = the one-wave-per-SIMD kernel (afx_attn3.hip; any S > 64 -- shorter sequences fall back to the 4-wave kernel),
+# 1 = the 4-wave kernel always.  Both must match fp32 softmax on the same bf16 inputs.
 @pytest.fixture(params=[0, 1], ids=['v3-wave64q', '4wave'])
 def attn_impl(request, ops):
     ops.set_attn_impl(request.param)
@@ -120,10 +120,11 @@ def _sdpa_ref(q, k, v):
 
 
 @pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2), (1, 129, 1), (1, 128, 1), (1, 192, 2), (2, 320, 3),
-                                   (1, 576, 9), (1, 2048, 4)])
+                                   (1, 576, 9), (1, 2048, 4), (1, 65, 1), (1, 191, 2), (2, 1101, 3), (1, 767, 1)])
 def test_attention(ops, attn_impl, B, S, H):
     """S = 128 (two KV tiles: prologue + last-tile code only), 192 (one loop iteration), 320 / 576 (partly filled 256-query blocks,
-    2-4 loop iterations: every ring slot), H = 9 (heads -> XCD map with an incomplete last group), ragged S (4-wave kernel)."""
+    2-4 loop iterations: every ring slot), H = 9 (heads -> XCD map with an incomplete last group), ragged S (the last KV tile's
+    keys past the end start from -inf through the key mask: 65 = one real key in the last tile, 191 = one masked key, 333, 767, 1101)."""
     g = torch.Generator().manual_seed(S)
     q = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
     k = bf(torch.randn(B, S, H, 128, generator=g)).to(dev())
@@ -210,8 +211,8 @@ def _count_nonidentical(fn, reps, junk):
 @pytest.mark.parametrize('S', [4608, 4173])
 def test_attention_race_probe(ops, S):
     """100+ launches on fixed inputs with cache-disturbing work in between: every output bit-identical.  This is the probe that found
-    the compiler-dropped DMA wait of round 2; S = 4608 runs the one-wave-per-SIMD kernel (hand-counted vmcnt / lgkmcnt
-    waits, LDS rings), S = 4173 the 4-wave kernel's ragged path."""
+    the compiler-dropped DMA wait of round 2: the one-wave-per-SIMD kernel (hand-counted vmcnt / lgkmcnt waits, LDS rings)
+    at S = 4608 and on the ragged S = 4173 (clamped last-tile DMA, key mask)."""
     g = torch.Generator(device='cuda').manual_seed(0)
     q, k, v = (torch.randn(1, S, 24, 128, generator=g, device='cuda').bfloat16() for _ in range(3))
     junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')

@@ -72,7 +72,7 @@ if __name__ == '__main__':
         print('FAILED' if bad else 'OK', bad)
         sys.exit(1 if bad else 0)
     print('parity vs fp32 softmax on the device')
-    shapes = [(1, 128, 1), (1, 256, 2), (1, 320, 3), (2, 576, 2), (1, 1024, 8), (1, 4224, 24), (1, 4608, 24)]
+    shapes = [(1, 128, 1), (1, 256, 2), (1, 320, 3), (2, 576, 2), (1, 1024, 8), (1, 4224, 24), (1, 4608, 24), (1, 65, 1), (1, 333, 2), (1, 4173, 24), (2, 1101, 24)]
     for B, S, H in shapes:
         for impl in (1, 0):
             err, fin = check(B, S, H, impl)
@@ -100,6 +100,8 @@ if __name__ == '__main__':
             timeit(1, 4608, 24, impl, a.reps)
     for impl in (1, 0):
         timeit(1, 4224, 24, impl, a.reps)
+    for impl in (1, 0):
+        timeit(1, 4173, 24, impl, a.reps)
     ops.set_attn_impl(0)
     print('FAILED' if bad else 'OK', bad)
     sys.exit(1 if bad else 0)

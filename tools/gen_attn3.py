@@ -94,7 +94,9 @@ def asm(text, outs='', ins='', clob=''):
 def qk(sl, m):
     """MFMA m = 0..15 of S^T = K Q^T of slab sl: kb = m & 1, s = m >> 1."""
     kb, s = m & 1, m >> 1
-    return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, {0 if s == 0 else S(sl, kb)}')
+    if s == 0:      # the first k-step starts from the key mask of the tile (all zeros except in the ragged last tile: -inf past the end)
+        return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, %0', '', f'"v"(kmask{kb})')
+    return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, {S(sl, kb)}')
 
 
 def pv(sl, m):
@@ -119,7 +121,7 @@ def read_k(i, slot):
 
 def dma(kind, slot, piece):
     base = (0 if kind == 'k' else V_BASE) + slot * TILE + piece * 4096
-    src, off = ('ksrc', f'koff{piece}') if kind == 'k' else ('vsrc', f'voff{piece}')
+    src, off = ('ksrc', f'kofs{piece}') if kind == 'k' else ('vsrc', f'voff{piece}')
     # s_add_u32 writes SCC: without the clobber hipcc keeps a loop-exit compare alive across this statement (it did: endless loop)
     return asm(f's_add_u32 m0, %0, {base}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %1, %2', '', f'"s"(wave_lds), "v"({off}), "s"({src})',
                '"memory", "scc"')
@@ -251,7 +253,7 @@ def prologue_dma():
     out = ['// generated by tools/gen_attn3.py -- K(0), K(1), K(2), V^T(0), K(3), V^T(1): the order the counted waits assume']
     for kind, tile, slot in (('k', 0, 0), ('k', 1, 1), ('k', 2, 2), ('v', 0, 0), ('k', 3, 3), ('v', 1, 1)):
         src = 'ksrc' if kind == 'k' else 'vsrc'
-        out.append(f'{{ const uint64_t {src} = {kind}_src({tile});')
+        out.append(f'{{ const uint64_t {src} = {kind}_src({tile});' + (f' A3_KOFS({tile})' if kind == 'k' else ''))
         out += [dma(kind, slot, i) for i in range(4)]
         out.append('}')
     return out
@@ -278,7 +280,7 @@ def body(J):
     out.append('A3_TR(4)')
     out.append(wait('s_barrier'))
     out.append('A3_TR(0)')
-    out.append('{ const uint64_t ksrc = k_src(t + 4), vsrc = v_src(t + 2);')
+    out.append('{ const uint64_t ksrc = k_src(t + 4), vsrc = v_src(t + 2); A3_KOFS(t + 4) A3_MASK_LAST(t + 1)')
     # phase A: S_A(t+1), O_A += V(t) P_A(t) | softmax of S_B(t) | V(t) fragments, DMA K(t+4) -> slot J
     sm = softmax_ops(1)
     cnt = valu_counts(True)
