@@ -41,28 +41,42 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def audit_asm_owned(asm_path: str, kernel_substr: str) -> None:
-    """A kernel whose registers are asm-owned must contain no compiler-generated accumulator move and no scratch access: hipcc only
-    emits them to spill, and it would spill INTO registers it cannot know are in use (silent corruption).  Raises on a violation."""
+def audit_asm_owned(asm_path: str, kernel_substr: str, vgpr_limit: int = 96) -> None:
+    """A kernel whose registers are asm-owned (literal names in the asm text: v[vgpr_limit:255] and the whole accumulator file) must
+    contain no compiler-generated instruction that touches them and no scratch access: hipcc cannot know they are in use, and
+    amdgpu_num_vgpr is a budget, not a fence (it was exceeded once: silent corruption).  Raises on a violation."""
+    import re
+    reg = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\b(a)\d+\b|\b(a)\[\d+:\d+\]')
     in_kernel = in_asm = False
+    seen = False
     bad = []
     with open(asm_path) as f:
         for n, line in enumerate(f, 1):
             t = line.strip()
-            if t.endswith(':') and not t.startswith('.L') and not t.startswith(';'):
-                in_kernel = kernel_substr in t
-            if not in_kernel:
+            label = t.split(';')[0].strip()          # "_ZN3afx...E:      ; @_ZN3afx..."
+            if label.endswith(':') and not label.startswith('.L') and label:
+                in_kernel = kernel_substr in label
+                seen = seen or in_kernel
+            if not in_kernel or not t:
                 continue
             if 'ASMSTART' in t:
                 in_asm = True
             elif 'ASMEND' in t:
                 in_asm = False
-            elif not in_asm and (t.startswith('v_accvgpr') or t.startswith('scratch_') or t.startswith('buffer_') and 'offen' in t):
-                bad.append(f'{n}: {t}')
-            if '.private_segment_fixed_size' in t or 'ScratchSize' in t:
-                pass
+            elif not in_asm and t[0] not in ';.':
+                code = t.split(';')[0]
+                if t.startswith('v_accvgpr') or t.startswith('scratch_') or t.startswith('buffer_') and 'offen' in t:
+                    bad.append(f'{n}: {t}')
+                    continue
+                for m in reg.finditer(code):
+                    if m.group(4) or m.group(5) or int(m.group(1) or m.group(3)) >= vgpr_limit:
+                        bad.append(f'{n}: {t}')
+                        break
+    if not seen:
+        raise RuntimeError(f'{asm_path}: kernel {kernel_substr} not found by the register audit')
     if bad:
-        raise RuntimeError(f'{asm_path}: compiler-generated spill code in an asm-owned kernel ({kernel_substr}):\n' + '\n'.join(bad[:20]))
+        raise RuntimeError(f'{asm_path}: compiler-generated code touches asm-owned registers / spills in {kernel_substr} '
+                           f'({len(bad)} instructions):\n' + '\n'.join(bad[:20]))
 
 
 def build(force: bool = False, verbose: bool = True) -> str:

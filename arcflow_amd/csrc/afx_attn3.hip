@@ -1,5 +1,5 @@
 // Joint flash attention forward for gfx950 -- ONE wave per SIMD, 64 queries per wave, hand-placed instruction stream.
-// head_dim 128, bf16 in / out, no mask, any S >= 128.  The MMDiT product path (afx_attn.hip's 4-wave kernel stays for shorter
+// head_dim 128, bf16 in / out, no mask, any S > 64.  The MMDiT product path (afx_attn.hip's 4-wave kernel stays for shorter
 // sequences and the text encoders' EXT variants; launch_attention dispatches).
 //
 // Same mathematics and operand layouts as attention_kernel (afx_attn.hip): both products transposed on v_mfma_f32_32x32x16_bf16,
@@ -69,6 +69,7 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 #define A3_INC(name) A3_STR(A3_GEN/name)
 #include A3_INC(a3_rescale.inc)
 #include A3_INC(a3_readout.inc)
+#include A3_INC(a3_mask.inc)
 
 // One tile = iteration t with ring slot J = t & 3 (gen/a3_body{J}.inc):
 //   phase A   MFMA: S_A^T(t+1) (16), O_A^T += V^T(t) P_A^T(t) (16)   VALU: softmax of S_B(t)     LDS: V^T(t) fragments | DMA K(t+4)
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
 #define A3_VOFF(i) ((uint32_t)(((int64_t)(dv_r + 32 * (i)) * S_pad + dv_c) * 2))
   const uint32_t koff0 = A3_KOFF(0), koff1 = A3_KOFF(1), koff2 = A3_KOFF(2), koff3 = A3_KOFF(3);
   const uint32_t voff0 = A3_VOFF(0), voff1 = A3_VOFF(1), voff2 = A3_VOFF(2), voff3 = A3_VOFF(3);
-  // Ragged S: the K rows of the LAST tile past the end are clamped to row S - 1 (finite data; their scores start from -inf, below),
+  // Ragged S: the K rows of the LAST tile past the end are clamped to row S - 1 (finite data; their scores get -inf added in front of the last tile's softmax streams: gen/a3_mask.inc, cold),
   // so the last tile's DMA pieces use their own per-lane offsets; tiles past the end re-fetch the last one.
   const int last0 = (ntiles - 1) * KVB;
 #define A3_KOFFL(i) ((uint32_t)(((int64_t)(min(last0 + dk_r + 16 * (i), S - 1) - last0) * ldk + dk_c) * 2))
@@ -130,20 +131,6 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) v
   const bool klast_ = (TILE) >= ntiles - 1;                                                                               \
   const uint32_t kofs0 = klast_ ? koffl0 : koff0, kofs1 = klast_ ? koffl1 : koff1, kofs2 = klast_ ? koffl2 : koff2,       \
                  kofs3 = klast_ ? koffl3 : koff3;
-  // Key mask = the C operand of the first k-step of every S^T tile: zeros, except for the ragged last tile where keys >= S start
-  // from -inf (their exp2 is 0: no weight, no row-sum contribution).  MFMA row r of key block kb = key (r&3) + 8 (r>>2) + 4 hi.
-  f32x16_t kmask0, kmask1;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) kmask0[r] = kmask1[r] = 0.f;
-#define A3_MASK_LAST(TILE)                                                                                                \
-  if (S != S_pad && (TILE) == ntiles - 1) {                                                                               \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                                      \
-      const int key_ = last0 + (r & 3) + 8 * (r >> 2) + 4 * hi;                                                           \
-      kmask0[r] = key_ >= S ? -INFINITY : 0.f;                                                                            \
-      kmask1[r] = key_ + 32 >= S ? -INFINITY : 0.f;                                                                       \
-    }                                                                                                                     \
-    asm volatile("s_nop 7" : "+v"(kmask0), "+v"(kmask1)); /* VALU write -> MFMA SrcC read wait states */                  \
-  }
   const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * S * ldk + h * 128);
   const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S_pad);
   const int64_t ktile_bytes = (int64_t)KVB * ldk * 2;

@@ -94,9 +94,21 @@ def asm(text, outs='', ins='', clob=''):
 def qk(sl, m):
     """MFMA m = 0..15 of S^T = K Q^T of slab sl: kb = m & 1, s = m >> 1."""
     kb, s = m & 1, m >> 1
-    if s == 0:      # the first k-step starts from the key mask of the tile (all zeros except in the ragged last tile: -inf past the end)
-        return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, %0', '', f'"v"(kmask{kb})')
-    return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, {S(sl, kb)}')
+    return asm(f'{MFMA} {S(sl, kb)}, {K(kb, s)}, {Q(sl, s)}, {0 if s == 0 else S(sl, kb)}')
+
+
+def mask_ops(sl):
+    """Ragged S, last tile only (cold): scores of the keys past the end -> -inf before the slab's softmax reads them.  Score register
+    i = 16 kb + r of a lane holds key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi of the tile (the MFMA D layout).  The K rows behind them are
+    clamped copies of row S - 1 (finite), V^T is zero there."""
+    lines = [f'#define A3_MASK_S{sl} \\']
+    for i in range(32):
+        kb, r = i >> 4, i & 15
+        key = 32 * kb + (r & 3) + 8 * (r >> 2)
+        lines.append(f'  {{ const float pen_ = last0 + {key} + 4 * hi >= S ? -INFINITY : 0.f; '
+                     f'asm volatile("v_add_f32 {Sx(sl, i)}, {Sx(sl, i)}, %0" : : "v"(pen_)); }} \\')
+    lines.append('  asm volatile("s_nop 1");')
+    return lines
 
 
 def pv(sl, m):
@@ -280,7 +292,7 @@ def body(J):
     out.append('A3_TR(4)')
     out.append(wait('s_barrier'))
     out.append('A3_TR(0)')
-    out.append('{ const uint64_t ksrc = k_src(t + 4), vsrc = v_src(t + 2); A3_KOFS(t + 4) A3_MASK_LAST(t + 1)')
+    out.append('{ const uint64_t ksrc = k_src(t + 4), vsrc = v_src(t + 2); A3_KOFS(t + 4)')
     # phase A: S_A(t+1), O_A += V(t) P_A(t) | softmax of S_B(t) | V(t) fragments, DMA K(t+4) -> slot J
     sm = softmax_ops(1)
     cnt = valu_counts(True)
@@ -306,6 +318,7 @@ def body(J):
     cnt = valu_counts(False)
     k = 0
     out.append('// ---- phase B')
+    out.append('if (__builtin_expect(S != S_pad && t + 2 == ntiles, 0)) { A3_MASK_S0 }')
     for m in range(32):
         if m < 16:
             out.append(qk(1, m))
@@ -327,6 +340,7 @@ def final():
     out = ['// generated by tools/gen_attn3.py -- last tile t = ntiles - 1 (runtime ring slot: vs = (t & 3) * 16384)']
     out.append(wait('s_waitcnt vmcnt(8) lgkmcnt(0)\\n\\ts_barrier', own=True))
     out += [read_v(i, 0, 'vs') for i in range(16)]
+    out.append('if (S != S_pad) { A3_MASK_S1 }')
     out += emit(softmax_ops(1))
     out.append(wait('s_waitcnt lgkmcnt(0)\\n\\ts_nop 3'))
     out += [pv(0, m) for m in range(16)]
@@ -369,7 +383,7 @@ def main():
     MERGE = a.merge
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'arcflow_amd', 'csrc', a.out)
     os.makedirs(root, exist_ok=True)
-    files = {'a3_init.inc': decl(), 'a3_qload.inc': q_loads(), 'a3_tile0.inc': tile0(), 'a3_final.inc': final(),
+    files = {'a3_init.inc': decl(), 'a3_mask.inc': mask_ops(0) + mask_ops(1), 'a3_qload.inc': q_loads(), 'a3_tile0.inc': tile0(), 'a3_final.inc': final(),
              'a3_rescale.inc': rescale(0) + rescale(1), 'a3_readout.inc': readout(), 'a3_prologue_dma.inc': prologue_dma()}
     for J in range(4):
         files[f'a3_body{J}.inc'] = body(J)

@@ -1,3 +1,4 @@
-cd $GRAFT_REPO_ROOT
-bash tools/profile_round.sh r03a > gpurun_out/r03a_profile_round.log 2>&1
-tail -30 gpurun_out/r03a_profile_round.log
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_production_shape.py -m gpu -q -k "attention" 2>&1 | tail -8
+timeout 200 python tools/attn_bench.py 2>&1 | tail -25
