@@ -35,9 +35,28 @@ def merge_lora(sd: Dict[str, Tensor], lora: Optional[Dict[str, Tensor]], scale: 
         if a is None or b is None or key not in out:
             raise KeyError(f'LoRA module {m}: missing lora_A/lora_B or base weight')
         w = out[key]
-        delta = (b.to(w.device, torch.float32) @ a.to(w.device, torch.float32)) * scale
-        out[m + '.weight'] = (w.float() + delta).to(w.dtype)
+        out[m + '.weight'] = _merge_one(w, a, b, scale)
     return out
+
+
+def _merge_one(w: Tensor, a: Tensor, b: Tensor, scale: float) -> Tensor:
+    """W + scale * B A, accumulated in fp32, rounded once.  On the GPU this is the library's own fp32-accumulating GEMM
+    (`afx_linear_bf16_f32out`, C += B . (A^T)^T with the rank as the contraction, zero-padded to the kernel's K granule); the
+    host branch only serves weights that are packed on a machine without a device (the CPU tests)."""
+    if not (w.is_cuda or (torch.cuda.is_available() and a.is_cuda)):
+        delta = (b.to(torch.float32) @ a.to(torch.float32)) * scale
+        return (w.float() + delta).to(w.dtype)
+    from . import ops
+    dev = w.device if w.is_cuda else a.device
+    r = a.shape[0]
+    rp = (r + 63) // 64 * 64
+    bb = torch.zeros(b.shape[0], rp, dtype=torch.bfloat16, device=dev)
+    bb[:, :r] = (b.to(dev, torch.float32) * scale).to(torch.bfloat16)
+    at = torch.zeros(a.shape[1], rp, dtype=torch.bfloat16, device=dev)
+    at[:, :r] = a.to(dev, torch.bfloat16).t()
+    acc = w.to(dev, torch.float32).contiguous()
+    ops.linear_f32out(bb, at, out=acc, accumulate=True)
+    return acc.to(w.dtype).to(w.device)
 
 
 def _bf16(t: Tensor, device) -> Tensor:

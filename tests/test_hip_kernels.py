@@ -452,3 +452,21 @@ def test_linear_stream_k_gate_residual_inplace(ops):
     from arcflow_amd import _lib
     assert _lib.load().afx_linear_sk_last_split() > 0
     assert rel_l2(out, ref) < 4e-3
+
+
+
+@pytest.mark.parametrize('out_f,in_f,r', [(384, 256, 32), (3072, 3072, 256), (200, 136, 8)])
+def test_lora_merge_runs_on_the_library_gemm(out_f, in_f, r):
+    """Load-time LoRA fold W + B A (arcflow_amd/weights.py, reference: arcflux.py:295-301 keeps the side GEMMs) goes through
+    afx_linear_bf16_f32out on the device -- compared with the fp32 host product of the same bf16 adapters."""
+    from arcflow_amd.weights import merge_lora
+    g = torch.Generator().manual_seed(out_f + r)
+    w = (torch.randn(out_f, in_f, generator=g) * 0.05).bfloat16()
+    a = (torch.randn(r, in_f, generator=g) * 0.1).bfloat16()
+    b = (torch.randn(out_f, r, generator=g) * 0.1).bfloat16()
+    ref = (w.float() + b.float() @ a.float()).bfloat16()
+    got = merge_lora({'m.weight': w.cuda()}, {'m.lora_A.weight': a.cuda(), 'm.lora_B.weight': b.cuda()})['m.weight']
+    assert got.is_cuda and got.dtype == torch.bfloat16
+    d = (got.cpu().float() - ref.float()).abs()
+    # fp32 accumulation order differs: at most one bf16 ulp on a few entries
+    assert d.max() <= 2.0 ** -7 * ref.float().abs().max() and (d > 0).float().mean() < 0.01
