@@ -86,11 +86,121 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
   }
 }
 
+// LayerNorm + modulate for D = 512 * NCH (3072: both model families), R consecutive rows per wave.  The one-row kernel above reads 8 bytes of
+// modulation vector (scale + shift, fp32) for every 2 bytes of x it normalises -- out of L1 / L2, but through the same 64 B/clk address path; here a
+// lane keeps (1 + scale, shift) of its NCH chunks in registers across the wave's rows and reloads them only when the (sample, stream) of a row
+// differs from the previous one's.  The next row's chunks are requested before the current one is reduced.  Same arithmetic, same order: bit-identical.
+template <int NCH, int R>
+__global__ __launch_bounds__(256) void norm_modulate_rows_kernel(
+    const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int rows,
+    const float* __restrict__ scale, const float* __restrict__ shift, int64_t ldmod, int rows_per_batch,
+    const float* __restrict__ scale_txt, const float* __restrict__ shift_txt, int n_txt) {
+  constexpr int D = 512 * NCH;
+  const int lane = threadIdx.x & 63;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= rows) return;
+  const int nrows = min(R, rows - row0);
+  float sc[NCH][8], sh[NCH][8];
+  int key = -1;
+  u32x4_t cur[NCH], nxt[NCH];
+  {
+    const bf16_t* xr = x + (int64_t)row0 * ldx;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) cur[i] = *reinterpret_cast<const u32x4_t*>(xr + (lane + i * 64) * 8);
+  }
+#pragma unroll 1
+  for (int rr = 0; rr < nrows; ++rr) {
+    const int row = row0 + rr;
+    if (rr + 1 < nrows) {
+      const bf16_t* xn = x + (int64_t)(row + 1) * ldx;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) nxt[i] = *reinterpret_cast<const u32x4_t*>(xn + (lane + i * 64) * 8);
+    }
+    const int b = row / rows_per_batch;
+    const bool txt = scale_txt != nullptr && row - b * rows_per_batch < n_txt;
+    const int k = 2 * b + (txt ? 1 : 0);
+    if (k != key) {                                              // wave-uniform
+      key = k;
+      const float* sp = (txt ? scale_txt : scale) + (int64_t)b * ldmod;
+      const float* hp = (txt ? shift_txt : shift) + (int64_t)b * ldmod;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        const int c = (lane + i * 64) * 8;
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(sp + c), s1 = *reinterpret_cast<const f32x4_t*>(sp + c + 4);
+        const f32x4_t h0 = *reinterpret_cast<const f32x4_t*>(hp + c), h1 = *reinterpret_cast<const f32x4_t*>(hp + c + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sc[i][e] = 1.0f + s0[e]; sc[i][4 + e] = 1.0f + s1[e];
+          sh[i][e] = h0[e];        sh[i][4 + e] = h1[e];
+        }
+      }
+    }
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      unpack8(cur[i], v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+    s = wave_sum(s);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    q = wave_sum(q);
+    const float rstd = rsqrtf(q / (float)D + 1e-6f);
+    bf16_t* orow = out + (int64_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (v[i][e] - mean) * rstd * sc[i][e] + sh[i][e];
+      *reinterpret_cast<u32x4_t*>(orow + (lane + i * 64) * 8) = pack8(r);
+    }
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) cur[i] = nxt[i];
+  }
+}
+
+static int nm_rows_per_wave() {
+  static int r = -1;
+  if (r < 0) {
+    const char* e = getenv("AFX_NM_ROWS");
+    r = e ? atoi(e) : 2;            // 2 rows per wave: 16.4 -> 14.5 us at 4608 x 3072 (4: 15.1; 0 = the one-row kernel)
+  }
+  return r;
+}
+
+// true when the multi-row kernel took the launch
+static bool launch_norm_modulate_rows(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
+                                      const float* shift, int64_t ldmod, int rows_per_batch, const float* scale_txt, const float* shift_txt,
+                                      int n_txt, hipStream_t stream) {
+  const int R = nm_rows_per_wave();
+  if (D != 3072 || rows < 1024 || (R != 2 && R != 4)) return false;
+  const dim3 grid((rows + 4 * R - 1) / (4 * R));
+  if (R == 2)
+    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+                       scale_txt, shift_txt, n_txt);
+  else
+    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 4>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+                       scale_txt, shift_txt, n_txt);
+  return true;
+}
+
 hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,
                                 int D, const float* scale, const float* shift, int64_t ldmod,
                                 int rows_per_batch, int rms, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   if (D > NM_MAX_CHUNKS * 512 || (D & 7)) return hipErrorInvalidValue;
+  if (!rms && launch_norm_modulate_rows(x, ldx, out, ldo, rows, D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, nullptr, nullptr, 0,
+                                        stream))
+    return hipGetLastError();
   hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows,
                      D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, rms, (const float*)nullptr,
                      (const float*)nullptr, 0);
@@ -104,6 +214,7 @@ hipError_t launch_norm_modulate_joint(const uint16_t* x, int64_t ldx, uint16_t* 
                                       int n_txt, hipStream_t stream) {
   if (rows <= 0) return hipSuccess;
   if (D > NM_MAX_CHUNKS * 512 || (D & 7) || S <= 0) return hipErrorInvalidValue;
+  if (launch_norm_modulate_rows(x, ldx, out, ldo, rows, D, scale, shift, ldmod, S, scale_txt, shift_txt, n_txt, stream)) return hipGetLastError();
   hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows, D, scale, shift, ldmod,
                      S, 0, scale_txt, shift_txt, n_txt);
   return hipGetLastError();

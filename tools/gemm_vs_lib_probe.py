@@ -10,6 +10,8 @@ from arcflow_amd import ops  # noqa: E402
 
 shapes = [(8192, 8192, 8192), (4608, 21504, 3072), (4608, 3072, 15360)]
 n = int(os.environ.get('N', '12'))
+if os.environ.get('SHAPE'):
+    shapes = [shapes[int(os.environ['SHAPE'])]]
 for M, N, K in shapes:
     a = torch.randn(M, K, device='cuda').bfloat16()
     w = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()

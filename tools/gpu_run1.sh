@@ -1,9 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-echo "shapes: 9216x3072 3072x3072 12288x3072 3072x12288 21504x3072 3072x15360 8192^3  (N x K, M = 4608)"
-for rep in 1 2; do
-for lib in "" _nt _stg_tm2 _stg_tn2 _stg_wg _stg_tm8; do
-  printf "%-10s " "base$lib"; ARCFLOW_HIP_LIB=$PWD/arcflow_amd/lib/libarcflow_hip$lib.so timeout 200 python tools/gemm_shapes_time.py 2>&1 | tail -1
-done
-printf "%-10s " "hipblaslt"; TORCH=1 timeout 200 python tools/gemm_shapes_time.py 2>&1 | tail -1
-done
+timeout 600 python -m pytest tests/test_hip_kernels.py tests/test_hip_engine.py tests/test_production_shape.py -m gpu -q -x -k "norm or forward or engine" 2>&1 | tail -4
+for r in 0 2 4 0 2 4; do echo "AFX_NM_ROWS=$r"; AFX_NM_ROWS=$r timeout 200 python tools/microbench.py elem 2>&1 | grep norm_modulate; done
+for r in 0 4 2 0 4 2; do echo "AFX_NM_ROWS=$r"; AFX_NM_ROWS=$r timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python tools/bench_brief.py; done
