@@ -93,7 +93,9 @@ def distill_setup(cfg: Dict[str, Any]) -> Tuple[str, Dict[str, Any], DistillConf
         grad_clip=tc.get('diffusion_grad_clip', 0.0), grad_clip_begin_iter=tc.get('diffusion_grad_clip_begin_iter', 0),
         ema_gamma=ema.get('momentum_cfg', {}).get('gamma', 7.0), ema_start_iter=ema.get('start_iter', 0),
         lora_rank=den.get('lora_rank', 0) if den.get('use_lora', False) else 0,
-        lora_dropout=den.get('lora_dropout', 0.0) if den.get('use_lora', False) else 0.0)
+        lora_dropout=den.get('lora_dropout', 0.0) if den.get('use_lora', False) else 0.0,
+        # not in the reference's configs (it has no fp8 path): train_cfg.teacher_fp8 / student_fp8, e.g. --cfg-options train_cfg.student_fp8=True
+        teacher_fp8=bool(tc.get('teacher_fp8', False)), student_fp8=bool(tc.get('student_fp8', False)))
     runner = cfg.get('runner', {})
     ck = cfg.get('checkpoint_config', {})
     run = dict(name=cfg.get('name', 'arcflow'), total_iters=cfg.get('total_iters', 10000),

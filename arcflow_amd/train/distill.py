@@ -65,6 +65,8 @@ class DistillConfig:
     lora_rank: int = 0                    # 0: train heads + norm_out only; 256 in the reference configs
     lora_dropout: float = 0.0             # peft lora_dropout on the adapters' input (0.05 in the reference configs)
     teacher_fp8: bool = False             # BASELINE.json configs[4]: frozen teacher forwards on the fp8 MFMA (student + grads stay bf16)
+    student_fp8: bool = False             # configs[4] "fp8 MFMA fwd + bf16 grads": the student's block linears run their forward (and the
+                                          # backward's recompute) on the fp8 MFMA, dgrad / LoRA gradients stay bf16 (train/trunk.py enable_fp8)
 
 
 def warp(t: torch.Tensor, shift: float) -> torch.Tensor:
@@ -143,6 +145,11 @@ class ArcFlowDistiller:
                                    generator=torch.Generator(device=self.device).manual_seed(init_seed))
             self.ema[self._off[4]:].copy_(self.params[self._off[4]:])
         self.student.bind_packed(packed)
+        if cfg.student_fp8:
+            if self.trunk is not None:
+                self.trunk.enable_fp8(shared=self.teacher._weights if cfg.teacher_fp8 else None)
+            else:
+                self.student.enable_fp8()
         self._ckpt = None
         self.reducer = GradReducer(process_group)
         self.sync_module_states()

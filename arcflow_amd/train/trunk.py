@@ -106,6 +106,8 @@ class LoraTrunk:
         self.seed = 0
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
         self._ones: Dict[int, torch.Tensor] = {}
+        self.fp8 = False            # block linears' forward / recompute on the fp8 MFMA (enable_fp8)
+        self.wq: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}     # packed key -> (e4m3 [out, in], row scales fp32 [out])
         self._build_frozen_transposes()
         self.refresh()
 
@@ -149,6 +151,46 @@ class LoraTrunk:
                 ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=self.base[key][rows], rows_per_batch=sp.out_f,
                            out=w[rows])                          # W' = W + B A  (fp32 accumulate, one rounding)
             self.wt[key] = ops.transpose(w)
+            if self.fp8:
+                self.wq[key] = ops.quant_rows_fp8(w)
+
+    # ------------------------------------------------------------------ fp8 forward (BASELINE.json configs[4]: "fp8 MFMA fwd + bf16 grads")
+    def _linear_keys(self) -> List[str]:
+        keys = [f'd{i}.{s}_{n}' for i in range(self.nd) for s in ('img', 'txt') for n in ('qkv', 'out', 'mlp1', 'mlp2')]
+        return keys + [f's{i}.{n}' for i in range(self.ns) for n in ('fused', 'out')]
+
+    def enable_fp8(self, shared: Optional[Dict[str, torch.Tensor]] = None) -> None:
+        """Run every block linear of the student's FORWARD (and of the backward's recompute, which must reproduce it) as
+        y = s_a[m] s_w[n] (e4m3(x) . e4m3(W')^T) on the fp8 MFMA: activations quantised per token right before each GEMM, the merged
+        weights W' = W + B A per output row -- the adapted ones again after every optimizer step (refresh()).  The BACKWARD is
+        unchanged: dgrad on the bf16 W'^T, LoRA gradients from the bf16 activations (straight-through: the quantiser has no
+        gradient of its own).  shared: a weight dict that already holds '<key>.weight_q' / '<key>.wscale' of the FROZEN linears
+        (the teacher engine after enable_fp8()) -- reused instead of a second copy."""
+        self.fp8 = True
+        for key in self._linear_keys():
+            if key in self.by_key or shared is None or key + '.weight_q' not in shared:
+                self.wq[key] = ops.quant_rows_fp8(self.packed[key + '.weight'])
+            else:
+                self.wq[key] = (shared[key + '.weight_q'], shared[key + '.wscale'])
+
+    def _lin(self, x: torch.Tensor, key: str, rows: Optional[slice] = None, out: Optional[torch.Tensor] = None,
+             pre: Optional[torch.Tensor] = None, xq=None, **kw) -> torch.Tensor:
+        """x [M, K] @ packed[key].weight[rows].T + bias[rows] (+ pre) through the bf16 or the fp8 GEMM.  xq: (q, scale) of x when
+        the caller already quantised it for another linear."""
+        w, b = self.packed[key + '.weight'], self.packed[key + '.bias']
+        if rows is not None:
+            w, b = w[rows], b[rows]
+        if not self.fp8:
+            return ops.linear(x, w, b, out=out, pre=pre, **kw)
+        q, sc = self.wq[key]
+        if rows is not None:
+            q, sc = q[rows], sc[rows]
+        aq, asc = xq if xq is not None else ops.quant_rows_fp8(x)
+        y = ops.linear_fp8(aq, asc, q, sc, b, out=out, **kw)
+        if pre is not None:                                      # the fp8 kernel has no pre-add input: one more pass, same value up to a rounding
+            assert kw.get('epilogue', 'none') == 'none'
+            ops.add_scale(y, b=pre, out=y)
+        return y
 
     def block_slice(self, block: int) -> Tuple[int, int]:
         """[a, b) of the flat parameter / gradient buffer holding the adapters of transformer block ``block``
@@ -278,7 +320,7 @@ class LoraTrunk:
         QKVp = torch.empty(S, 3 * D, **bf)                       # pre-norm k | v | q
         for s, rows, _ in self._streams(T, S):
             ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
-            ops.linear(Xn1[rows], pk[p + s + '_qkv.weight'], pk[p + s + '_qkv.bias'], out=QKVp[rows])
+            self._lin(Xn1[rows], p + s + '_qkv', out=QKVp[rows])
         Kp, V, Qp = QKVp[:, :D], QKVp[:, D:2 * D], QKVp[:, 2 * D:]
         K, Q, O = torch.empty(S, D, **bf), torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         self._rope(Kp, K, qkn[3], qkn[1], cos, sin, S, T)
@@ -291,18 +333,16 @@ class LoraTrunk:
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
             if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
                 y1 = self.ybuf[2 * i, self.row0:self.row0 + S][rows]
-                ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], out=y1)
+                self._lin(O[rows], p + s + '_out', out=y1)
                 ops.gate_residual(y1, mv[(s, 2)], X[rows], out=X1[rows])
             else:
-                ops.linear(O[rows], pk[p + s + '_out.weight'], pk[p + s + '_out.bias'], epilogue='gate_res', gate=mv[(s, 2)],
-                           residual=X[rows], out=X1[rows])
+                self._lin(O[rows], p + s + '_out', epilogue='gate_res', gate=mv[(s, 2)], residual=X[rows], out=X1[rows])
             ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-            ops.linear(Xn2[rows], pk[p + s + '_mlp1.weight'], pk[p + s + '_mlp1.bias'], out=Pre[rows],
-                       pre=self._corr(sp1, Xn2[rows], rows.start))
+            self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows], pre=self._corr(sp1, Xn2[rows], rows.start))
             ops.gelu(Pre[rows], out=Hh[rows])
             if fwd_only:
                 y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows]
-                ops.linear(Hh[rows], pk[p + s + '_mlp2.weight'], pk[p + s + '_mlp2.bias'], out=y2, pre=self._corr(sp2, Hh[rows], rows.start))
+                self._lin(Hh[rows], p + s + '_mlp2', out=y2, pre=self._corr(sp2, Hh[rows], rows.start))
                 ops.gate_residual(y2, mv[(s, 5)], X1[rows], out=Xo[rows])
         if fwd_only:
             return Xo
@@ -354,12 +394,12 @@ class LoraTrunk:
         Xn = ops.norm_modulate(X, sc, sh)
         corr = self._corr(sp_mlp, Xn, 0)
         if corr is None:
-            Fp = ops.linear(Xn, pk[p + 'fused.weight'], pk[p + 'fused.bias'])      # [S, 7D] pre-activation k|v|q|mlp
+            Fp = self._lin(Xn, p + 'fused')                      # [S, 7D] pre-activation k|v|q|mlp
         else:                                                    # the correction only touches the proj_mlp columns
             Fp = torch.empty(S, 7 * D, **bf)
-            w, bias = pk[p + 'fused.weight'], pk[p + 'fused.bias']
-            ops.linear(Xn, w[:3 * D], bias[:3 * D], out=Fp[:, :3 * D])
-            ops.linear(Xn, w[3 * D:], bias[3 * D:], out=Fp[:, 3 * D:], pre=corr)
+            xq = ops.quant_rows_fp8(Xn) if self.fp8 else None
+            self._lin(Xn, p + 'fused', rows=slice(0, 3 * D), out=Fp[:, :3 * D], xq=xq)
+            self._lin(Xn, p + 'fused', rows=slice(3 * D, 7 * D), out=Fp[:, 3 * D:], pre=corr, xq=xq)
         Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         G = torch.empty(S, 5 * D, **bf)                          # [O | gelu(mlp)] = proj_out operand
@@ -369,7 +409,7 @@ class LoraTrunk:
         ops.gelu(Mp, out=G[:, D:])
         if fwd_only:
             y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S]
-            ops.linear(G, pk[p + 'out.weight'], pk[p + 'out.bias'], out=y, pre=self._corr(sp_out, G, 0))
+            self._lin(G, p + 'out', out=y, pre=self._corr(sp_out, G, 0))
             return ops.gate_residual(y, gt, X)
         # ---- backward ----
         dY = ops.add_scale(dXo, gate=gt)

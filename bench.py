@@ -147,7 +147,7 @@ def train_main(args, rank, world, dev, dist):
     packed['norm_out.bias'] = packed['mod.bias'][-2 * D:].clone()
     # configs/flux/arcflux_2nfe_k16.py / configs/qwen/arcqwen_2nfe_k16.py: rank-256 LoRA, lora_dropout 0.05; Qwen: true-CFG
     # teacher (scale 4.0, negative prompt), decay 1000
-    kw = dict(lora_rank=256, lora_dropout=0.05, teacher_fp8=args.teacher_fp8)
+    kw = dict(lora_rank=256, lora_dropout=0.05, teacher_fp8=args.teacher_fp8, student_fp8=args.student_fp8)
     dc = DistillConfig(**kw) if flux else DistillConfig(teacher_guidance_scale=4.0, num_decay_iters=1000, **kw)
     eng = dict(num_double=nd, num_single=ns) if flux else dict(num_double=nd, joint_dim=joint)
     ds = ArcFlowDistiller(args.model, eng, None, dc, device=dev, packed=packed)
@@ -189,7 +189,10 @@ def train_main(args, rank, world, dev, dist):
                       f'trajectory matching, 2 student steps x 4 teacher states, LoRA r=256 + heads + norm_out trainable)',
             'value': sps, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'bf16 student + gradients, fp8 e4m3 frozen-teacher linears (configs[4])' if args.teacher_fp8 else 'bf16 (fp32 master weights / gradients / AdamW moments)',
+            'dtype': ('fp8 e4m3 forward linears (teacher + student forward / recompute), bf16 gradients (configs[4])' if args.teacher_fp8 and args.student_fp8
+                      else 'bf16 gradients and teacher, fp8 e4m3 student forward linears' if args.student_fp8
+                      else 'bf16 student + gradients, fp8 e4m3 frozen-teacher linears (configs[4])' if args.teacher_fp8
+                      else 'bf16 (fp32 master weights / gradients / AdamW moments)'),
             'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt embeddings, data-free noise latents)',
             'config': {'workload': ('ArcFlow-FLUX distillation training (train_flux.sh), LoRA adapters' if flux else
                                     'ArcFlow-Qwen-20B distillation training (train_qwen.sh), true-CFG teacher'),
@@ -216,6 +219,7 @@ def parse_args(argv=None):
     ap.add_argument('--model', default='flux', choices=['flux', 'qwen'])
     ap.add_argument('--train', action='store_true', help='time the distillation iteration (configs[3] flux / configs[4] qwen) instead of inference')
     ap.add_argument('--batch', type=int, default=None, help='--train: samples per GPU (default: 4 flux, 2 qwen, the reference configs)')
+    ap.add_argument('--student-fp8', action='store_true', help='--train: the student forward / recompute linears on the fp8 MFMA, gradients bf16 (configs[4]); says so in dtype')
     ap.add_argument('--teacher-fp8', action='store_true', help='--train: frozen teacher forwards on the fp8 MFMA (configs[4]); the line says so in dtype')
     ap.add_argument('--streams', type=int, default=1, help='images in flight per GPU (one HIP stream + engine context each, shared weights); '
                                                            '1 = the canonical line, 2 fills the under-filled last rounds: +3.8 % (r02)')
@@ -296,7 +300,7 @@ def main(argv=None):
                                               'roofline', 'roofline_attention') if k in q}
             gc.collect()
             torch.cuda.empty_cache()
-            ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8 = 1, 1, 'flux', None, False
+            ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8, ex.student_fp8 = 1, 1, 'flux', None, False, False
             t = train_main(ex, rank, world, dev, dist)
             line['train_flux'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
                                                     'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}

@@ -674,3 +674,84 @@ def test_lora_dropout_train_step_matches_cpu_autograd():
     dist2.iteration = 1
     info2 = dist2.train_step(cond, B, x_init=x0.cuda(), draws=draws)
     assert abs(info2['loss'] - info['loss']) > 1e-4 * abs(info['loss'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('family', ['flux', 'qwen'])
+def test_student_fp8_forward_bf16_grads_step(family):
+    """BASELINE.json configs[4] "fp8 MFMA fwd + bf16 grads" on the STUDENT: ``DistillConfig.student_fp8`` runs the block linears of the
+    student forward and of the backward's recompute as e4m3 x e4m3 GEMMs (activations quantised per token, merged weights W + B A per
+    output row, re-quantised after every optimizer step); dgrad and the LoRA gradients stay bf16 on the bf16 weights.  flux: with LoRA
+    dropout (the reference config); qwen: together with the true-CFG fp8 teacher (configs[4] with every forward on fp8).
+    Stated tolerance against the all-bf16 step on the same draws: loss within 8 %, flat gradient within 0.35 rel-L2 and cosine > 0.94
+    (each e4m3 GEMM carries ~4e-2 of noise, which the K = 16 mixture heads and the CFG scale amplify), next state within 5e-2."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from oracle import dit_ref as D
+    g = torch.Generator().manual_seed(31)
+    r = 64
+    if family == 'flux':
+        cfg, w = _setup()
+        B, hp, wp, T = 2, 8, 8, 64
+        pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+        pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+        cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+        arch = dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64)
+        extra = dict(lora_dropout=0.05)
+    else:
+        cfg = D.QwenCfg(num_layers=2, heads=2, joint_dim=192)
+        w = D.make_qwen_weights(cfg, seed=21)
+        w['proj_out.weight'] = (torch.randn(64, 256, generator=g) * 0.05).bfloat16()
+        w['proj_out.bias'] = (torch.randn(64, generator=g) * 0.02).bfloat16()
+        B, hp, wp, T = 1, 8, 8, 64
+        pe = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+        ne = (torch.randn(B, T, 192, generator=g) * 0.5).bfloat16()
+        cond = dict(prompt_embeds=pe.cuda(), negative_prompt_embeds=ne.cuda(), hp=hp, wp=wp)
+        arch = dict(num_double=2, heads=2, joint_dim=192)
+        extra = dict(teacher_guidance_scale=4.0, teacher_fp8=True)
+    x0 = torch.randn(B, hp * wp, 64, generator=g)
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    Bs, res = None, {}
+    for fp8 in (False, True):
+        dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r, student_fp8=fp8, **extra)
+        dist = ArcFlowDistiller(family, arch, w, dc)
+        tr = dist.trunk
+        assert tr.fp8 == fp8
+        if Bs is None:
+            Bs = {sp.name: (torch.randn(sp.out_f, r, generator=g) * 0.02) for sp in tr.specs}
+        for sp in tr.specs:
+            tr.B(sp).copy_(Bs[sp.name].cuda())
+        tr.refresh()
+        if fp8:     # the adapted weights were re-quantised from the merged copies; frozen ones come from the fp8 teacher when it has them
+            key = tr.specs[0].packed_key
+            q, sc = tr.wq[key]
+            wm = tr.packed[key + '.weight'].float()
+            deq = _e4m3_to_float(q) * sc[:, None]
+            assert ((deq - wm).norm() / wm.norm()).item() < 4e-2
+            if family == 'qwen':
+                assert tr.wq['d0.img_qkv'][0].data_ptr() == dist.teacher._weights['d0.img_qkv.weight_q'].data_ptr()
+        dist.iteration = 2
+        info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+        assert not info['skipped']
+        res[fp8] = (info['loss'], dist.grads[0].clone(), dist.last_x.clone())
+        # the optimizer step re-merged and re-quantised the adapted weights
+        if fp8:
+            q2, sc2 = tr.wq[key]
+            wm2 = tr.packed[key + '.weight'].float()
+            assert ((_e4m3_to_float(q2) * sc2[:, None] - wm2).norm() / wm2.norm()).item() < 4e-2
+    (l16, g16, x16), (l8, g8, x8) = res[False], res[True]
+    assert l8 != l16                                                     # the fp8 path really ran
+    assert abs(l8 - l16) < 8e-2 * abs(l16), (l8, l16)
+    rel = ((g8 - g16).norm() / g16.norm()).item()
+    cos = (torch.dot(g8, g16) / (g8.norm() * g16.norm())).item()
+    assert rel < 0.35 and cos > 0.94, (rel, cos)
+    assert ((x8 - x16).norm() / x16.norm()).item() < 5e-2
+
+
+def _e4m3_to_float(q):
+    """OCP e4m3 (uint8) -> fp32 (bias 7, no infinities, 0x7f / 0xff = NaN)."""
+    q = q.to(torch.int32)
+    s = torch.where((q & 0x80) != 0, -1.0, 1.0)
+    e = (q >> 3) & 0xF
+    m = (q & 7).float()
+    v = torch.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * torch.pow(2.0, (e - 7).float()))
+    return (s * v).to(torch.float32)

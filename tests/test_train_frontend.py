@@ -84,6 +84,10 @@ def test_config_reader_merges_bases_and_maps_to_distill_config(tmp_path):
     assert run['resume_from'] == 'checkpoints/exp_k16/latest.pth' and run['lora_dropout'] == 0.05
     cfg2 = CFG.apply_options(cfg, {'train_cfg.nfe': 4, 'total_iters': 10})
     assert cfg2['train_cfg']['nfe'] == 4 and cfg2['train_cfg']['gm_dropout'] == 0.1 and cfg2['total_iters'] == 10
+    # the fp8 forward options (BASELINE.json configs[4]; no key of the reference's configs): off by default, --cfg-options turns them on
+    assert not dc.teacher_fp8 and not dc.student_fp8
+    dc3 = CFG.distill_setup(CFG.apply_options(cfg, {'train_cfg.teacher_fp8': True, 'train_cfg.student_fp8': True}))[2]
+    assert dc3.teacher_fp8 and dc3.student_fp8
 
 
 @pytest.mark.skipif(not os.path.isdir('/root/reference/configs'), reason='reference tree not present')
