@@ -1,3 +1,6 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_distill.py -m gpu -q -x 2>&1 | tail -15
+for f in "--model qwen --teacher-fp8" "--model qwen --teacher-fp8 --student-fp8" "" "--student-fp8 --teacher-fp8"; do
+  echo "== $f"
+  timeout 900 python bench.py --train $f --steps 2 --warmup 1 2>gpurun_out/err.log | python tools/bench_brief.py || tail -5 gpurun_out/err.log
+done
