@@ -1142,7 +1142,7 @@ AFX_DEV uint64_t v3_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit valu
 constexpr int V3_THREADS = 256;
 constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (32 * NJ) * 128; }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool CONV = false>
 __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_kernel_v3(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ;
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
@@ -1172,6 +1172,17 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   const int tn = in_grp / gsz;
   const int m0 = tm * TM, n0 = tn * TN;
   const int nk = P.K / BK;
+  // CONV (the VAE decoders' 3x3 convolutions, afx_vae.hip): implicit GEMM on a zero-bordered NHWC grid -- K-tile t = (tap, 64-channel chunk)
+  // reads the SAME pixel rows shifted by dy * row pitch + dx, so the A stream's K offset becomes a (uniform) row shift + channel offset.
+  const float inv_ct = CONV ? 1.0f / (float)P.conv_cin_tiles : 0.f;
+  auto ka = [&](int t) -> int64_t {
+    if constexpr (!CONV) return (int64_t)t * (BK * 2);
+    const int ct = P.conv_cin_tiles;
+    const int tap = (int)(((float)t + 0.5f) * inv_ct);            // t / ct for t < 9 ct <= 72
+    const int cc = t - tap * ct;
+    const int ty = (tap * 11) >> 5;                               // tap / 3
+    return ((int64_t)((ty - 1) * P.conv_wp + (tap - 3 * ty - 1)) * P.lda + cc * BK) * 2;
+  };
 
   // per-lane byte offsets of this lane's chunks of an A tile (MI pieces of 32 rows) / a W tile (NJ pieces), k = 0
   const int prow = tid >> 3;                                       // + 32 i
@@ -1198,7 +1209,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   const char* wbase = reinterpret_cast<const char*>(P.W);
   auto stage_a = [&](int t) {
     t = t < nk ? t : nk - 1;
-    const char* src = abase + (int64_t)t * (BK * 2);
+    const char* src = abase + ka(t);
     char* dst = smem + (t & 1) * A_SLOT;
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -1298,7 +1309,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     AFX_TR(3)
     // ---- k-half 1 multiplies; DMA of A(t+2) -> slot t & 1 and the k-half-0 fragments of tile t+1 ---------------------------
     {
-      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + (int64_t)(t + 2) * (BK * 2)));
+      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + ka(t + 2)));
       char* adst = smem + (t & 1) * A_SLOT;
       const char* na = smem + ((t + 1) & 1) * A_SLOT;
       const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
@@ -1335,6 +1346,10 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #ifndef V3_EPI_SWAP
 #define V3_EPI_SWAP 1
 #endif
+    if constexpr (CONV) {      // bias (+ residual) + re-zeroing of the border pixels: the output grid is the next layer's padded input
+      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+    } else
     epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
 #ifdef AFX_GEMM_TRACE
     AFX_TRC(21)
@@ -1399,20 +1414,20 @@ static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   return total;
 }
 
-template <int MI, int NJ>
+template <int MI, int NJ, bool CONV = false>
 static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        v3_lds_bytes(MI, NJ));
     if (r != hipSuccess) return r;
     attr = true;
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
-    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
+    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
                           launch_timer().stop, 0, batch);
   else
-    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
+    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
   return hipGetLastError();
 }
 
@@ -1455,6 +1470,18 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     const GemmProblem& p = batch.p[i];
     const bool bf16_out = p.out_f32 == 0, f32_out = (p.out_f32 == 1 || p.out_f32 == 2) && p.epi == EPI_NONE;     // (3 = split-K slabs: 8-phase)
     v3_ok = v3_ok && (bf16_out || f32_out) && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
+  }
+  // ---- the VAE decoders' 3x3 convolutions: the same kernel with the implicit-GEMM address stream and the border-zeroing epilogue;
+  // 256x128 tiles for the <= 128-channel layers (the full-resolution stage and conv_out, half of a 256-wide tile otherwise)
+  if (impl == 3 && batch.nprob == 1 && batch.p[0].conv_cin_tiles > 0 && batch.p[0].conv_wp > 0 && batch.p[0].out_f32 == 0 &&
+      batch.p[0].fp8 == 0 && batch.p[0].pre == nullptr && batch.p[0].epi != EPI_GELU && batch.p[0].split_k <= 1 && tile_env == 0) {
+    const bool narrow = batch.p[0].N <= 128;
+    const int total = count_tiles(batch, 256, narrow ? 128 : 256, true);
+    batch.total_tiles = total;
+    if (total == 0) return hipSuccess;
+    batch.group_m = group_m_env ? group_m_env : GROUP_M;
+    batch.sk_cus = 0;
+    return narrow ? launch_v3<8, 4, true>(batch, total, stream) : launch_v3<8, 8, true>(batch, total, stream);
   }
   bool qk = false;
   for (int i = 0; i < batch.nprob; ++i) {
