@@ -283,6 +283,11 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     single = b_first == b_last;
     fetch_gate(b_first, g1);
   }
+  float gsum[CONV ? NS : 1][2], gsq[CONV ? NS : 1][2];        // CONV + gn_stats: this lane's share of the output's GroupNorm sums
+  if constexpr (CONV) {
+#pragma unroll
+    for (int st = 0; st < NS; ++st) gsum[st][0] = gsum[st][1] = gsq[st][0] = gsq[st][1] = 0.f;
+  }
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
@@ -292,7 +297,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       int yy = (int)((float)grow * (1.0f / (float)wp));           // grow / wp up to +-1: fix up exactly
       int xx = grow - yy * wp;
       if (xx < 0) { xx += wp; --yy; } else if (xx >= wp) { xx -= wp; ++yy; }
-      border = yy == 0 || yy == P.conv_hp - 1 || xx == 0 || xx == wp - 1;
+      border = yy <= 0 || yy >= P.conv_hp - 1 || xx == 0 || xx == wp - 1;        // (rows past the grid count as border: nothing of them is kept)
     }
     float rb = 0.f;                                               // ROWB: bias[row] (the transposed V projection)
     if constexpr (ROWB) {
@@ -359,6 +364,13 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       if constexpr (CONV) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = border ? 0.f : v[e];
+        if constexpr (SWAP) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            gsum[st][e >> 2] += v[e];
+            gsq[st][e >> 2] += v[e] * v[e];
+          }
+        }
       }
       if constexpr (SWAP) {
         float v8[8];
@@ -368,6 +380,36 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       } else {
         const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         __builtin_amdgcn_raw_buffer_store_b64(o, rc, (int)(roff + coff[st]), 0, 0);
+      }
+    }
+  }
+  if constexpr (CONV && SWAP) {
+    if (P.gn_stats != nullptr) {                                  // (uniform)
+      static_assert(NS <= 4, "one quantity per lane of a 16-lane group");
+      // butterfly over the 16 lanes (frow) that own the same columns, then lane frow = k adds quantity k = 4 st + 2 half + {sum, sumsq}
+      float mine = 0.f;
+#pragma unroll
+      for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int sq = 0; sq < 2; ++sq) {
+            float x = sq ? gsq[st][h] : gsum[st][h];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
+            mine = frow == 4 * st + 2 * h + sq ? x : mine;
+          }
+      const int k = frow, st_k = k >> 2, h_k = (k >> 1) & 1;
+      int gc = 0;
+      bool ok = false;
+#pragma unroll
+      for (int st = 0; st < NS; ++st)
+        if (st == st_k) { gc = gcol[st]; ok = coff[st] != OOB; }
+      if (ok && k < 4 * NS) {
+        const int g = (gc + 4 * h_k) / P.gn_gs;
+        const int slot = ((row_base >> 7) + (col_base >> 6)) & (GN_SLOTS - 1);
+        double* dst = P.gn_stats + ((int64_t)slot * P.gn_groups + g) * 2 + (k & 1);
+        __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)dst, (double)mine);
       }
     }
   }
@@ -1371,9 +1413,14 @@ LaunchTimer& launch_timer() {
 
 // ---- tile shape / kernel choice -------------------------------------------------------------------------------------------
 struct GemmMode { int impl = -1, tile = 0; };
+bool gemm_qk_fusion_available();
 static GemmMode& gemm_mode() {
   static GemmMode m;
   return m;
+}
+bool gemm_conv_stats_available() {                      // convolution launches go to a kernel whose epilogue accumulates GroupNorm sums
+  if (gemm_mode().impl < 0) (void)gemm_qk_fusion_available();
+  return gemm_mode().impl != 1;
 }
 bool gemm_qk_fusion_available() {
   if (gemm_mode().impl < 0) {                           // same defaults as launch_gemm's first call

@@ -41,6 +41,12 @@ struct GemmProblem {
   // weight, W = the token matrix -- so C [head_dim * heads, keys] IS the attention kernel's V^T operand; w_perm16 loads the W rows
   // (keys) of every 16-group in the order key_of_pos (afx_attn.hip) wants its columns, bias_rows adds bias[row] instead of bias[col].
   int32_t w_perm16, bias_rows;
+  // Convolution launches (one-wave-per-SIMD kernel): GroupNorm statistics of the OUTPUT grid, accumulated by the epilogue so that the
+  // normalisation that follows needs no pass of its own over the grid: per group g the sum and the sum of squares of the stored values
+  // are added (fp64 atomics) to gn_stats[slot][g][2], slot = a hash of the tile in [0, GN_SLOTS) (spreads the atomics; the reader sums
+  // the slots).  gn_gs = channels per group (4, 8 or a multiple of 8).  nullptr: off.
+  double* gn_stats;
+  int32_t gn_gs, gn_groups;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 
@@ -58,8 +64,10 @@ struct GemmBatch {
 };
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
+bool gemm_conv_stats_available();           // GemmProblem::gn_stats is honoured (every kernel but the 2-stage reference one)
 bool gemm_qk_fusion_available();            // the launcher would take a problem with qk_D > 0 (kernel mode 3, no stream-K request)
 void gemm_set_mode(int impl, int tile);      // kernel / tile-shape override of AFX_GEMM_IMPL / AFX_GEMM_TILE (see launch_gemm)
+constexpr int GN_SLOTS = 64;
 constexpr int64_t GEMM_SK_FLAG_BYTES = 4096;                       // 1024 flag words
 constexpr int64_t GEMM_SK_SLAB_BYTES = 256ll * 256 * 256 * 4;      // 256 work-groups x one fp32 256x256 tile
 

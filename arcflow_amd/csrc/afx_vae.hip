@@ -66,6 +66,15 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
+// the convolution epilogue's slotted partial sums -> stats[2 * groups]
+__global__ void gn_sum_slots_kernel(const double* __restrict__ slots, int groups, double* __restrict__ stats) {
+  const int i = threadIdx.x;
+  if (i >= 2 * groups) return;
+  double a = 0.0;
+  for (int s = 0; s < GN_SLOTS; ++s) a += slots[(int64_t)s * 2 * groups + i];
+  stats[i] = a;
+}
+
 // per-channel affine of the normalisation: y = x * coef[c] + coef[C + c]
 __global__ void gn_coeff_kernel(const double* __restrict__ stats, double count, int C, int groups, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, float* __restrict__ coef) {
@@ -277,8 +286,8 @@ static inline unsigned vblocks(int64_t n) { return (unsigned)((n + 255) / 256); 
 
 extern "C" {
 
-int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
-                     int32_t Cout, const void* res, void* stream) {
+static int conv3x3_impl(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
+                        int32_t Cout, const void* res, double* gn_stats, int32_t groups, void* stream) {
   // x, y, res: zero-bordered NHWC grids [(H+2)*(W+2), C]; x must have >= (W+3) readable rows before and after
   // (guard band of the shifted taps).  w: [Cout][3][3][Cin] bf16 (tap-major K).  Cin % 64 == 0, Cout % 8 == 0.
   if (!x || !w || !y || H < 1 || W < 1 || Cin < 64 || Cin % 64 || Cout < 8 || Cout % 8)
@@ -294,9 +303,29 @@ int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, in
   if (res != nullptr) {          // y = res + conv(x): residual epilogue with a unit gate
     p.epi = EPI_GATE_RES; p.gate = nullptr; p.ldg = 0; p.res = (const uint16_t*)res; p.ldr = Cout;
   }
+  if (gn_stats != nullptr) {   // GroupNorm sums of y from the epilogue (one-wave-per-SIMD kernel only): [GN_SLOTS][groups][2] doubles, zeroed here
+    if (groups < 1 || groups > 64 || Cout % groups || (Cout / groups) % 4 || ((Cout / groups) > 8 && (Cout / groups) % 8) || !gemm_conv_stats_available())
+      return fail(AFX_E_INVALID, "afx_conv3x3_bf16_stats: need Cout / groups in {4, 8, 16, 24, ...} and the one-wave-per-SIMD GEMM");
+    HIP_TRY(hipMemsetAsync(gn_stats, 0, sizeof(double) * 2 * groups * GN_SLOTS, (hipStream_t)stream));
+    p.gn_stats = gn_stats; p.gn_gs = Cout / groups; p.gn_groups = groups;
+  }
   HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;
 }
+
+int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
+                     int32_t Cout, const void* res, void* stream) {
+  return conv3x3_impl(x, w, bias, y, H, W, Cin, Cout, res, nullptr, 0, stream);
+}
+
+int afx_conv3x3_bf16_stats(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                           const void* res, double* gn_stats, int32_t groups, void* stream) {
+  if (!gn_stats) return fail(AFX_E_INVALID, "afx_conv3x3_bf16_stats: null statistics buffer");
+  return conv3x3_impl(x, w, bias, y, H, W, Cin, Cout, res, gn_stats, groups, stream);
+}
+
+int afx_conv_stats_available(void) { return gemm_conv_stats_available() ? 1 : 0; }
+
 
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
@@ -310,6 +339,24 @@ int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int3
   const unsigned nblk = (unsigned)std::min<int64_t>(2048, (rows + rstep - 1) / rstep);
   float* coef = reinterpret_cast<float*>(stats_ws + 2 * groups);
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, rows, C, groups, stats_ws);
+  const double count = (double)H * W * (C / groups);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, count, C, groups, gamma, beta, eps, coef);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(4096, (rows + rstep - 1) / rstep)), dim3(256), 0, st,
+                     (const bf16_t*)x, (bf16_t*)y, rows, C, coef, act, H + 2, W + 2);
+  HIP_TRY(hipGetLastError());
+  return AFX_OK;
+}
+
+int afx_groupnorm_nhwc_from_stats(const void* x, void* y, const double* gn_stats, double* stats_ws, int32_t H, int32_t W, int32_t C,
+                                  int32_t groups, const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
+  // gn_stats: what afx_conv3x3_bf16_stats left for the grid x ([GN_SLOTS][groups][2] partial sums); stats_ws as in afx_groupnorm_nhwc
+  if (!x || !y || !gn_stats || !stats_ws || !gamma || !beta || C % 8 || groups < 1 || groups > 64 || C % groups || 256 % (C >> 3) || C > 2048)
+    return fail(AFX_E_INVALID, "bad argument to afx_groupnorm_nhwc_from_stats");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)(H + 2) * (W + 2);
+  const int rstep = 256 / (C >> 3);
+  float* coef = reinterpret_cast<float*>(stats_ws + 2 * groups);
+  hipLaunchKernelGGL(gn_sum_slots_kernel, dim3(1), dim3(128), 0, st, gn_stats, groups, stats_ws);
   const double count = (double)H * W * (C / groups);
   hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, count, C, groups, gamma, beta, eps, coef);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(4096, (rows + rstep - 1) / rstep)), dim3(256), 0, st,

@@ -9,6 +9,8 @@ conv [Cout,Cin,3,3] -> [Cout][tap][Cin] (K-contiguous), to_q|to_k|to_v stacked.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Dict, Sequence
 
@@ -35,6 +37,7 @@ class _Grid:
         rows = (H + 2) * (W + 2)
         self.buf = torch.zeros(rows + 2 * self.guard, Cn, dtype=torch.bfloat16, device=device) if buf is None else buf
         self.t = self.buf[self.guard:self.guard + rows]
+        self.stats = None           # GroupNorm partial sums of this grid, left by the convolution that produced it (afx_conv3x3_bf16_stats)
 
 
 class _GridPool:
@@ -117,19 +120,36 @@ class AutoencoderKLDecoder:
         self.w[a + 'qkv.bias'] = torch.cat([self.w[a + n + '.bias'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
         self._stats = torch.zeros(128 + 2048, dtype=torch.float64, device=self.dev)   # 2*groups doubles + 2*C floats
         self._pool = _GridPool(self.dev)
+        # GroupNorm sums out of the producing convolution's epilogue: a ring of slotted buffers (a grid's sums live until its norm ran:
+        # at most the block input + conv1 output at a time; 4 is generous)
+        self._conv_stats = bool(self.lib.afx_conv_stats_available()) and os.environ.get('AFX_VAE_CONV_STATS', '1') != '0'     # (0: A/B runs)
+        self._stat_ring = [torch.zeros(64 * 2 * self.groups, dtype=torch.float64, device=self.dev) for _ in range(4)]
+        self._stat_i = 0
 
     # ------------------------------------------------------------------ primitives on grids
-    def _conv(self, name: str, x: _Grid, cout: int, res: _Grid = None) -> _Grid:
+    def _conv(self, name: str, x: _Grid, cout: int, res: _Grid = None, stats: bool = True) -> _Grid:
+        """stats: the output feeds a GroupNorm -> its sums come out of the GEMM epilogue (no statistics pass over the grid later)."""
         w, b = self.w[name + '.weight'], self.w[name + '.bias']
-        y = self._pool.grid(x.H, x.W, w.shape[0])
-        _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, w.shape[0],
-                                             None if res is None else _p(res.t), _s()))
+        co = w.shape[0]
+        y = self._pool.grid(x.H, x.W, co)
+        gs = co // self.groups if co % self.groups == 0 else 0
+        if stats and self._conv_stats and gs >= 4 and gs % 4 == 0 and (gs <= 8 or gs % 8 == 0):
+            y.stats = self._stat_ring[self._stat_i % len(self._stat_ring)]
+            self._stat_i += 1
+            _lib.check(self.lib.afx_conv3x3_bf16_stats(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, co, None if res is None else _p(res.t),
+                                                       _p(y.stats), self.groups, _s()))
+        else:
+            _lib.check(self.lib.afx_conv3x3_bf16(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, co, None if res is None else _p(res.t), _s()))
         return y
 
     def _gn(self, name: str, x: _Grid, act: bool) -> _Grid:
         y = self._pool.grid(x.H, x.W, x.C)
-        _lib.check(self.lib.afx_groupnorm_nhwc(_p(x.t), _p(y.t), _p(self._stats), x.H, x.W, x.C, self.groups,
-                                               _p(self.w[name + '.weight']), _p(self.w[name + '.bias']), 1e-6, int(act), _s()))
+        g, b = self.w[name + '.weight'], self.w[name + '.bias']
+        if x.stats is not None:
+            _lib.check(self.lib.afx_groupnorm_nhwc_from_stats(_p(x.t), _p(y.t), _p(x.stats), _p(self._stats), x.H, x.W, x.C, self.groups,
+                                                              _p(g), _p(b), 1e-6, int(act), _s()))
+        else:
+            _lib.check(self.lib.afx_groupnorm_nhwc(_p(x.t), _p(y.t), _p(self._stats), x.H, x.W, x.C, self.groups, _p(g), _p(b), 1e-6, int(act), _s()))
         return y
 
     def _resnet(self, p: str, x: _Grid) -> _Grid:
@@ -164,7 +184,7 @@ class AutoencoderKLDecoder:
                 up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
                 _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
                 x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.conv', up, 0)
-        x = self._conv('decoder.conv_out', self._gn('decoder.conv_norm_out', x, True), 0)
+        x = self._conv('decoder.conv_out', self._gn('decoder.conv_norm_out', x, True), 0, stats=False)
         img = torch.empty(3, x.H, x.W, dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.afx_nhwc_to_image(_p(x.t), _p(img), x.H, x.W, x.C, _s()))
         return img

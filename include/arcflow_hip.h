@@ -277,6 +277,17 @@ int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, in
  * C/8 must divide 256 (C = 64, 128, 256, 512, 1024, 2048) */
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream);
+/* The same convolution, and the GroupNorm sums of ITS OUTPUT accumulated by the GEMM epilogue: gn_stats = AFX_GN_SLOTS x groups x 2 doubles
+ * (zeroed by the call; partial sums spread over the slots by tile), Cout / groups = 4, 8 or a multiple of 8.  afx_groupnorm_nhwc_from_stats
+ * then normalises y without a statistics pass of its own (diffusers' ResnetBlock2D order norm -> act -> conv: every GroupNorm input of the
+ * decoder except the attention output is a convolution output).  afx_conv_stats_available(): 0 when the GEMM kernel override in force has no
+ * such epilogue (AFX_GEMM_IMPL=1). */
+#define AFX_GN_SLOTS 64
+int afx_conv3x3_bf16_stats(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                           const void* res, double* gn_stats, int32_t groups, void* stream);
+int afx_groupnorm_nhwc_from_stats(const void* x, void* y, const double* gn_stats, double* stats_ws, int32_t H, int32_t W, int32_t C,
+                                  int32_t groups, const float* gamma, const float* beta, float eps, int32_t act, void* stream);
+int afx_conv_stats_available(void);
 int afx_upsample2x_nhwc(const void* x, void* y, int32_t H, int32_t W, int32_t C, void* stream);
 /* scatter == 0: compact[H*W, C] = interior(padded);  != 0: interior(padded) = compact (+ interior(res_padded)) */
 int afx_interior_nhwc(void* padded, void* compact, const void* res_padded, int32_t H, int32_t W, int32_t C, int32_t scatter,

@@ -29,6 +29,45 @@ def test_conv3x3_implicit_gemm_vs_torch():
     assert border.abs().max().item() == 0          # the epilogue keeps the padded grid's border zero
 
 
+@pytest.mark.parametrize('H,W,ci,co,groups,with_res', [(9, 13, 64, 128, 32, True), (20, 17, 128, 256, 32, False), (6, 40, 64, 512, 32, True),
+                                                      (31, 33, 64, 128, 16, False)])
+def test_conv3x3_epilogue_groupnorm_sums(H, W, ci, co, groups, with_res):
+    """afx_conv3x3_bf16_stats: the GroupNorm sums of the convolution's OUTPUT grid come out of the GEMM epilogue (slotted fp64 partial sums) and
+    afx_groupnorm_nhwc_from_stats normalises with them -- against sums of the stored grid and against afx_groupnorm_nhwc (its own statistics
+    pass) on the same grid.  Channels per group 4 / 8 / 16 / 8; both tile widths (Cout = 128: 256x128 tiles)."""
+    from arcflow_amd import _lib
+    from arcflow_amd.vae import _Grid, _p, _s
+    lib = _lib.load()
+    assert lib.afx_conv_stats_available() == 1
+    g = torch.Generator().manual_seed(H * W + co)
+    x = torch.randn(ci, H, W, generator=g).bfloat16()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).bfloat16()
+    b = torch.randn(co, generator=g).bfloat16()
+    gx, gr, gy = _Grid(H, W, ci, 'cuda'), _Grid(H, W, co, 'cuda'), _Grid(H, W, co, 'cuda')
+    gx.t.view(H + 2, W + 2, ci)[1:-1, 1:-1] = x.permute(1, 2, 0).cuda()
+    gr.t.view(H + 2, W + 2, co)[1:-1, 1:-1] = torch.randn(H, W, co, generator=g).bfloat16().cuda()
+    wp = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous().cuda()
+    slots = torch.full((64, groups, 2), 7.0, dtype=torch.float64, device='cuda')          # the call zeroes it
+    _lib.check(lib.afx_conv3x3_bf16_stats(_p(gx.t), _p(wp), _p(b.cuda()), _p(gy.t), H, W, ci, co, _p(gr.t) if with_res else None,
+                                          _p(slots), groups, _s()))
+    got = slots.sum(0).cpu()                                                               # [groups, 2]
+    y = gy.t.view(H + 2, W + 2, co).double().cpu()
+    assert y[0].abs().max() == 0 and y[:, 0].abs().max() == 0                              # border still zero
+    yg = y.view(-1, groups, co // groups)
+    ref = torch.stack([yg.sum((0, 2)), (yg * yg).sum((0, 2))], 1)
+    # the epilogue sums the fp32 values BEFORE their rounding to bf16 (2^-9 relative per element): a random walk of n such errors
+    n = (H + 2) * (W + 2) * (co // groups)
+    assert ((got[:, 0] - ref[:, 0]).abs() <= 2.0 ** -8 * (n * ref[:, 1]).sqrt()).all(), (got[:, 0] - ref[:, 0]).abs().max().item()
+    assert ((got[:, 1] - ref[:, 1]).abs() <= 2e-3 * ref[:, 1]).all(), ((got[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max().item()
+    gamma, beta = torch.randn(co, generator=g).cuda(), torch.randn(co, generator=g).cuda()
+    ws = torch.zeros(2 * groups + co, dtype=torch.float64, device='cuda')
+    ya, yb = _Grid(H, W, co, 'cuda'), _Grid(H, W, co, 'cuda')
+    _lib.check(lib.afx_groupnorm_nhwc_from_stats(_p(gy.t), _p(ya.t), _p(slots), _p(ws), H, W, co, groups, _p(gamma), _p(beta), 1e-6, 1, _s()))
+    _lib.check(lib.afx_groupnorm_nhwc(_p(gy.t), _p(yb.t), _p(ws), H, W, co, groups, _p(gamma), _p(beta), 1e-6, 1, _s()))
+    d = (ya.t.float() - yb.t.float()).abs().max().item()
+    assert d <= 2.0 ** -6 * yb.t.float().abs().max().item(), d
+
+
 @pytest.mark.parametrize('hp,wp', [(4, 4), (3, 5)])
 def test_decoder_vs_oracle(hp, wp):
     from arcflow_amd.vae import AutoencoderKLDecoder
