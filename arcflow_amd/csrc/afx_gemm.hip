@@ -155,7 +155,7 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 // FP8: the product is scaled by a_scale[row] * w_scale[col] first (row-wise activation, per-output-channel weight scales);
 // PRE: a bf16 [M, N] term (GemmProblem::pre, the LoRA-dropout correction) is added before the activation / gate.
 // CONV: the rows are pixels of a zero-bordered [conv_hp][conv_wp] grid (implicit 3x3 convolution): border pixels are stored as zero.
-template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false>
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false, bool GN = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? (NJ + 1) / 2 : NJ; // steps per row tile (SWAP with an odd NJ: the last step pairs the lone column tile with
@@ -281,12 +281,28 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     for (int ii = 0; ii < PF && ii < MI; ++ii) fetch_res(ii, rw[ii % (PF + 1)]);
     const int b_first = row_base / rpb, b_last = (row_base + MI * 16 - 1) / rpb;      // scalar divisions, once
     single = b_first == b_last;
-    fetch_gate(b_first, g1);
+    if constexpr (!CONV) fetch_gate(b_first, g1);      // (convolutions: a plain residual add, no gate vector -- 64 registers less)
   }
-  float gsum[CONV ? NS : 1][2], gsq[CONV ? NS : 1][2];        // CONV + gn_stats: this lane's share of the output's GroupNorm sums
-  if constexpr (CONV) {
+  // GN (256x128-tile convolutions of the one-wave-per-SIMD kernel, GemmProblem::gn_stats): this lane's share of the output's GroupNorm sums --
+  // a lane's 8 columns are two 4-channel halves, 8 running floats for the two steps of a row tile.  Only the narrow tile has it: in the epilogue
+  // of a 256x256 tile hipcc already parks VGPRs in accumulator registers as row tiles free them, and 8 more live floats make it spill 1.1 KB of
+  // ACCUMULATORS to scratch instead (tried: one prefetch stage less, no gate arrays, a scheduling barrier per row tile -- no change); the
+  // register-free alternative, private LDS cells updated by ds_add_f32, costs 70 % more time per tile (the LDS atomic unit is slow).  The wide
+  // layers (>= 256 channels: 4x smaller grids per channel) keep the separate statistics pass.
+  constexpr int GH = GN ? (NS > 2 ? 1 : 2) : 1;
+  constexpr int GQ = 2 * NS * GH;                                  // quantities per lane: (step, half) x {sum, sum of squares}
+  float gsum[GN ? NS : 1][GH], gsq[GN ? NS : 1][GH];
+  if constexpr (GN) {
 #pragma unroll
-    for (int st = 0; st < NS; ++st) gsum[st][0] = gsum[st][1] = gsq[st][0] = gsq[st][1] = 0.f;
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+      for (int h = 0; h < GH; ++h) {
+        float z = 0.f;
+        asm volatile("" : "+v"(z));          // opaque zero, created HERE: a plain 0.f is materialised above the main loop and lives through it
+        gsum[st][h] = z;
+        asm volatile("" : "+v"(z));
+        gsq[st][h] = z;
+      }
   }
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
@@ -309,11 +325,13 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
     }
     if constexpr (EPI == EPI_GATE_RES) {
       if (ii + PF < MI) fetch_res(ii + PF, rw[(ii + PF) % (PF + 1)]);
+      if constexpr (!CONV) {
 #pragma unroll
       for (int st = 0; st < NS; ++st)
 #pragma unroll
         for (int e = 0; e < CW; ++e) gi[st][e] = g1[st][e];
-      if (!single) {                                            // (uniform) rows of several samples in this wave's tile
+      }
+      if (!CONV && !single) {                                            // (uniform) rows of several samples in this wave's tile
         const int grow = row_base + ii * 16 + frow;
         int b = (int)((float)grow * inv_rpb);                   // floor(grow / rpb) up to +-1: fix up exactly
         const int rem = grow - b * rpb;
@@ -358,17 +376,17 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         for (int e = 0; e < CW; ++e) {
           const uint32_t w = rw[ii % (PF + 1)][st][e >> 1];
           const float rr = __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
-          v[e] = rr + (has_gate ? gi[st][e] : 1.0f) * v[e];       // no gate: plain residual add
+          v[e] = CONV ? rr + v[e] : rr + (has_gate ? gi[st][e] : 1.0f) * v[e];       // no gate: plain residual add
         }
       }
       if constexpr (CONV) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = border ? 0.f : v[e];
-        if constexpr (SWAP) {
+        if constexpr (GN) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            gsum[st][e >> 2] += v[e];
-            gsq[st][e >> 2] += v[e] * v[e];
+            gsum[st][GH == 2 ? e >> 2 : 0] += v[e];
+            gsq[st][GH == 2 ? e >> 2 : 0] += v[e] * v[e];
           }
         }
       }
@@ -383,32 +401,30 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       }
     }
   }
-  if constexpr (CONV && SWAP) {
+  if constexpr (GN) {
     if (P.gn_stats != nullptr) {                                  // (uniform)
-      static_assert(NS <= 4, "one quantity per lane of a 16-lane group");
-      // butterfly over the 16 lanes (frow) that own the same columns, then lane frow = k adds quantity k = 4 st + 2 half + {sum, sumsq}
+      static_assert(SWAP && GQ <= 16, "one quantity per lane of a 16-lane row");
+      // sum over the 16 lanes (frow) that own the same columns -- a DPP row -- then lane frow = k adds quantity k = 2 (GH st + half) + {sum, sumsq}
+      auto row_sum = [](float x) {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, false));   // row_half_mirror
+        x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, false));   // row_mirror
+        return x;
+      };
       float mine = 0.f;
-#pragma unroll
-      for (int st = 0; st < NS; ++st)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int sq = 0; sq < 2; ++sq) {
-            float x = sq ? gsq[st][h] : gsum[st][h];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) x += __shfl_xor(x, o, 64);
-            mine = frow == 4 * st + 2 * h + sq ? x : mine;
-          }
-      const int k = frow, st_k = k >> 2, h_k = (k >> 1) & 1;
       int gc = 0;
       bool ok = false;
 #pragma unroll
-      for (int st = 0; st < NS; ++st)
-        if (st == st_k) { gc = gcol[st]; ok = coff[st] != OOB; }
-      if (ok && k < 4 * NS) {
-        const int g = (gc + 4 * h_k) / P.gn_gs;
+      for (int q = 0; q < GQ; ++q) {
+        const float x = row_sum((q & 1) ? gsq[(q >> 1) / GH][(q >> 1) % GH] : gsum[(q >> 1) / GH][(q >> 1) % GH]);
+        mine = frow == q ? x : mine;
+        if (frow == q) { gc = gcol[(q >> 1) / GH] + 4 * ((q >> 1) % GH); ok = coff[(q >> 1) / GH] != OOB; }
+      }
+      if (ok && frow < GQ) {
+        const int g = gc / P.gn_gs;
         const int slot = ((row_base >> 7) + (col_base >> 6)) & (GN_SLOTS - 1);
-        double* dst = P.gn_stats + ((int64_t)slot * P.gn_groups + g) * 2 + (k & 1);
+        double* dst = P.gn_stats + ((int64_t)slot * P.gn_groups + g) * 2 + (frow & 1);
         __builtin_amdgcn_global_atomic_fadd_f64((__attribute__((address_space(1))) double*)dst, (double)mine);
       }
     }
@@ -1389,8 +1405,8 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #define V3_EPI_SWAP 1
 #endif
     if constexpr (CONV) {      // bias (+ residual) + re-zeroing of the border pixels: the output grid is the next layer's padded input
-      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
-      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
     } else
     epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
 #ifdef AFX_GEMM_TRACE
@@ -1418,9 +1434,9 @@ static GemmMode& gemm_mode() {
   static GemmMode m;
   return m;
 }
-bool gemm_conv_stats_available() {                      // convolution launches go to a kernel whose epilogue accumulates GroupNorm sums
+bool gemm_conv_stats_available() {                      // convolution launches go to the kernel whose epilogue accumulates GroupNorm sums
   if (gemm_mode().impl < 0) (void)gemm_qk_fusion_available();
-  return gemm_mode().impl != 1;
+  return gemm_mode().impl == 3 && gemm_mode().tile == 0;
 }
 bool gemm_qk_fusion_available() {
   if (gemm_mode().impl < 0) {                           // same defaults as launch_gemm's first call

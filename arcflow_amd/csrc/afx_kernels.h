@@ -44,7 +44,7 @@ struct GemmProblem {
   // Convolution launches (one-wave-per-SIMD kernel): GroupNorm statistics of the OUTPUT grid, accumulated by the epilogue so that the
   // normalisation that follows needs no pass of its own over the grid: per group g the sum and the sum of squares of the stored values
   // are added (fp64 atomics) to gn_stats[slot][g][2], slot = a hash of the tile in [0, GN_SLOTS) (spreads the atomics; the reader sums
-  // the slots).  gn_gs = channels per group (4, 8 or a multiple of 8).  nullptr: off.
+  // the slots).  gn_gs = channels per group (4, 8 or a multiple of 8); N <= 128 only (the 256x128 tile).  nullptr: off.
   double* gn_stats;
   int32_t gn_gs, gn_groups;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
@@ -64,7 +64,7 @@ struct GemmBatch {
 };
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
-bool gemm_conv_stats_available();           // GemmProblem::gn_stats is honoured (every kernel but the 2-stage reference one)
+bool gemm_conv_stats_available();           // GemmProblem::gn_stats is honoured (kernel mode 3, no forced tile shape)
 bool gemm_qk_fusion_available();            // the launcher would take a problem with qk_D > 0 (kernel mode 3, no stream-K request)
 void gemm_set_mode(int impl, int tile);      // kernel / tile-shape override of AFX_GEMM_IMPL / AFX_GEMM_TILE (see launch_gemm)
 constexpr int GN_SLOTS = 64;

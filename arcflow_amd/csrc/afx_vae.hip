@@ -304,8 +304,9 @@ static int conv3x3_impl(const void* x, const void* w, const void* bias, void* y,
     p.epi = EPI_GATE_RES; p.gate = nullptr; p.ldg = 0; p.res = (const uint16_t*)res; p.ldr = Cout;
   }
   if (gn_stats != nullptr) {   // GroupNorm sums of y from the epilogue (one-wave-per-SIMD kernel only): [GN_SLOTS][groups][2] doubles, zeroed here
-    if (groups < 1 || groups > 64 || Cout % groups || (Cout / groups) % 4 || ((Cout / groups) > 8 && (Cout / groups) % 8) || !gemm_conv_stats_available())
-      return fail(AFX_E_INVALID, "afx_conv3x3_bf16_stats: need Cout / groups in {4, 8, 16, 24, ...} and the one-wave-per-SIMD GEMM");
+    const int gs = groups > 0 && Cout % groups == 0 ? Cout / groups : 0;
+    if (groups < 1 || groups > 64 || gs < 4 || gs % 4 || (gs > 8 && gs % 8) || Cout > 128 || !gemm_conv_stats_available())
+      return fail(AFX_E_INVALID, "afx_conv3x3_bf16_stats: need Cout <= 128 (the 256x128-tile kernel), Cout / groups = 4, 8 or a multiple of 8, and the one-wave-per-SIMD GEMM");
     HIP_TRY(hipMemsetAsync(gn_stats, 0, sizeof(double) * 2 * groups * GN_SLOTS, (hipStream_t)stream));
     p.gn_stats = gn_stats; p.gn_gs = Cout / groups; p.gn_groups = groups;
   }

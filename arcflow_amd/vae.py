@@ -133,7 +133,7 @@ class AutoencoderKLDecoder:
         co = w.shape[0]
         y = self._pool.grid(x.H, x.W, co)
         gs = co // self.groups if co % self.groups == 0 else 0
-        if stats and self._conv_stats and gs >= 4 and gs % 4 == 0 and (gs <= 8 or gs % 8 == 0):
+        if stats and self._conv_stats and co <= 128 and gs >= 4 and gs % 4 == 0 and (gs <= 8 or gs % 8 == 0):
             y.stats = self._stat_ring[self._stat_i % len(self._stat_ring)]
             self._stat_i += 1
             _lib.check(self.lib.afx_conv3x3_bf16_stats(_p(x.t), _p(w), _p(b), _p(y.t), x.H, x.W, x.C, co, None if res is None else _p(res.t),

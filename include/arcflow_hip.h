@@ -278,7 +278,8 @@ int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, in
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream);
 /* The same convolution, and the GroupNorm sums of ITS OUTPUT accumulated by the GEMM epilogue: gn_stats = AFX_GN_SLOTS x groups x 2 doubles
- * (zeroed by the call; partial sums spread over the slots by tile), Cout / groups = 4, 8 or a multiple of 8.  afx_groupnorm_nhwc_from_stats
+ * (zeroed by the call; partial sums spread over the slots by tile), Cout <= 128 (the 256x128-tile kernel: the full-resolution stage, whose
+ * grids are the largest), Cout / groups = 4, 8 or a multiple of 8.  afx_groupnorm_nhwc_from_stats
  * then normalises y without a statistics pass of its own (diffusers' ResnetBlock2D order norm -> act -> conv: every GroupNorm input of the
  * decoder except the attention output is a convolution output).  afx_conv_stats_available(): 0 when the GEMM kernel override in force has no
  * such epilogue (AFX_GEMM_IMPL=1). */

@@ -29,12 +29,12 @@ def test_conv3x3_implicit_gemm_vs_torch():
     assert border.abs().max().item() == 0          # the epilogue keeps the padded grid's border zero
 
 
-@pytest.mark.parametrize('H,W,ci,co,groups,with_res', [(9, 13, 64, 128, 32, True), (20, 17, 128, 256, 32, False), (6, 40, 64, 512, 32, True),
-                                                      (31, 33, 64, 128, 16, False)])
+@pytest.mark.parametrize('H,W,ci,co,groups,with_res', [(9, 13, 64, 128, 32, True), (20, 17, 128, 128, 32, False), (6, 40, 64, 64, 8, True),
+                                                      (31, 33, 64, 128, 16, False), (300, 70, 64, 128, 32, True)])
 def test_conv3x3_epilogue_groupnorm_sums(H, W, ci, co, groups, with_res):
     """afx_conv3x3_bf16_stats: the GroupNorm sums of the convolution's OUTPUT grid come out of the GEMM epilogue (slotted fp64 partial sums) and
     afx_groupnorm_nhwc_from_stats normalises with them -- against sums of the stored grid and against afx_groupnorm_nhwc (its own statistics
-    pass) on the same grid.  Channels per group 4 / 8 / 16 / 8; both tile widths (Cout = 128: 256x128 tiles)."""
+    pass) on the same grid.  Channels per group 4 / 4 / 8 / 8 / 4 (Cout <= 128: the 256x128-tile kernel)."""
     from arcflow_amd import _lib
     from arcflow_amd.vae import _Grid, _p, _s
     lib = _lib.load()
