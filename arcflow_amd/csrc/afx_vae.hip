@@ -182,6 +182,54 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   for (int i = threadIdx.x; i < cols; i += 256) pr[i] = f32_to_bf16(__expf((sr[i] - mx) * scale) * inv);
 }
 
+// The same for rows of at most 16384 columns (cols % 4 == 0): the row is read ONCE, 16 bytes per lane and load, and stays in registers
+// between the maximum, the exponentials and the store (the three-pass kernel above reads it three times with 4-byte loads and takes
+// exp twice: 685 us for the 16384 x 16384 scores of the 1024^2 decode's mid-block attention).
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ s, int64_t lds_, bf16_t* __restrict__ p, int64_t ldp,
+                                                               int cols, float scale) {
+  constexpr int NV = 16;
+  __shared__ float red[4];
+  const f32x4_t* sr = reinterpret_cast<const f32x4_t*>(s + (int64_t)blockIdx.x * lds_);
+  bf16_t* pr = p + (int64_t)blockIdx.x * ldp;
+  const int nv = cols >> 2;
+  f32x4_t v[NV];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    v[j] = i < nv ? sr[i] : (f32x4_t){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) mx = fmaxf(fmaxf(fmaxf(v[j][0], v[j][1]), fmaxf(v[j][2], v[j][3])), mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[j][e] = __expf((v[j][e] - mx) * scale);                  // (-inf padding -> 0)
+      sum += v[j][e];
+    }
+  sum = wave_sum(sum);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+  typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = threadIdx.x + 256 * j;
+    if (i < nv) {
+      const u32x2_t o = {pack_bf16x2(v[j][0] * inv, v[j][1] * inv), pack_bf16x2(v[j][2] * inv, v[j][3] * inv)};
+      *reinterpret_cast<u32x2_t*>(pr + 4 * i) = o;
+    }
+  }
+}
+
 // packed latent tokens [N = hp*wp, 64] f32 (channel c*4 + ph*2 + pw) -> zero-bordered NHWC [2hp+2][2wp+2][Cpad] bf16,
 // value = lat / scaling + shift  (arcflux_pipeline.py:531-532), channels >= 16 zero.
 __global__ __launch_bounds__(256) void latent_to_nhwc_kernel(const float* __restrict__ tok, bf16_t* __restrict__ y, int hp, int wp,
@@ -386,7 +434,10 @@ int afx_interior_nhwc(void* padded, void* compact, const void* res_padded, int32
 int afx_softmax_rows_f32(const float* s, int64_t lds_, void* p, int64_t ldp, int32_t rows, int32_t cols, float scale,
                          void* stream) {
   if (!s || !p || rows < 1 || cols < 1) return fail(AFX_E_INVALID, "bad argument to afx_softmax_rows_f32");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds_, (bf16_t*)p, ldp, cols, scale);
+  if (cols % 4 == 0 && cols <= 16384 && lds_ % 4 == 0 && ldp % 4 == 0 && ((uintptr_t)s & 15) == 0 && ((uintptr_t)p & 7) == 0)
+    hipLaunchKernelGGL(softmax_rows_reg_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds_, (bf16_t*)p, ldp, cols, scale);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, s, lds_, (bf16_t*)p, ldp, cols, scale);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -245,3 +245,20 @@ def test_qwen_decoder_1024sq_released_width_vs_oracle_on_device():
     d = (img.float() - ref).reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
     r = ref.reshape(3, 16, 64, 16, 64).pow(2).sum(dim=(0, 2, 4)).sqrt()
     assert (d / r).max().item() < 6e-2, (d / r).max().item()
+
+
+@pytest.mark.parametrize('rows,cols', [(7, 64), (5, 1000), (3, 16384), (4, 1023), (2, 20000)])
+def test_softmax_rows_both_kernels(rows, cols):
+    """afx_softmax_rows_f32 (mid-block attention of the AutoencoderKL decoder): the single-read register kernel (cols % 4 == 0, <= 16384)
+    and the three-pass fallback against torch.softmax; bf16 output: 2^-8 relative."""
+    from arcflow_amd import _lib
+    from arcflow_amd.vae import _p, _s
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(rows * cols)
+    s = (torch.randn(rows, cols, generator=g) * 4).cuda()
+    p = torch.empty(rows, cols, dtype=torch.bfloat16, device='cuda')
+    _lib.check(lib.afx_softmax_rows_f32(_p(s), cols, _p(p), cols, rows, cols, 0.37, _s()))
+    ref = torch.softmax(s.double() * 0.37, -1)
+    err = ((p.double() - ref).abs() / ref.clamp(min=1e-30)).max().item()
+    assert err < 2.0 ** -7, err
+    assert abs(p.double().sum(-1) - 1).max().item() < 2e-3
