@@ -160,6 +160,7 @@ def main():
             print(json.dumps(dict(iter=dist_.iteration, time=round(now - t_last, 3), **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in info.items()})), flush=True)
             t_last = now
         if dist_.iteration % run['save_interval'] == 0 or dist_.iteration == total:
+            dist_.reducer.check_consistent(dist_.params)      # every rank took the same optimizer steps: raises before a diverged state is saved
             if rank == 0:
                 path = checkpoint.save_checkpoint(dist_, ckpt_dir, fp16=run['ckpt_fp16'], fp16_ema=run['ckpt_fp16_ema'])
                 print(f'[train] saved {path}', flush=True)
