@@ -44,7 +44,8 @@ def needs_build() -> bool:
 def audit_asm_owned(asm_path: str, kernel_substr: str, vgpr_limit: int = 96) -> None:
     """A kernel whose registers are asm-owned (literal names in the asm text: v[vgpr_limit:255] and the whole accumulator file) must
     contain no compiler-generated instruction that touches them and no scratch access: hipcc cannot know they are in use, and
-    amdgpu_num_vgpr is a budget, not a fence (it was exceeded once: silent corruption).  Raises on a violation."""
+    a wrong amdgpu_num_vgpr ceiling was exceeded once (silent corruption), and past the right one hipcc spills into accumulator registers.
+    Raises on a violation."""
     import re
     reg = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\b(a)\d+\b|\b(a)\[\d+:\d+\]')
     in_kernel = in_asm = False

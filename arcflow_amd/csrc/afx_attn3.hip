@@ -20,7 +20,7 @@
 //     at most one memory instruction (ds_read_b128 or LDS-DMA) and 4-5 VALU (MI355X_MICROARCH: <= 5 single-issue fillers hide
 //     in a 32-cycle MFMA gap of a lone wave).  The stream is GENERATED (tools/gen_attn3.py -> gen/a3_*.inc, committed) and all
 //     wide operands are ASM-OWNED: literal register names in the instruction text (map in the generator's header), while
-//     `amdgpu_num_vgpr(192)` confines hipcc's own allocation to v[0:95].  Left to allocate 461 of 512 registers itself hipcc
+//     `amdgpu_num_vgpr(96)` confines hipcc's own allocation to v[0:95].  Left to allocate 461 of 512 registers itself hipcc
 //     split live ranges and spilled (464 registers, 2600 accumulator moves in the first build; the generator's header lists
 //     what else was tried).  hipcc inserts no waits and no hazard padding inside this stream, so every dependency is kept
 //     >= 16 MFMAs apart by the phase structure or carries an explicit s_nop / s_waitcnt; arcflow_amd/build.py audits the ISA
@@ -77,7 +77,7 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 // Softmax of one slab and tile = 134 instructions (gen_attn3.softmax_ops): two interleaved v_max3 chains, the xor-32 exchange,
 // the rescale decision (cold branch), then per score fma / exp2 / row-sum add and per pair cvt_pk, software-pipelined so that a
 // v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
-__global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(192))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
+__global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                   int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
                                                                   int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
