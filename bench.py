@@ -113,7 +113,7 @@ def cpu_baseline(budget_s: float = 12.0):
 
 # the bf16 block GEMMs of the forward: two instantiations of one kernel template -- 256x224 tiles for the N = 3072 / 12288 launches (96 per
 # forward), 256x256 for the k|q|v^T and the single blocks' fused launches (57); the events cover every launch (AFX_GEMM_IMPL=2: gemm_kernel_v2<false>)
-GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 7> + afx::gemm_kernel_v3<8, 8>'
+GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 7, false> + afx::gemm_kernel_v3<8, 8, false>'
 if os.environ.get('AFX_GEMM_IMPL', '3')[:1] == '2':
     GEMM_KERNEL_NAME = 'afx::gemm_kernel_v2<false>'
 POWER_CAPPED_MFMA_TF = 1950.0
