@@ -165,7 +165,7 @@ class ArcFlowDistiller:
         copies / merged LoRA weights are rebuilt and the ranks' buffers are checksummed against each other.  No-op on one rank.
         Call again after loading a checkpoint on one rank only."""
         red = self.reducer
-        if red.world == 1:
+        if red._skip_single:
             return
         red.broadcast_(self.params, src)
         red.broadcast_(self.ema, src)

@@ -26,6 +26,10 @@ class GradReducer:
         self.world = self.dist.get_world_size(process_group) if self.dist else 1
         self.rank = self.dist.get_rank(process_group) if self.dist else 0
         self.backend = self.dist.get_backend(process_group) if self.dist else None
+        # ARCFLOW_DP_FORCE_COLLECTIVES=1: issue every collective even in a one-rank group -- lets a single-GPU box execute the RCCL branch
+        # (async handles, stream waits, the exposed-time events) that otherwise first runs on a multi-GPU node (tests/test_distill.py)
+        import os
+        self._skip_single = self.world == 1 and os.environ.get('ARCFLOW_DP_FORCE_COLLECTIVES', '0') != '1'
         self._pending: List = []
         self._staged: List[Tuple[torch.Tensor, torch.Tensor]] = []
         self.bytes_launched = 0          # per iteration (reset by finish): the tests check "every byte exactly once"
@@ -36,7 +40,7 @@ class GradReducer:
         if flat_grad.numel() == 0:
             return
         self.bytes_launched += flat_grad.numel() * flat_grad.element_size()
-        if self.dist is None or self.world == 1:
+        if self.dist is None or self._skip_single:
             return
         assert flat_grad.is_contiguous()
         if flat_grad.is_cuda and self.backend == 'gloo':      # 2 ranks on one GPU (tests): stage through the host
@@ -79,7 +83,7 @@ class GradReducer:
         """Overwrite `flat` on every rank with rank `src`'s values -- what DDP does with the module state at construction
         (``_sync_module_states``, reached through lakonlab/parallel/ddp_wrapper.py:19-25): ranks must start from identical trainables,
         identical seeds alone do not guarantee it (a resumed rank, a different library build)."""
-        if self.dist is None or self.world == 1:
+        if self.dist is None or self._skip_single:
             return flat
         if flat.is_cuda and self.backend == 'gloo':
             host = flat.detach().to('cpu', copy=True)
@@ -93,7 +97,7 @@ class GradReducer:
         """Raise when the ranks do not hold the same values in `flat` (three fp64 checksums over different index subsets, MIN / MAX
         over ranks; no temporary of the buffer's size: the FLUX trainable set is 650 M values).  Called after the construction
         broadcast and by tools/train.py at every checkpoint interval."""
-        if self.dist is None or self.world == 1:
+        if self.dist is None or self._skip_single:
             return
         x = flat.detach().flatten()
         sums = torch.stack([x.sum(dtype=torch.float64), x[::2].sum(dtype=torch.float64), x[1::3].sum(dtype=torch.float64)])
@@ -106,7 +110,7 @@ class GradReducer:
                                f'(rank {self.rank} has {sums.tolist()})')
 
     def all_reduce_max(self, value: float, device) -> float:
-        if self.dist is None or self.world == 1:
+        if self.dist is None or self._skip_single:
             return value
         dev = 'cpu' if self.backend == 'gloo' else device
         t = torch.tensor([value], dtype=torch.float32, device=dev)

@@ -755,3 +755,57 @@ def _e4m3_to_float(q):
     m = (q & 7).float()
     v = torch.where(e == 0, m / 8.0 * 2.0 ** -6, (1.0 + m / 8.0) * torch.pow(2.0, (e - 7).float()))
     return (s * v).to(torch.float32)
+
+
+_RCCL_ONE_RANK = r'''
+import os, sys, torch
+sys.path.insert(0, os.getcwd())
+import torch.distributed as dist
+os.environ['MASTER_ADDR'] = '127.0.0.1'
+os.environ.setdefault('MASTER_PORT', '29731')
+os.environ['ARCFLOW_DP_FORCE_COLLECTIVES'] = '1'
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+from tests.test_distill import _setup
+from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+cfg, w = _setup()
+B, hp, wp, T = 2, 8, 8, 64
+g = torch.Generator().manual_seed(3)
+pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+x0 = torch.randn(B, hp * wp, 64, generator=g)
+draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+out = {}
+for force in ('1', '0'):
+    os.environ['ARCFLOW_DP_FORCE_COLLECTIVES'] = force
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=64)
+    d = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+    assert d.reducer.backend == 'nccl' and d.reducer._skip_single == (force == '0')
+    d.iteration = 1
+    info = d.train_step(cond, B, x_init=x0.cuda(), draws=draws)
+    torch.cuda.synchronize()
+    d.reducer.check_consistent(d.params)
+    out[force] = (info['loss'], d.params.clone(), info['allreduce_bytes'] if 'allreduce_bytes' in info else None, info.get('allreduce_exposed_ms'))
+dp = (out['1'][1] - out['0'][1]).abs().max().item()
+# (not bit-identical: the loss and the column sums are accumulated with float atomics, 1e-8 run to run)
+assert abs(out['1'][0] - out['0'][0]) <= 1e-6 * abs(out['0'][0]) and dp <= 1e-6, ('a one-rank SUM all-reduce must change nothing', out['1'][0], out['0'][0], dp)
+print('RCCL_ONE_RANK_OK', out['1'][0], out['1'][2], out['1'][3])
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_branch_of_the_exchange_executes_on_one_rank(tmp_path):
+    """The 'nccl' (= RCCL) branch of GradReducer -- async all-reduce handles on device tensors, the compute stream's wait, the exposed-time
+    events, the construction broadcast and the checksum all-reduces -- has only ever run as 'gloo' in the tests (two ranks cannot share one
+    GPU under RCCL).  A one-rank nccl group with ARCFLOW_DP_FORCE_COLLECTIVES=1 executes every one of those calls on this single-GPU box;
+    a one-rank SUM changes nothing, so the step must equal the run that skips the collectives (to the 1e-8 of the float atomics)."""
+    import subprocess
+    import sys
+    script = tmp_path / 'rccl_one_rank.py'
+    script.write_text(_RCCL_ONE_RANK)
+    env = dict(os.environ, MASTER_PORT=str(29500 + os.getpid() % 400))
+    r = subprocess.run([sys.executable, str(script)], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'RCCL_ONE_RANK_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
