@@ -1,3 +1,12 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_distill.py -m gpu -q -x -k "rccl" 2>&1 | tail -5
-ARCFLOW_DP_FORCE_COLLECTIVES=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --train --steps 1 --warmup 1 2>&1 | tail -3 | cut -c1-1200
+mkdir -p gpurun_out
+t0=$(date +%s)
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+t1=$(date +%s)
+echo "default bench.py wall: $((t1-t0)) s"
+python tools/bench_brief.py < gpurun_out/bench_default.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_default.json').read().strip().split('\n')[-1])
+print({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in ('value','frac','achieved','ms_per_step','kind','cores','unit')}) for k,v in d.items() if k not in ('config','metric','data')})
+PY
