@@ -470,3 +470,21 @@ def test_lora_merge_runs_on_the_library_gemm(out_f, in_f, r):
     d = (got.cpu().float() - ref.float()).abs()
     # fp32 accumulation order differs: at most one bf16 ulp on a few entries
     assert d.max() <= 2.0 ** -7 * ref.float().abs().max() and (d > 0).float().mean() < 0.01
+
+
+@pytest.mark.parametrize('rows,rpb', [(1025, 1025), (2050, 1025), (2049, 683), (1024, 512)])
+def test_norm_modulate_two_rows_per_wave(ops, rows, rpb):
+    """D = 3072, rows >= 1024: norm_modulate_rows_kernel<6, 2> (two rows per wave, modulation vectors kept in registers and reloaded when the
+    sample changes between a wave's rows) -- odd row counts, a sample boundary inside a wave's pair, strided input."""
+    D = 3072
+    g = torch.Generator().manual_seed(rows + rpb)
+    B = (rows + rpb - 1) // rpb
+    xb = bf(torch.randn(rows, D + 64, generator=g) * 1.5 - 0.2).to(dev())
+    x = xb[:, :D]                                              # row-strided view
+    sc = torch.randn(B, D, generator=g).to(dev())
+    sh = torch.randn(B, D, generator=g).to(dev())
+    out = ops.norm_modulate(x, sc, sh, rows_per_batch=rpb)
+    idx = torch.arange(rows, device=dev()) // rpb
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), eps=1e-6) * (1 + sc[idx]) + sh[idx]
+    assert rel_l2(out, ref) < 4e-3
+    assert (out.float() - ref).abs().max().item() < 0.08

@@ -1,12 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-t0=$(date +%s)
-python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
-t1=$(date +%s)
-echo "default bench.py wall: $((t1-t0)) s"
-python tools/bench_brief.py < gpurun_out/bench_default.json
-python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/bench_default.json').read().strip().split('\n')[-1])
-print({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in ('value','frac','achieved','ms_per_step','kind','cores','unit')}) for k,v in d.items() if k not in ('config','metric','data')})
-PY
+timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q -x -k "norm_modulate or race_probe" 2>&1 | tail -3
+(echo "# tools/race_probe.py + tools/race_probe_attn.py + tools/determinism_probe.py on the last build of round 3"; timeout 600 python tools/race_probe.py 2>&1 | tail -25; timeout 600 python tools/race_probe_attn.py 2>&1 | tail -12; timeout 600 python tools/determinism_probe.py 2>&1 | tail -8) > gpurun_out/r03z_probes.txt
+grep -v amdgpu.ids gpurun_out/r03z_probes.txt | tail -45
