@@ -1,5 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_hip_kernels.py -m gpu -q -x -k "norm_modulate or race_probe" 2>&1 | tail -3
-(echo "# tools/race_probe.py + tools/race_probe_attn.py + tools/determinism_probe.py on the last build of round 3"; timeout 600 python tools/race_probe.py 2>&1 | tail -25; timeout 600 python tools/race_probe_attn.py 2>&1 | tail -12; timeout 600 python tools/determinism_probe.py 2>&1 | tail -8) > gpurun_out/r03z_probes.txt
-grep -v amdgpu.ids gpurun_out/r03z_probes.txt | tail -45
+mkdir -p gpurun_out; rm -rf gpurun_out/mfma_pmc
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d gpurun_out/mfma_pmc -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
+python tools/pmc_by_grid.py 'gpurun_out/mfma_pmc/**/*counter_collection.csv' > gpurun_out/r03z_pmc_mfma_busy.txt
+cat gpurun_out/r03z_pmc_mfma_busy.txt | cut -c1-260
