@@ -168,7 +168,9 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   // epilogue is ONE basic block the scheduler can interleave (a taken branch costs a lone wave ~30 cycles of refetch).
   const int rows_ok = min(max(M - row_base, 0), MI * 16);
   const int64_t ldc = P.ldc;
-  __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.C + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 2));
+  const int up = CONV ? P.up_phase : 0;                           // (uniform) folded upsample: rows are scattered over the whole 2x grid
+  __amdgpu_buffer_rsrc_t rc = (CONV && up != 0) ? uniform_rsrc(P.C, (int)((int64_t)(2 * P.conv_hp - 2) * (2 * P.conv_wp - 2) * ldc * 2))
+                                                : uniform_rsrc(P.C + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 2));
   const int ldc2 = (int)(ldc * 2);
   int ldr2 = 0, rpb = 1, ldg4 = 0;
   float inv_rpb = 1.f;
@@ -306,7 +308,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   }
 #pragma unroll
   for (int ii = 0; ii < MI; ++ii) {
-    const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
+    uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
     bool border = false;
     if constexpr (CONV) {
       const int grow = row_base + ii * 16 + frow, wp = P.conv_wp;
@@ -314,6 +316,13 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
       int xx = grow - yy * wp;
       if (xx < 0) { xx += wp; --yy; } else if (xx >= wp) { xx -= wp; ++yy; }
       border = yy <= 0 || yy >= P.conv_hp - 1 || xx == 0 || xx == wp - 1;        // (rows past the grid count as border: nothing of them is kept)
+      if (up != 0) {                                              // source pixel (yy, xx) -> pixel (2 yy + py - 1, 2 xx + px - 1) of the 2x grid
+        const int oy = 2 * yy + ((up - 1) >> 1) - 1, ox = 2 * xx + ((up - 1) & 1) - 1;
+        const int oh = 2 * P.conv_hp - 2, ow = 2 * wp - 2;
+        const bool inside = oy >= 0 && oy < oh && ox >= 0 && ox < ow;
+        border = oy <= 0 || oy >= oh - 1 || ox <= 0 || ox >= ow - 1;   // source border pixels land on the 2x grid's border (or outside)
+        roff = inside ? (uint32_t)(oy * ow + ox) * (uint32_t)ldc2 : OOB;
+      }
     }
     float rb = 0.f;                                               // ROWB: bias[row] (the transposed V projection)
     if constexpr (ROWB) {
@@ -1233,13 +1242,20 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   // CONV (the VAE decoders' 3x3 convolutions, afx_vae.hip): implicit GEMM on a zero-bordered NHWC grid -- K-tile t = (tap, 64-channel chunk)
   // reads the SAME pixel rows shifted by dy * row pitch + dx, so the A stream's K offset becomes a (uniform) row shift + channel offset.
   const float inv_ct = CONV ? 1.0f / (float)P.conv_cin_tiles : 0.f;
+  const int up = CONV ? P.up_phase : 0;                           // 0: 3x3 taps from (-1, -1); 1 + 2 py + px: 2x2 taps from (py - 1, px - 1)
   auto ka = [&](int t) -> int64_t {
     if constexpr (!CONV) return (int64_t)t * (BK * 2);
     const int ct = P.conv_cin_tiles;
     const int tap = (int)(((float)t + 0.5f) * inv_ct);            // t / ct for t < 9 ct <= 72
     const int cc = t - tap * ct;
-    const int ty = (tap * 11) >> 5;                               // tap / 3
-    return ((int64_t)((ty - 1) * P.conv_wp + (tap - 3 * ty - 1)) * P.lda + cc * BK) * 2;
+    int dy, dx;
+    if (up == 0) {
+      const int ty = (tap * 11) >> 5;                             // tap / 3
+      dy = ty - 1; dx = tap - 3 * ty - 1;
+    } else {
+      dy = (tap >> 1) + ((up - 1) >> 1) - 1; dx = (tap & 1) + ((up - 1) & 1) - 1;
+    }
+    return ((int64_t)(dy * P.conv_wp + dx) * P.lda + cc * BK) * 2;
   };
 
   // per-lane byte offsets of this lane's chunks of an A tile (MI pieces of 32 rows) / a W tile (NJ pieces), k = 0
@@ -1536,8 +1552,13 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
   }
   // ---- the VAE decoders' 3x3 convolutions: the same kernel with the implicit-GEMM address stream and the border-zeroing epilogue;
   // 256x128 tiles for the <= 128-channel layers (the full-resolution stage and conv_out, half of a 256-wide tile otherwise)
-  if (impl == 3 && batch.nprob == 1 && batch.p[0].conv_cin_tiles > 0 && batch.p[0].conv_wp > 0 && batch.p[0].out_f32 == 0 &&
-      batch.p[0].fp8 == 0 && batch.p[0].pre == nullptr && batch.p[0].epi != EPI_GELU && batch.p[0].split_k <= 1 && tile_env == 0) {
+  bool conv_all = impl == 3 && tile_env == 0 && batch.nprob >= 1;
+  for (int i = 0; i < batch.nprob; ++i) {
+    const GemmProblem& p = batch.p[i];
+    conv_all = conv_all && p.conv_cin_tiles > 0 && p.conv_wp > 0 && p.out_f32 == 0 && p.fp8 == 0 && p.pre == nullptr && p.epi != EPI_GELU &&
+               p.split_k <= 1 && p.N == batch.p[0].N && (p.up_phase == 0 || (p.epi == EPI_NONE && p.gn_stats == nullptr));
+  }
+  if (conv_all) {
     const bool narrow = batch.p[0].N <= 128;
     const int total = count_tiles(batch, 256, narrow ? 128 : 256, true);
     batch.total_tiles = total;

@@ -47,6 +47,13 @@ struct GemmProblem {
   // the slots).  gn_gs = channels per group (4, 8 or a multiple of 8); N <= 128 only (the 256x128 tile).  nullptr: off.
   double* gn_stats;
   int32_t gn_gs, gn_groups;
+  // Nearest-2x upsample folded into the 3x3 convolution that follows it (one-wave-per-SIMD kernel, afx_upconv3x3_bf16): output pixel
+  // (2y + py, 2x + px) of conv3x3(upsample2x(X)) only sees the 2x2 neighbourhood rows {y - 1 + py, y + py} x cols {x - 1 + px, x + px} of X, with
+  // the 3x3 taps that fall on the same source pixel summed -- four PHASE convolutions with 2x2 taps (K = 4 * Cin instead of 9 * Cin on 4x the
+  // pixels: 44 % of the flops and no upsampled grid in memory).  up_phase = 1 + 2 py + px (0: plain convolution): the A rows are the LOW-resolution
+  // padded grid [conv_hp][conv_wp], the taps are 2 x 2 starting at (py - 1, px - 1), and the epilogue scatters row (yy, xx) to pixel
+  // (2 yy + py - 1, 2 xx + px - 1) of the [2 conv_hp - 2][2 conv_wp - 2] output grid (border pixels as zeros, positions outside dropped).
+  int32_t up_phase;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 

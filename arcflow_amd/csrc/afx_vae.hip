@@ -373,6 +373,29 @@ int afx_conv3x3_bf16_stats(const void* x, const void* w, const void* bias, void*
   return conv3x3_impl(x, w, bias, y, H, W, Cin, Cout, res, gn_stats, groups, stream);
 }
 
+int afx_upconv3x3_bf16(const void* x, const void* w4, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream) {
+  // y = conv3x3(upsample_nearest_2x(x)) + bias without the upsampled grid: x is the LOW-resolution zero-bordered grid [(H+2)*(W+2), Cin] (guard rows
+  // as for afx_conv3x3_bf16), y the [(2H+2)*(2W+2), Cout] grid, w4 = the four phase kernels [2 py + px][Cout][2][2][Cin] bf16 (the 3x3 taps that fall
+  // on the same source pixel summed: arcflow_amd.vae.phase_weights).  One launch of four problems on the one-wave-per-SIMD kernel.
+  if (!x || !w4 || !y || H < 1 || W < 1 || Cin < 64 || Cin % 64 || Cout < 8 || Cout % 8)
+    return fail(AFX_E_INVALID, "afx_upconv3x3_bf16: need Cin %% 64 == 0, Cout %% 8 == 0");
+  if (!gemm_conv_stats_available()) return fail(AFX_E_INVALID, "afx_upconv3x3_bf16 needs the one-wave-per-SIMD GEMM (AFX_GEMM_IMPL=3, no forced tile)");
+  if ((int64_t)(2 * H + 2) * (2 * W + 2) * Cout * 2 >= (1ll << 31)) return fail(AFX_E_INVALID, "afx_upconv3x3_bf16: output grid >= 2 GiB");
+  GemmBatch gb{};
+  gb.nprob = 4;
+  for (int ph = 0; ph < 4; ++ph) {
+    GemmProblem& p = gb.p[ph];
+    p = GemmProblem{};
+    p.A = (const uint16_t*)x; p.lda = Cin; p.W = (const uint16_t*)w4 + (int64_t)ph * Cout * 4 * Cin; p.ldw = 4 * (int64_t)Cin; p.bias = (const uint16_t*)bias;
+    p.C = (uint16_t*)y; p.ldc = Cout; p.M = (H + 2) * (W + 2); p.N = Cout; p.K = 4 * Cin;
+    p.rows_per_batch = 1 << 30;
+    p.conv_cin_tiles = Cin / 64; p.conv_wp = W + 2; p.conv_hp = H + 2;
+    p.up_phase = 1 + ph;
+  }
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int afx_conv_stats_available(void) { return gemm_conv_stats_available() ? 1 : 0; }
 
 

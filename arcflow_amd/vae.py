@@ -62,6 +62,34 @@ class _GridPool:
         return _Grid(H, W, Cn, self.dev, buf)
 
 
+def phase_weights(wp9: torch.Tensor, cin: int) -> torch.Tensor:
+    """[Cout, 9 * cin] (tap-major 3x3 kernel, the layout of afx_conv3x3_bf16) -> [4, Cout, 4 * cin]: the four 2x2 kernels of
+    conv3x3(nearest-2x upsample(.)) acting on the LOW-resolution grid.  Output pixel (2y + py, 2x + px) reads source rows {y - 1 + py, y + py}:
+    for py = 0 the taps dy = -1 | {0, +1} fall on them, for py = 1 the taps {-1, 0} | +1 (the same in x); taps on one source pixel add up
+    (in fp32, rounded once to bf16).  Phase index 2 py + px, tap index 2 ty + tx: the layout afx_upconv3x3_bf16 expects."""
+    co = wp9.shape[0]
+    w = wp9.float().reshape(co, 3, 3, cin)
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}                   # phase -> 3x3 tap indices landing on source row 0 / 1 of the 2x2 footprint
+    out = torch.zeros(4, co, 2, 2, cin, dtype=torch.float32, device=wp9.device)
+    for py in (0, 1):
+        for px in (0, 1):
+            for ty in (0, 1):
+                for tx in (0, 1):
+                    acc = 0
+                    for a in rows[py][ty]:
+                        for b in rows[px][tx]:
+                            acc = acc + w[:, a, b]
+                    out[2 * py + px, :, ty, tx] = acc
+    return out.reshape(4, co, 4 * cin).to(torch.bfloat16).contiguous()
+
+
+def _upconv(lib, pool, x: "_Grid", w4: torch.Tensor, b: torch.Tensor) -> "_Grid":
+    """conv3x3(nearest-2x upsample(x)) + b through afx_upconv3x3_bf16: the upsampled grid is never written."""
+    y = pool.grid(2 * x.H, 2 * x.W, w4.shape[1])
+    _lib.check(lib.afx_upconv3x3_bf16(_p(x.t), _p(w4), _p(b), _p(y.t), x.H, x.W, x.C, w4.shape[1], _s()))
+    return y
+
+
 def _single_head_attention(lib, xn: _Grid, x: _Grid, w_qkv, b_qkv, w_out, b_out, scale: float) -> _Grid:
     """x + proj(softmax(q k^T * scale) v) over the H*W pixels of a grid (xn = normalised x): two MFMA GEMMs around an fp32
     row softmax.  The token count is padded to a multiple of 64 for the GEMM contraction; padded keys get P = 0."""
@@ -118,6 +146,11 @@ class AutoencoderKLDecoder:
         a = 'decoder.mid_block.attentions.0.'
         self.w[a + 'qkv.weight'] = torch.cat([self.w[a + n + '.weight'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
         self.w[a + 'qkv.bias'] = torch.cat([self.w[a + n + '.bias'] for n in ('to_q', 'to_k', 'to_v')]).contiguous()
+        # nearest-2x upsample folded into the upsamplers' convolutions (four 2x2 phase kernels on the low-resolution grid)
+        self._fold_up = bool(self.lib.afx_conv_stats_available()) and os.environ.get('AFX_VAE_FOLD_UPSAMPLE', '1') != '0'     # (0: A/B runs)
+        if self._fold_up:
+            for k in [k for k in self.w if '.upsamplers.0.conv.weight' in k]:
+                self.w[k[:-len('.weight')] + '.weight4'] = phase_weights(self.w[k], self.w[k].shape[1] // 9)
         self._stats = torch.zeros(128 + 2048, dtype=torch.float64, device=self.dev)   # 2*groups doubles + 2*C floats
         self._pool = _GridPool(self.dev)
         # GroupNorm sums out of the producing convolution's epilogue: a ring of slotted buffers (a grid's sums live until its norm ran:
@@ -181,9 +214,13 @@ class AutoencoderKLDecoder:
             for j in range(self.lpb + 1):
                 x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
             if i < n - 1:
-                up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
-                _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
-                x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.conv', up, 0)
+                un = f'decoder.up_blocks.{i}.upsamplers.0.conv'
+                if self._fold_up:
+                    x = _upconv(self.lib, self._pool, x, self.w[un + '.weight4'], self.w[un + '.bias'])
+                else:
+                    up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
+                    _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
+                    x = self._conv(un, up, 0)
         x = self._conv('decoder.conv_out', self._gn('decoder.conv_norm_out', x, True), 0, stats=False)
         img = torch.empty(3, x.H, x.W, dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.afx_nhwc_to_image(_p(x.t), _p(img), x.H, x.W, x.C, _s()))
@@ -246,6 +283,10 @@ class AutoencoderKLQwenImageDecoder:
         wq = sd['post_quant_conv.weight'].float().reshape(16, 16)
         std, mean = torch.tensor(self.latents_std, dtype=torch.float32), torch.tensor(self.latents_mean, dtype=torch.float32)
         self._pool = _GridPool(self.dev)
+        self._fold_up = bool(self.lib.afx_conv_stats_available()) and os.environ.get('AFX_VAE_FOLD_UPSAMPLE', '1') != '0'
+        if self._fold_up:
+            for k in [k for k in self.w if '.upsamplers.0.resample.1.weight' in k]:
+                self.w[k[:-len('.weight')] + '.weight4'] = phase_weights(self.w[k], self.w[k].shape[1] // 9)
         self._A = (wq * std[None, :]).contiguous().to(self.dev)
         self._b = (wq @ mean + sd['post_quant_conv.bias'].float()).contiguous().to(self.dev)
 
@@ -286,9 +327,13 @@ class AutoencoderKLQwenImageDecoder:
             for j in range(self.nrb + 1):
                 x = self._resnet(f'decoder.up_blocks.{i}.resnets.{j}.', x)
             if i != self.n_up - 1:
-                up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
-                _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
-                x = self._conv(f'decoder.up_blocks.{i}.upsamplers.0.resample.1', up)
+                un = f'decoder.up_blocks.{i}.upsamplers.0.resample.1'
+                if self._fold_up:
+                    x = _upconv(self.lib, self._pool, x, self.w[un + '.weight4'], self.w[un + '.bias'])
+                else:
+                    up = self._pool.grid(2 * x.H, 2 * x.W, x.C)
+                    _lib.check(self.lib.afx_upsample2x_nhwc(_p(x.t), _p(up.t), x.H, x.W, x.C, _s()))
+                    x = self._conv(un, up)
         x = self._conv('decoder.conv_out', self._norm('decoder.norm_out', x, True))
         img = torch.empty(3, x.H, x.W, dtype=torch.float32, device=self.dev)
         _lib.check(self.lib.afx_nhwc_to_image(_p(x.t), _p(img), x.H, x.W, x.C, _s()))

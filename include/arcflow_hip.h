@@ -289,6 +289,11 @@ int afx_conv3x3_bf16_stats(const void* x, const void* w, const void* bias, void*
 int afx_groupnorm_nhwc_from_stats(const void* x, void* y, const double* gn_stats, double* stats_ws, int32_t H, int32_t W, int32_t C,
                                   int32_t groups, const float* gamma, const float* beta, float eps, int32_t act, void* stream);
 int afx_conv_stats_available(void);
+/* y = conv3x3(nearest-2x upsample(x)) + bias with the upsample FOLDED into the convolution (diffusers Upsample2D: F.interpolate(nearest) then conv,
+ * reached through vae.decode, arcflux_pipeline.py:531-534): x = the low-resolution zero-bordered grid [(H+2)*(W+2), Cin], y = [(2H+2)*(2W+2), Cout],
+ * w4 = four 2x2 phase kernels [2 py + px][Cout][2][2][Cin] bf16 built from the 3x3 weight (arcflow_amd.vae.phase_weights): 44 % of the flops of the
+ * convolution on the upsampled grid, which is never written.  Needs afx_conv_stats_available() (the one-wave-per-SIMD GEMM). */
+int afx_upconv3x3_bf16(const void* x, const void* w4, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin, int32_t Cout, void* stream);
 int afx_upsample2x_nhwc(const void* x, void* y, int32_t H, int32_t W, int32_t C, void* stream);
 /* scatter == 0: compact[H*W, C] = interior(padded);  != 0: interior(padded) = compact (+ interior(res_padded)) */
 int afx_interior_nhwc(void* padded, void* compact, const void* res_padded, int32_t H, int32_t W, int32_t C, int32_t scatter,

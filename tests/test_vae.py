@@ -262,3 +262,33 @@ def test_softmax_rows_both_kernels(rows, cols):
     err = ((p.double() - ref).abs() / ref.clamp(min=1e-30)).max().item()
     assert err < 2.0 ** -7, err
     assert abs(p.double().sum(-1) - 1).max().item() < 2e-3
+
+
+@pytest.mark.parametrize('H,W,ci,co', [(5, 7, 64, 72), (16, 9, 128, 256), (33, 20, 64, 128)])
+def test_upsample_folded_into_conv_vs_torch(H, W, ci, co):
+    """afx_upconv3x3_bf16 = conv3x3(nearest-2x upsample(x)) as four 2x2 phase convolutions on the low-resolution grid (diffusers Upsample2D:
+    F.interpolate(scale_factor=2, mode='nearest') then conv): against torch on the same bf16 inputs; the 2x grid's border stays zero and every
+    interior pixel is written (the output buffer starts as NaN)."""
+    from arcflow_amd import _lib
+    from arcflow_amd.vae import _Grid, _p, _s, phase_weights
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H * W + co)
+    x = torch.randn(1, ci, H, W, generator=g).bfloat16()
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.05).bfloat16()
+    b = torch.randn(co, generator=g).bfloat16()
+    gx, gy = _Grid(H, W, ci, 'cuda'), _Grid(2 * H, 2 * W, co, 'cuda')
+    gx.t.view(H + 2, W + 2, ci)[1:-1, 1:-1] = x[0].permute(1, 2, 0).cuda()
+    gy.t.fill_(float('nan'))
+    w9 = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous().cuda()
+    w4 = phase_weights(w9, ci)
+    assert w4.shape == (4, co, 4 * ci)
+    _lib.check(lib.afx_upconv3x3_bf16(_p(gx.t), _p(w4), _p(b.cuda()), _p(gy.t), H, W, ci, co, _s()))
+    out = gy.t.view(2 * H + 2, 2 * W + 2, co)
+    assert torch.isfinite(out.float()).all()                                   # every position of the 2x grid was written
+    up = torch.nn.functional.interpolate(x.float(), scale_factor=2, mode='nearest')
+    ref = torch.nn.functional.conv2d(up, wt.float(), b.float(), padding=1)[0]
+    got = out[1:-1, 1:-1].permute(2, 0, 1).float().cpu()
+    # the phase kernels are sums of up to four bf16 taps rounded once more to bf16: 2^-8 relative on the weights
+    assert ((got - ref).norm() / ref.norm()).item() < 8e-3, ((got - ref).norm() / ref.norm()).item()
+    border = torch.cat([out[0].flatten(), out[-1].flatten(), out[:, 0].flatten(), out[:, -1].flatten()])
+    assert border.abs().max().item() == 0
