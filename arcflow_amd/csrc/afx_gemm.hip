@@ -1559,6 +1559,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
                p.split_k <= 1 && p.N == batch.p[0].N && (p.up_phase == 0 || (p.epi == EPI_NONE && p.gn_stats == nullptr));
   }
   if (conv_all) {
+    // 256x128 tiles for the <= 128-channel layers only: for the 128^2 stage (134 tiles of 256x256 for 256 CUs, K = 4608) 268 narrow tiles measured
+    // 116 us per launch against 93
     const bool narrow = batch.p[0].N <= 128;
     const int total = count_tiles(batch, 256, narrow ? 128 : 256, true);
     batch.total_tiles = total;

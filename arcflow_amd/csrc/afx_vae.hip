@@ -60,29 +60,28 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict_
     atomicAdd(&part[g1][0], s1); atomicAdd(&part[g1][1], q1);
   }
   __syncthreads();
+  // 2048 blocks adding to the same 2 * groups doubles serialise in the L2's atomic unit: 93 us for a 17 MB grid.  One of GN_SLOTS copies per
+  // block (gn_coeff_kernel folds them): 32 atomics per address instead of 2048.
   if (threadIdx.x < groups) {
-    atomicAdd(stats + threadIdx.x * 2, (double)part[threadIdx.x][0]);
-    atomicAdd(stats + threadIdx.x * 2 + 1, (double)part[threadIdx.x][1]);
+    double* dst = stats + ((int64_t)(blockIdx.x % GN_SLOTS) * groups + threadIdx.x) * 2;
+    atomicAdd(dst, (double)part[threadIdx.x][0]);
+    atomicAdd(dst + 1, (double)part[threadIdx.x][1]);
   }
 }
 
-// the convolution epilogue's slotted partial sums -> stats[2 * groups]
-__global__ void gn_sum_slots_kernel(const double* __restrict__ slots, int groups, double* __restrict__ stats) {
-  const int i = threadIdx.x;
-  if (i >= 2 * groups) return;
-  double a = 0.0;
-  for (int s = 0; s < GN_SLOTS; ++s) a += slots[(int64_t)s * 2 * groups + i];
-  stats[i] = a;
-}
-
-// per-channel affine of the normalisation: y = x * coef[c] + coef[C + c]
+// stats: [GN_SLOTS][groups][2] partial sums (the statistics kernel's or a convolution epilogue's)
 __global__ void gn_coeff_kernel(const double* __restrict__ stats, double count, int C, int groups, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float eps, float* __restrict__ coef) {
   const int ch = blockIdx.x * blockDim.x + threadIdx.x;
   if (ch >= C) return;
   const int gi = ch / (C / groups);
-  const double mean = stats[gi * 2] / count;
-  const double var = stats[gi * 2 + 1] / count - mean * mean;
+  double s0 = 0.0, s1 = 0.0;                                     // fold the GN_SLOTS partial sums of this channel's group
+  for (int sl = 0; sl < GN_SLOTS; ++sl) {
+    s0 += stats[((int64_t)sl * groups + gi) * 2];
+    s1 += stats[((int64_t)sl * groups + gi) * 2 + 1];
+  }
+  const double mean = s0 / count;
+  const double var = s1 / count - mean * mean;
   const float a = rsqrtf((float)var + eps) * gamma[ch];
   coef[ch] = a;
   coef[C + ch] = beta[ch] - (float)mean * a;
@@ -401,18 +400,20 @@ int afx_conv_stats_available(void) { return gemm_conv_stats_available() ? 1 : 0;
 
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
+  // stats_ws layout (doubles): [0, 2 groups) the sums | [2 groups, 2 groups + C) the 2 C float coefficients | then AFX_GN_SLOTS x 2 groups slot partials
   if (!x || !y || !stats_ws || !gamma || !beta || C % 8 || groups < 1 || groups > 64 || C % groups || (C / groups) % 4 || 256 % (C >> 3))
     return fail(AFX_E_INVALID, "bad argument to afx_groupnorm_nhwc");
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = (int64_t)(H + 2) * (W + 2);
   if (C > 2048) return fail(AFX_E_INVALID, "afx_groupnorm_nhwc: C <= 2048");
-  HIP_TRY(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * groups, st));
+  double* slots = stats_ws + 2 * groups + C;
+  HIP_TRY(hipMemsetAsync(slots, 0, sizeof(double) * 2 * groups * GN_SLOTS, st));
   const int rstep = 256 / (C >> 3);
   const unsigned nblk = (unsigned)std::min<int64_t>(2048, (rows + rstep - 1) / rstep);
   float* coef = reinterpret_cast<float*>(stats_ws + 2 * groups);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, rows, C, groups, stats_ws);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(256), 0, st, (const bf16_t*)x, rows, C, groups, slots);
   const double count = (double)H * W * (C / groups);
-  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, count, C, groups, gamma, beta, eps, coef);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slots, count, C, groups, gamma, beta, eps, coef);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(4096, (rows + rstep - 1) / rstep)), dim3(256), 0, st,
                      (const bf16_t*)x, (bf16_t*)y, rows, C, coef, act, H + 2, W + 2);
   HIP_TRY(hipGetLastError());
@@ -428,9 +429,8 @@ int afx_groupnorm_nhwc_from_stats(const void* x, void* y, const double* gn_stats
   const int64_t rows = (int64_t)(H + 2) * (W + 2);
   const int rstep = 256 / (C >> 3);
   float* coef = reinterpret_cast<float*>(stats_ws + 2 * groups);
-  hipLaunchKernelGGL(gn_sum_slots_kernel, dim3(1), dim3(128), 0, st, gn_stats, groups, stats_ws);
   const double count = (double)H * W * (C / groups);
-  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, count, C, groups, gamma, beta, eps, coef);
+  hipLaunchKernelGGL(gn_coeff_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gn_stats, count, C, groups, gamma, beta, eps, coef);
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)std::min<int64_t>(4096, (rows + rstep - 1) / rstep)), dim3(256), 0, st,
                      (const bf16_t*)x, (bf16_t*)y, rows, C, coef, act, H + 2, W + 2);
   HIP_TRY(hipGetLastError());

@@ -273,7 +273,8 @@ int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
  * re-zeroes the border.  x must be readable (W+3) rows before and after the grid.  w: [Cout][3][3][Cin] bf16. */
 int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
                      int32_t Cout, const void* res, void* stream);
-/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: 2*groups doubles + 2*C floats of scratch; act 1 = SiLU;
+#define AFX_GN_SLOTS 64
+/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: (2 + 2*AFX_GN_SLOTS)*groups + C doubles of scratch; act 1 = SiLU;
  * C/8 must divide 256 (C = 64, 128, 256, 512, 1024, 2048) */
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream);
@@ -283,7 +284,6 @@ int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int3
  * then normalises y without a statistics pass of its own (diffusers' ResnetBlock2D order norm -> act -> conv: every GroupNorm input of the
  * decoder except the attention output is a convolution output).  afx_conv_stats_available(): 0 when the GEMM kernel override in force has no
  * such epilogue (AFX_GEMM_IMPL=1). */
-#define AFX_GN_SLOTS 64
 int afx_conv3x3_bf16_stats(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                            const void* res, double* gn_stats, int32_t groups, void* stream);
 int afx_groupnorm_nhwc_from_stats(const void* x, void* y, const double* gn_stats, double* stats_ws, int32_t H, int32_t W, int32_t C,

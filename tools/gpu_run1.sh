@@ -1,2 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_vae.py tests/test_pipeline.py tests/test_inference_script.py -m gpu -q -x 2>&1 | tail -4
+for i in 1 2 3; do timeout 300 python tools/vae_bench.py qwen 2>&1 | tail -1; done
+for i in 1 2; do AFX_VAE_FOLD_UPSAMPLE=0 timeout 300 python tools/vae_bench.py qwen 2>&1 | tail -1; done
+for i in 1 2; do timeout 300 python tools/vae_bench.py 2>&1 | tail -2; done

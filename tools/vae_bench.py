@@ -22,7 +22,10 @@ def timeit(fn, n=5):
 
 
 tok = torch.randn(1, 4096, 64, device='cuda')
-flux = AutoencoderKLDecoder(vae_ref.make_decoder_weights((128, 256, 512, 512), seed=0), (128, 256, 512, 512))
-print(f'FLUX AutoencoderKL decoder        1024^2: {timeit(lambda: flux.decode_packed(tok, 64, 64)):.1f} ms')
-qwen = AutoencoderKLQwenImageDecoder(vae_qwen_ref.make_decoder_weights(dim=96, seed=0), [0.0] * 16, [1.0] * 16)
-print(f'Qwen AutoencoderKLQwenImage decoder 1024^2: {timeit(lambda: qwen.decode_packed(tok, 64, 64)):.1f} ms')
+which = sys.argv[1] if len(sys.argv) > 1 else 'both'
+if which in ('both', 'flux'):
+  flux = AutoencoderKLDecoder(vae_ref.make_decoder_weights((128, 256, 512, 512), seed=0), (128, 256, 512, 512))
+  print(f'FLUX AutoencoderKL decoder        1024^2: {timeit(lambda: flux.decode_packed(tok, 64, 64)):.1f} ms')
+if which in ('both', 'qwen'):
+  qwen = AutoencoderKLQwenImageDecoder(vae_qwen_ref.make_decoder_weights(dim=96, seed=0), [0.0] * 16, [1.0] * 16)
+  print(f'Qwen AutoencoderKLQwenImage decoder 1024^2: {timeit(lambda: qwen.decode_packed(tok, 64, 64)):.1f} ms')
