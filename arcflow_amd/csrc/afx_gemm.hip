@@ -1466,7 +1466,7 @@ bool gemm_qk_fusion_available() {
 }
 void gemm_set_mode(int impl, int tile) {
   gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;
-  gemm_mode().tile = (tile >= 0 && tile <= 5) ? tile : 0;
+  gemm_mode().tile = (tile >= 0 && tile <= 6) ? tile : 0;
 }
 struct TileCfg { int tm, tn, group_m; };
 // {4,4} = 128x128: 64 accumulators and 80 KiB of LDS, TWO work-groups per CU -- for launches that would leave most CUs without a
@@ -1474,7 +1474,9 @@ struct TileCfg { int tm, tn, group_m; };
 // {8,7} = 256x224: the shape that makes the forward's N = 3072 launches (18 row tiles of the 4096 + 512 row problems x 14 column
 // tiles = 252) and the N = 12288 launch (990 tiles = 3.87 rounds of 7/8-size tiles) fill their last round -- what hipBLASLt's
 // MT256x224 kernels do for these shapes (1295 vs 1161 TF at 4608 x 3072 x 3072 in profiles/r02s_microbench.log)
-static const TileCfg kTileCfg[5] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}, {128, 128, 8}, {256, 224, GROUP_M}};
+// {7,8} = 224x256: the k|q|v^T launch of the Qwen-Image shape (4096 + 128 rows: 612 tiles of 256x256 = 2.39 rounds -> 718 tiles of 7/8 the size =
+// 2.8 rounds); a wave keeps its 128 columns = one head, so the fused q / k epilogue works unchanged (FLUX's 4096 + 512 rows stay 256x256: 648 tiles)
+static const TileCfg kTileCfg[6] = {{256, 256, GROUP_M}, {288, 192, 5}, {320, 192, 4}, {128, 128, 8}, {256, 224, GROUP_M}, {224, 256, GROUP_M}};
 
 static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   int total = 0;
@@ -1521,7 +1523,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (const char* g = getenv("AFX_GEMM_GROUP_M")) group_m_env = atoi(g) > 0 ? atoi(g) : 0;
     // AFX_GEMM_IMPL: 1 = simple 2-stage kernel (reference / A-B), 2 = 8-phase kernel only, 3 (default) = one-wave-per-SIMD kernel
     // for the forward's bf16 epilogue modes (8-phase for everything else).  AFX_GEMM_TILE (impl 3): 0 = pick per launch,
-    // 1 / 2 / 3 = force 256x256 / 288x192 / 320x192.  afx_gemm_set_mode() overrides both (parity tests, A/B runs).
+    // 1 ... 6 = force 256x256 / 288x192 / 320x192 / 128x128 / 256x224 / 224x256.  afx_gemm_set_mode() overrides both (parity tests, A/B runs).
     if (impl < 0) {
       const char* e = getenv("AFX_GEMM_IMPL");
       impl = (e && e[0] == '1') ? 1 : (e && e[0] == '2') ? 2 : 3;
@@ -1589,8 +1591,21 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     int best = 0;
     bool f32_any = false;                               // fp32-output launches: the shapes with an even number of column tiles per wave only
     for (int i = 0; i < batch.nprob; ++i) f32_any = f32_any || batch.p[i].out_f32 != 0;
-    if (qk) best = 0;                                   // one head = one wave's 128 columns: the 256x256 shape only
-    else if (tile_env >= 1 && tile_env <= 5) best = (tile_env == 5 && f32_any) ? 0 : tile_env - 1;
+    if (qk) {                                           // one head = one wave's 128 columns: the two 256-wide shapes only
+      best = 0;
+      if (tile_env == 6) best = 5;
+      else if (tile_env == 0) {
+        const int t0 = count_tiles(batch, 256, 256, false), t5 = count_tiles(batch, 224, 256, false);
+        if (t0 == 0) return hipSuccess;
+        static double pen_qk224 = -1;
+        if (pen_qk224 < 0) {
+          const char* e = getenv("AFX_GEMM_PEN_QK224");   // A/B knob (1e9 = never)
+          pen_qk224 = e ? atof(e) : 1.03;
+        }
+        const double c0 = (double)((t0 + cus - 1) / cus) * 256, c5 = (double)((t5 + cus - 1) / cus) * 224 * pen_qk224;
+        if (c5 < c0) best = 5;
+      }
+    } else if (tile_env >= 1 && tile_env <= 6) best = (tile_env == 5 && f32_any) ? 0 : tile_env - 1;
     else {
       double best_cost = 0;
       int tiles256 = 0;
@@ -1627,7 +1642,7 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     batch.sk_cus = 0;
     return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream)
          : best == 2 ? launch_v3<10, 6>(batch, total, stream) : best == 3 ? launch_v3<4, 4>(batch, total, stream)
-         : launch_v3<8, 7>(batch, total, stream);
+         : best == 4 ? launch_v3<8, 7>(batch, total, stream) : launch_v3<7, 8>(batch, total, stream);
   }
   int total = count_tiles(batch, BM, BN, true);
   batch.total_tiles = total;

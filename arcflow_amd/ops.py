@@ -62,7 +62,7 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 def set_gemm_mode(impl: int = 3, tile: int = 0) -> None:
     """Kernel / tile-shape override of every bf16 GEMM (``afx_gemm_set_mode``): impl 3 = one-wave-per-SIMD kernel with tile 0 = picked
-    per launch, 1 / 2 / 3 / 4 / 5 = 256x256 / 288x192 / 320x192 / 128x128 / 256x224; impl 2 = 8-phase 256x256 kernel; impl 1 = simple reference kernel."""
+    per launch, 1 ... 6 = 256x256 / 288x192 / 320x192 / 128x128 / 256x224 / 224x256; impl 2 = 8-phase 256x256 kernel; impl 1 = simple reference kernel."""
     _lib.check(_lib.load().afx_gemm_set_mode(impl, tile))
 
 

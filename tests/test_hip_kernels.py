@@ -32,9 +32,9 @@ def bf(t):
 
 # ------------------------------------------------------------------------------------------ GEMM
 # (impl, tile) of afx_gemm_set_mode: the one-wave-per-SIMD kernel with the tile shape picked per launch / forced to 256x256 /
-# 288x192 / 320x192 / 128x128, and the 8-phase 256x256 kernel.  Every mode must give the same results on the same inputs.
-GEMM_MODES = [(3, 0), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (2, 0)]
-GEMM_MODE_IDS = ['auto', 'v3-256x256', 'v3-288x192', 'v3-320x192', 'v3-128x128', 'v3-256x224', '8phase']
+# 288x192 / 320x192 / 128x128 / 256x224 / 224x256, and the 8-phase 256x256 kernel.  Every mode must give the same results on the same inputs.
+GEMM_MODES = [(3, 0), (3, 1), (3, 2), (3, 3), (3, 4), (3, 5), (3, 6), (2, 0)]
+GEMM_MODE_IDS = ['auto', 'v3-256x256', 'v3-288x192', 'v3-320x192', 'v3-128x128', 'v3-256x224', 'v3-224x256', '8phase']
 
 
 @pytest.fixture
