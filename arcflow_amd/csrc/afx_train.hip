@@ -9,6 +9,10 @@
 #include <algorithm>
 
 #include "afx_api_util.h"
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -389,30 +393,44 @@ __global__ __launch_bounds__(256) void gemv_t_kernel(const float* __restrict__ x
 
 // AdaLayerNormContinuous backward w.r.t. its modulation:  xn = LN(x) (1 + scale) + shift
 //   d_scale[b, c] += sum_rows dxn * LN(x),   d_shift[b, c] += sum_rows dxn     (rows of batch b)
-// One wave per row computes the row statistics, then every lane adds its 8-column chunks atomically into the
-// [B, 2, D] fp32 result (scale first, like the reference's chunk order).
+// A wave computes the row statistics of its rows_per_wave rows and keeps its 8-column chunks' sums in registers; the per-wave [2][D]
+// partials are folded into the [B, 2, D] fp32 result by normout_reduce_kernel (scale first, like the reference's chunk order).
 __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restrict__ x, int64_t ldx,
-                                                          const bf16_t* __restrict__ dxn, int64_t ldd, float* __restrict__ dmod,
+                                                          const bf16_t* __restrict__ dxn, int64_t ldd, float* __restrict__ part,
                                                           int rows, int D, int rows_per_batch, int rows_per_wave) {
   const int lane = threadIdx.x & 63;
   const int wv = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int row0 = wv * rows_per_wave;
   const bool active = row0 < rows;
   const int nchunk = D >> 3;
-  const int b = active ? row0 / rows_per_batch : 0;   // rows_per_wave divides rows_per_batch
   float ds[8][8], dh[8][8];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ds[i][e] = dh[i][e] = 0.f;
-  for (int row = row0; active && row < min(rows, row0 + rows_per_wave); ++row) {
+  // the next row's x and dxn chunks are requested before the current row is reduced (two dependent wave reductions per row)
+  const int row_end = active ? min(rows, row0 + rows_per_wave) : row0;
+  u32x4_t xc[8], dc[8], xn[8], dn[8];
+  auto fetch = [&](int row, u32x4_t (&xa)[8], u32x4_t (&da)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = lane + i * 64;
+      if (c < nchunk) {
+        xa[i] = *reinterpret_cast<const u32x4_t*>(x + (int64_t)row * ldx + c * 8);
+        da[i] = *reinterpret_cast<const u32x4_t*>(dxn + (int64_t)row * ldd + c * 8);
+      }
+    }
+  };
+  if (row0 < row_end) fetch(row0, xc, dc);
+  for (int row = row0; row < row_end; ++row) {
+    if (row + 1 < row_end) fetch(row + 1, xn, dn);
     float v[8][8];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
-        unpack8(*reinterpret_cast<const u32x4_t*>(x + (int64_t)row * ldx + c * 8), v[i]);
+        unpack8(xc[i], v[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[i][e];
       }
@@ -436,7 +454,7 @@ __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restri
       const int c = lane + i * 64;
       if (c < nchunk) {
         float gr[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(dxn + (int64_t)row * ldd + c * 8), gr);
+        unpack8(dc[i], gr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           ds[i][e] += gr[e] * (v[i][e] - mean) * rstd;
@@ -444,29 +462,43 @@ __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restri
         }
       }
     }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xc[i] = xn[i]; dc[i] = dn[i]; }
   }
-  // combine the 4 waves of the block in LDS (they almost always belong to one batch entry): one global atomic set per block
-  extern __shared__ float red[];                 // [2][D]
-  __shared__ int b_blk;
-  if (threadIdx.x == 0) b_blk = b;               // wave 0 of a launched block always has rows
-  for (int j = threadIdx.x; j < 2 * D; j += 256) red[j] = 0.f;
-  __syncthreads();
+  // every wave stores its [2][D] partial sums (plain, coalesced stores); normout_reduce_kernel folds the waves of a batch entry.  (The first
+  // version combined the work-group's waves with LDS float atomics and added one atomic set per work-group to the result: 176 us for a
+  // 4608 x 3072 call with 32 rows per wave, 60-86 us with 4-8 -- device-scope float atomics are performed at the memory side.)
   if (active) {
-    float* dst0 = b == b_blk ? red : dmod + (int64_t)b * 2 * D;
+    float* dst = part + (int64_t)wv * 2 * D;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int c = lane + i * 64;
       if (c < nchunk) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          atomicAdd(dst0 + c * 8 + e, ds[i][e]);
-          atomicAdd(dst0 + D + c * 8 + e, dh[i][e]);
-        }
+        *reinterpret_cast<f32x4_t*>(dst + c * 8) = (f32x4_t){ds[i][0], ds[i][1], ds[i][2], ds[i][3]};
+        *reinterpret_cast<f32x4_t*>(dst + c * 8 + 4) = (f32x4_t){ds[i][4], ds[i][5], ds[i][6], ds[i][7]};
+        *reinterpret_cast<f32x4_t*>(dst + D + c * 8) = (f32x4_t){dh[i][0], dh[i][1], dh[i][2], dh[i][3]};
+        *reinterpret_cast<f32x4_t*>(dst + D + c * 8 + 4) = (f32x4_t){dh[i][4], dh[i][5], dh[i][6], dh[i][7]};
       }
     }
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < 2 * D; j += 256) atomicAdd(dmod + (int64_t)b_blk * 2 * D + j, red[j]);
+}
+
+// dmod[b][j] += sum over the waves w of batch entry b of part[w][j]; blockIdx.y splits a batch entry's waves, one atomic per (split, column)
+__global__ __launch_bounds__(256) void normout_reduce_kernel(const float* __restrict__ part, float* __restrict__ dmod, int waves_per_batch,
+                                                             int twoD, int splits) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= twoD) return;
+  const int b = blockIdx.y / splits, sp = blockIdx.y % splits;
+  const int per = (waves_per_batch + splits - 1) / splits;
+  const int w0 = sp * per, w1 = min(waves_per_batch, w0 + per);
+  const float* p = part + ((int64_t)b * waves_per_batch + w0) * twoD + j;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int w = w0;
+  for (; w + 3 < w1; w += 4, p += 4 * (int64_t)twoD) {
+    a0 += p[0]; a1 += p[twoD]; a2 += p[2 * (int64_t)twoD]; a3 += p[3 * (int64_t)twoD];
+  }
+  for (; w < w1; ++w, p += twoD) a0 += p[0];
+  atomicAdd(dmod + (int64_t)b * twoD + j, (a0 + a1) + (a2 + a3));
 }
 
 // dW[j, k] += sum_b dmod[b, j] * x[b, k]   (rank-B update of the norm_out.linear weight, B <= 8)
@@ -684,11 +716,37 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
                          int32_t D, int32_t rows_per_batch, void* stream) {
   if (!x || !dxn || !dmod_accum || rows < 1 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1 || rows % rows_per_batch)
     return fail(AFX_E_INVALID, "bad argument to afx_normout_backward");
-  int rpw = rows_per_batch >= 2048 ? 32 : 16;
+  // rows per wave: 8 (a 4608-row call = 576 waves on 256 CUs; the first version's 32 left it with 36 work-groups).  AFX_NORMOUT_RPW overrides.
+  static int rpw_env = -1;
+  if (rpw_env < 0) {
+    const char* e = getenv("AFX_NORMOUT_RPW");
+    rpw_env = e ? atoi(e) : 0;
+  }
+  int rpw = rpw_env > 0 ? rpw_env : 8;
   while (rows_per_batch % rpw) rpw >>= 1;
-  const int waves = rows / rpw;
-  hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream, (const bf16_t*)x, ldx,
-                     (const bf16_t*)dxn, ldd, dmod_accum, rows, D, rows_per_batch, rpw);
+  const int waves = rows / rpw, wpb = rows_per_batch / rpw, nb = rows / rows_per_batch;
+  hipStream_t st = (hipStream_t)stream;
+  // [waves][2][D] fp32 scratch, kept per stream and grown on demand (hipMallocAsync / hipFreeAsync per call cost ~20 us of the 30 us a 512-row
+  // call took); calls on one stream are ordered, so the buffer is free again when the next call's first kernel starts
+  static std::mutex ws_mu;
+  static std::map<hipStream_t, std::pair<float*, size_t>> ws_map;
+  float* part = nullptr;
+  {
+    std::lock_guard<std::mutex> lk(ws_mu);
+    auto& e = ws_map[st];
+    const size_t need = (size_t)waves * 2 * D * sizeof(float);
+    if (e.second < need) {
+      if (e.first != nullptr) HIP_TRY(hipFree(e.first));          // (synchronises: only when a larger shape shows up)
+      e.first = nullptr; e.second = 0;
+      HIP_TRY(hipMalloc((void**)&e.first, need));
+      e.second = need;
+    }
+    part = e.first;
+  }
+  hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dxn, ldd, part, rows, D,
+                     rows_per_batch, rpw);
+  const int splits = wpb >= 64 ? 8 : 1;
+  hipLaunchKernelGGL(normout_reduce_kernel, dim3((2 * D + 255) / 256, nb * splits), dim3(256), 0, st, part, dmod_accum, wpb, 2 * D, splits);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

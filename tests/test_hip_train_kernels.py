@@ -143,6 +143,23 @@ def test_normout_backward_and_outer(ops):
     close(dW, 1 + dflat.cpu().T @ semb, rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize('B,N,D', [(1, 4608, 3072), (2, 516, 3072), (3, 100, 1024)])
+def test_normout_backward_training_shapes(ops, B, N, D):
+    """The two-stage version (per-wave partial sums, then a fold over the waves of a batch entry) at the training shapes: many waves per
+    batch entry (split fold), a row count that forces fewer rows per wave (516 = 4 x 129), accumulation INTO a non-zero result."""
+    g = torch.Generator().manual_seed(B * N)
+    x = (torch.randn(B * N, D, generator=g) * 2 + 0.5).bfloat16()
+    dxn = torch.randn(B * N, D, generator=g).bfloat16()
+    xf = x.double().reshape(B, N, D)
+    ln = (xf - xf.mean(-1, keepdim=True)) / torch.sqrt(xf.var(-1, unbiased=False, keepdim=True) + 1e-6)
+    dsc = (dxn.double().reshape(B, N, D) * ln).sum(1)
+    dsh = dxn.double().reshape(B, N, D).sum(1)
+    start = torch.full((B, 2, D), 0.5, device='cuda')
+    dmod = ops.normout_backward(x.cuda(), dxn.cuda(), start.clone(), N)
+    close(dmod[:, 0] - 0.5, dsc.float(), rtol=2e-4, atol=2e-2)
+    close(dmod[:, 1] - 0.5, dsh.float(), rtol=2e-4, atol=2e-2)
+
+
 def test_adamw_ema_sumsq_cast(ops):
     g = torch.Generator().manual_seed(5)
     n = 100003
