@@ -20,6 +20,7 @@ Design for MI355X:
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Dict, List, Optional, Tuple
 
@@ -27,6 +28,9 @@ import torch
 
 from .. import _lib, ops
 from ..engine import MMDiTEngine
+
+
+_LORA_SPLITK = os.environ.get('ARCFLOW_LORA_SPLITK', '1') != '0'      # (0: A/B runs)
 
 
 def _p(t):
@@ -268,12 +272,21 @@ class LoraTrunk:
     def _site_seed(self, sp: LoraSpec) -> int:
         return (self.seed * 0x9E3779B1 + (sp.off_a * 2654435761 % (1 << 32))) & 0xffffffff
 
+    @staticmethod
+    def _skinny(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+        """x [M, K] @ w[r, K].T with r = the LoRA rank (256 columns): a launch of 8-72 tiles whose time is the length of its K loop.  For the
+        K >= 8192 sites (mlp1's dy B, mlp2's / proj_out's x A^T) eight K chunks into fp32 slabs + one fold pass halve it (101 -> 49 us at
+        4096 x 256 x 12288, 98 -> 34 us for the 512-row text stream; at K = 3072 the plain launch is as fast: tools/skinny_bench.py)."""
+        if w.shape[1] >= 8192 and _LORA_SPLITK:
+            return ops.linear_splitk(x, w, split_k=8 if x.shape[0] > 1024 else 16)
+        return ops.linear(x, w)
+
     def _corr(self, sp: Optional[LoraSpec], x: torch.Tensor, row_off: int) -> Optional[torch.Tensor]:
         """B A (x . delta): what lora_dropout adds to the merged-weight product (None without dropout / adapter)."""
         if sp is None or self.p_drop <= 0:
             return None
         xd = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=0)
-        return ops.linear(ops.linear(xd, self.a16[sp.name]), self.b16[sp.name])
+        return ops.linear(self._skinny(xd, self.a16[sp.name]), self.b16[sp.name])
 
     def _dx_extra(self, sp: Optional[LoraSpec], dT: Optional[torch.Tensor], dx: torch.Tensor, row_off: int) -> None:
         """dx += ((dy B) A) . delta -- the input gradient of the dropout correction."""
@@ -286,8 +299,8 @@ class LoraTrunk:
         Returns dy B [M, r]."""
         if self.p_drop > 0:
             x = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
-        t = ops.linear(x, self.a16[sp.name])                     # [M, r]
-        dT = ops.linear(dy, self.bt16[sp.name])                  # [M, r]
+        t = self._skinny(x, self.a16[sp.name])                   # [M, r]
+        dT = self._skinny(dy, self.bt16[sp.name])                # [M, r]
         xt, dyt = ops.transpose(x, 64), ops.transpose(dy, 64)    # contraction over the M tokens
         tt, dTt = ops.transpose(t, 64), ops.transpose(dT, 64)
         ops.linear_f32out(dyt, tt, out=self.B(sp, grads), accumulate=True)
