@@ -97,3 +97,27 @@ def test_weight_packing_and_lora_merge():
     ref = (w[name + '.weight'].float() + b.float() @ a.float()).bfloat16()
     assert torch.equal(merged[name + '.weight'], ref)
     assert merged['x_embedder.weight'] is w['x_embedder.weight']
+
+
+def test_phase_weights_reproduce_conv_of_nearest_upsample():
+    """arcflow_amd.vae.phase_weights (host logic of afx_upconv3x3_bf16): conv3x3(nearest-2x upsample(x)) == the four 2x2 phase convolutions on
+    the low-resolution input, interleaved -- in fp32 torch on the CPU (the kernel side is tests/test_vae.py::test_upsample_folded_into_conv_vs_torch)."""
+    import torch
+    from arcflow_amd.vae import phase_weights
+    g = torch.Generator().manual_seed(0)
+    co, ci, H, W = 8, 64, 5, 6
+    wt = (torch.randn(co, ci, 3, 3, generator=g) * 0.1).bfloat16()
+    x = torch.randn(1, ci, H, W, generator=g)
+    w9 = wt.permute(0, 2, 3, 1).reshape(co, 9 * ci).contiguous()
+    w4 = phase_weights(w9, ci).float().reshape(4, co, 2, 2, ci)
+    ref = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2, mode='nearest'), wt.float(), padding=1)[0]
+    xp = torch.nn.functional.pad(x, (1, 1, 1, 1))[0]                          # zero border, like the padded grid
+    out = torch.zeros(co, 2 * H, 2 * W)
+    for py in (0, 1):
+        for px in (0, 1):
+            k = w4[2 * py + px].permute(0, 3, 1, 2)                           # [co, ci, 2, 2]
+            # source rows {y - 1 + py, y + py} -> padded rows {y + py, y + py + 1}
+            ph = torch.nn.functional.conv2d(xp[None, :, py:py + H + 1, px:px + W + 1], k)[0]
+            out[:, py::2, px::2] = ph
+    # the phase kernels are sums of bf16 taps rounded once more to bf16
+    assert ((out - ref).norm() / ref.norm()).item() < 5e-3
