@@ -1,2 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for r in 1 2; do for g in 6 3 9 18; do echo -n "GROUP_M=$g "; AFX_GEMM_GROUP_M=$g timeout 300 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras 2>/dev/null | python tools/bench_brief.py; done; done
+mkdir -p gpurun_out
+timeout 1200 python tools/train.py examples/flux_distill_2nfe.py --synthetic --iters 4 --work-dir /tmp/soak --cfg-options train_cfg.student_fp8=True train_cfg.teacher_fp8=True checkpoint_config.interval=2 > gpurun_out/r03z_train_cli_soak_fp8.log 2>&1
+tail -8 gpurun_out/r03z_train_cli_soak_fp8.log | cut -c1-300
