@@ -243,7 +243,8 @@ class ArcFlowDistiller:
         return torch.full((B,), g, device=self.device)
 
     def _teacher_u(self, x, sigma, cond):
-        """Teacher velocity (GaussianFlow.forward_u, gaussian_flow.py:224-254): optional true CFG on a 2B batch."""
+        """Teacher velocity (GaussianFlow.forward_u, gaussian_flow.py:224-254).  True CFG: the reference runs ONE forward on a 2B batch [negative; positive];
+        here the two halves are two forwards of B samples each (per-sample results are identical, the engine's micro-batch holds at most 4 samples)."""
         xb = x.to(torch.bfloat16)
         g = self._guid(x.shape[0], teacher=True)
         if self.cfg.teacher_guidance_scale != 1.0 and 'negative_prompt_embeds' not in cond:
