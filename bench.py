@@ -288,7 +288,8 @@ def main(argv=None):
         line = infer_main(args, args.model, rank, world, dev, dist)
         if rank == 0 and world == 1 and args.model == 'flux' and not args.no_extras and not args.fp8 and args.streams == 1:
             # The driver times ONE default run: after the FLUX headline (whose timed region is over) the same process measures the
-            # other configs BASELINE.json names -- Qwen-Image inference (configs[2]) and one FLUX distillation iteration (configs[3]) --
+            # other configs BASELINE.json names -- Qwen-Image inference (configs[2]), one FLUX distillation iteration (configs[3]) and one Qwen-Image
+            # distillation iteration with the fp8 forwards (configs[4]) --
             # and attaches them as extra objects.  The headline's value / ms_per_step / steps are untouched.
             import gc
             gc.collect()
@@ -304,6 +305,16 @@ def main(argv=None):
             t = train_main(ex, rank, world, dev, dist)
             line['train_flux'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
                                                     'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}
+            gc.collect()
+            torch.cuda.empty_cache()
+            del t
+            # configs[4]: Qwen-Image distillation, true-CFG teacher, "fp8 MFMA fwd + bf16 grads" (teacher and student forwards on the e4m3 MFMA;
+            # says so in its dtype -- reduced precision, an extra object, never the headline)
+            ex.model, ex.teacher_fp8, ex.student_fp8 = 'qwen', True, True
+            t = train_main(ex, rank, world, dev, dist)
+            line['train_qwen_fp8'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
+                                                        'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}
+            del t
             gc.collect()
             torch.cuda.empty_cache()
         if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -1,4 +1,12 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python tools/train.py examples/flux_distill_2nfe.py --synthetic --iters 4 --work-dir /tmp/soak --cfg-options train_cfg.student_fp8=True train_cfg.teacher_fp8=True checkpoint_config.interval=2 > gpurun_out/r03z_train_cli_soak_fp8.log 2>&1
-tail -8 gpurun_out/r03z_train_cli_soak_fp8.log | cut -c1-300
+t0=$(date +%s)
+python bench.py > gpurun_out/bench_default.json 2> gpurun_out/bench_default.err
+t1=$(date +%s)
+echo "default bench.py wall: $((t1-t0)) s"
+tail -3 gpurun_out/bench_default.err
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/bench_default.json').read().strip().split('\n')[-1])
+print({k:(v if not isinstance(v,dict) else {kk:vv for kk,vv in v.items() if kk in ('value','frac','achieved','ms_per_step','kind','cores','unit','max_mem_gb','dtype')}) for k,v in d.items() if k not in ('config','metric','data')})
+PY
