@@ -345,18 +345,27 @@ hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, 
 
 // ------------------------------------------------------------------------------------------------
 // Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): out[b] = [cos(a) | sin(a)],
-// a_i = scale * t_b * exp(-ln(1e4) * i / 128)
-__global__ void sincos_kernel(const float* __restrict__ t, float scale, float* __restrict__ out, int B) {
+// a_i = scale * t_b * exp(-ln(1e4) * i / 128).
+// cast_mode models the reference's explicit casts of the conditioning scalar to the trunk dtype (bf16):
+//   1  FLUX  `timestep.to(hidden_states.dtype) * 1000` (arcflux.py:160-162): t and the product are bf16 tensors -- sigma 0.76190
+//            reaches the sinusoid as 760.0, guidance 3.5 as 3504;
+//   2  Qwen  `timestep.to(hidden_states.dtype)` (arcqwen.py:128), the x1000 is Timesteps(scale=1000) in fp32;
+//   0  none (fp32 scalar).
+__global__ void sincos_kernel(const float* __restrict__ t, float scale, float* __restrict__ out, int B, int cast_mode) {
   const int i = threadIdx.x;        // 0..127
   const int b = blockIdx.x;
   if (b >= B) return;
   const float f = expf(-9.210340371976184f * (float)i / 128.0f);
-  const float a = scale * (t[b] * f);
+  float tb = t[b];
+  if (cast_mode != 0) tb = bf16_to_f32(f32_to_bf16(tb));
+  float a;
+  if (cast_mode == 1) a = bf16_to_f32(f32_to_bf16(tb * scale)) * f;
+  else a = scale * (tb * f);
   out[b * 256 + i] = cosf(a);
   out[b * 256 + 128 + i] = sinf(a);
 }
-hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream) {
-  hipLaunchKernelGGL(sincos_kernel, dim3(B), dim3(128), 0, stream, t, scale, out, B);
+hipError_t launch_sincos(const float* t, float scale, float* out, int B, int cast_mode, hipStream_t stream) {
+  hipLaunchKernelGGL(sincos_kernel, dim3(B), dim3(128), 0, stream, t, scale, out, B, cast_mode);
   return hipGetLastError();
 }
 

@@ -413,12 +413,12 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   if (c->temb_override != nullptr) {
     HIP_TRY(hipMemcpyAsync(ws.temb, c->temb_override, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
   } else {
-    HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, st));
+    HIP_TRY(launch_sincos(t, 1000.0f, ws.sincos, B, d.family == 0 ? 1 : 2, st));
     HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
     HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 0, st));
   }
   if (d.guidance_embeds) {
-    HIP_TRY(launch_sincos(g, 1000.0f, ws.sincos, B, st));
+    HIP_TRY(launch_sincos(g, 1000.0f, ws.sincos, B, 1, st));
     HIP_TRY(launch_gemv(ws.sincos, W16(c, "temb.g.l1.weight"), W16(c, "temb.g.l1.bias"), ws.tmp, B, (int)D, 256, 1, 0, st));
     HIP_TRY(launch_gemv(ws.tmp, W16(c, "temb.g.l2.weight"), W16(c, "temb.g.l2.bias"), ws.temb, B, (int)D, (int)D, 0, 1, st));
   }
@@ -718,11 +718,11 @@ int afx_mmdit_prepare_steps(afx_ctx* c, const void* pooled, const float* t_steps
     float* temb = ws.prep_temb + (int64_t)k * B * D;
     float* hid = sc + (int64_t)k * B * D;                        // [B, D] hidden of the current MLP (overwritten by the SiLU below)
     float* sin_ = ws.prep_mod;                                   // [B, 256] / [B, pooled_dim]: free until the big pass
-    HIP_TRY(launch_sincos(t_steps + (int64_t)k * B, 1000.0f, sin_, B, st));
+    HIP_TRY(launch_sincos(t_steps + (int64_t)k * B, 1000.0f, sin_, B, d.family == 0 ? 1 : 2, st));
     HIP_TRY(launch_gemv(sin_, W16(c, "temb.t.l1.weight"), W16(c, "temb.t.l1.bias"), hid, B, (int)D, 256, 1, 0, st));
     HIP_TRY(launch_gemv(hid, W16(c, "temb.t.l2.weight"), W16(c, "temb.t.l2.bias"), temb, B, (int)D, (int)D, 0, 0, st));
     if (d.guidance_embeds) {
-      HIP_TRY(launch_sincos(g, 1000.0f, sin_, B, st));
+      HIP_TRY(launch_sincos(g, 1000.0f, sin_, B, 1, st));
       HIP_TRY(launch_gemv(sin_, W16(c, "temb.g.l1.weight"), W16(c, "temb.g.l1.bias"), hid, B, (int)D, 256, 1, 0, st));
       HIP_TRY(launch_gemv(hid, W16(c, "temb.g.l2.weight"), W16(c, "temb.g.l2.bias"), temb, B, (int)D, (int)D, 0, 1, st));
     }

@@ -131,7 +131,7 @@ hipError_t launch_qk_norm_rope2(uint16_t* xk, uint16_t* xq, int64_t ldx, const f
                                 hipStream_t stream);
 hipError_t launch_gemv(const float* x, const uint16_t* W, const uint16_t* bias, float* y, int B, int N,
                        int K, int act, int accumulate, hipStream_t stream, int64_t ldy = 0);
-hipError_t launch_sincos(const float* t, float scale, float* out, int B, hipStream_t stream);
+hipError_t launch_sincos(const float* t, float scale, float* out, int B, int cast_mode, hipStream_t stream);
 hipError_t launch_silu(const float* x, float* y, int64_t n, hipStream_t stream);
 hipError_t launch_bf16_to_f32(const uint16_t* x, float* y, int64_t n, hipStream_t stream);
 hipError_t launch_head_split(const uint16_t* head, int64_t ldh, uint16_t* means, uint16_t* logw,

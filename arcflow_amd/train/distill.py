@@ -160,10 +160,12 @@ class ArcFlowDistiller:
 
     # ------------------------------------------------------------------ helpers
     def sync_module_states(self, src: int = 0) -> None:
-        """Data parallel: every rank takes rank `src`'s trainables (flat fp32 buffer; EMA and optimizer state follow), as torch
-        DDP broadcasts the wrapped module's state at construction (lakonlab/parallel/ddp_wrapper.py:19-25).  Then the bf16 working
-        copies / merged LoRA weights are rebuilt and the ranks' buffers are checksummed against each other.  No-op on one rank.
-        Call again after loading a checkpoint on one rank only."""
+        """Data parallel: every rank takes rank `src`'s trainables and EMA (the flat fp32 buffers), as torch DDP broadcasts the
+        wrapped module's state at construction (lakonlab/parallel/ddp_wrapper.py:19-25).  Then the bf16 working copies / merged LoRA
+        weights are rebuilt and the ranks' buffers are checksummed against each other.  No-op on one rank.
+        The optimizer moments, `opt_steps` and `iteration` are NOT broadcast (DDP does not either): a checkpoint has to be loaded on
+        EVERY rank, which is what tools/train.py does -- loading on one rank and calling this would leave the learning-rate schedule,
+        the bias correction and the moments rank-local."""
         red = self.reducer
         if red._skip_single:
             return

@@ -18,6 +18,32 @@ from typing import List, Optional, Tuple
 import torch
 
 
+def init_distributed(local_rank: int):
+    """Join the torchrun rendezvous as one rank and pick this rank's device.  Returns (torch.distributed, device string).
+
+    Production: backend "nccl" (= RCCL over xGMI), rank r on GPU r.  For boxes with ONE GPU (the build's test pool) two environment
+    switches let the very same launch lines -- `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --train`,
+    `tools/train.py --launcher pytorch` -- run end to end: ARCFLOW_DIST_BACKEND=gloo (RCCL refuses two ranks on one device; the
+    reducer stages device buffers through the host for gloo) and ARCFLOW_DIST_ONE_DEVICE=1 (every rank on cuda:0)."""
+    import os
+    import torch.distributed as dist
+    backend = os.environ.get('ARCFLOW_DIST_BACKEND', 'nccl')
+    index = 0 if os.environ.get('ARCFLOW_DIST_ONE_DEVICE', '0') == '1' else local_rank
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    torch.cuda.set_device(index)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', device_id=torch.device('cuda', index))
+    else:
+        dist.init_process_group(backend)
+    return dist, f'cuda:{index}'
+
+
+def host_or_device(dist, device):
+    """Where a small control tensor of a collective must live: gloo reduces host tensors, RCCL device tensors."""
+    return 'cpu' if dist.get_backend() == 'gloo' else device
+
+
 class GradReducer:
     def __init__(self, process_group=None):
         import torch.distributed as dist
@@ -101,12 +127,18 @@ class GradReducer:
             return
         x = flat.detach().flatten()
         sums = torch.stack([x.sum(dtype=torch.float64), x[::2].sum(dtype=torch.float64), x[1::3].sum(dtype=torch.float64)])
+        # NaN != NaN would read as "ranks disagree", and raising on one rank before the collectives would hang the others: the
+        # non-finite flag travels with the checksums (4th entry) and every rank raises the same error after the reduce
+        bad = (~torch.isfinite(sums)).any().to(torch.float64).reshape(1)
+        sums4 = torch.cat([torch.nan_to_num(sums, nan=0.0, posinf=0.0, neginf=0.0), bad])
         dev = 'cpu' if self.backend == 'gloo' else flat.device
-        lo, hi = sums.to(dev).clone(), sums.to(dev).clone()
+        lo, hi = sums4.to(dev).clone(), sums4.to(dev).clone()
         self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN, group=self.group)
         self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX, group=self.group)
+        if float(hi[3]) > 0:
+            raise RuntimeError(f'the {what} contain non-finite values on at least one rank (rank {self.rank}: checksums {sums.tolist()})')
         if not torch.equal(lo, hi):
-            raise RuntimeError(f'data-parallel ranks disagree on the {what}: checksums min {lo.tolist()} max {hi.tolist()} '
+            raise RuntimeError(f'data-parallel ranks disagree on the {what}: checksums min {lo[:3].tolist()} max {hi[:3].tolist()} '
                                f'(rank {self.rank} has {sums.tolist()})')
 
     def all_reduce_max(self, value: float, device) -> float:

@@ -229,7 +229,11 @@ class LoraTrunk:
         (diffusers Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0) -> Linear -> SiLU -> Linear).  The
         [B<=4]-row products run on the weight-streaming gemv kernel; the intermediates are kept for ``temb_backward``."""
         sp1, sp2 = self._spec('temb.t.l1'), self._spec('temb.t.l2')
-        t = sigma.to(self.dev, torch.float32).reshape(-1) * 1000.0
+        # the reference casts the timestep to the trunk dtype before the sinusoid, FLUX also the x1000 product
+        # (arcflux.py:160-162, arcqwen.py:128; the engine's sincos kernel does the same)
+        t = sigma.to(self.dev, torch.float32).reshape(-1).bfloat16().float() * 1000.0
+        if self.family == 'flux':
+            t = t.bfloat16().float()
         freqs = torch.exp(-math.log(10000.0) * torch.arange(128, dtype=torch.float32, device=self.dev) / 128.0)
         ang = t[:, None] * freqs[None]
         s = torch.cat([ang.cos(), ang.sin()], dim=1)                                   # [B, 256], cos first

@@ -138,6 +138,8 @@ def train_main(args, rank, world, dev, dist):
     flux = args.model == 'flux'
     D = 3072
     nd, ns, joint, T = (19, 38, 4096, 512) if flux else (60, 0, 3584, 128)
+    if args.blocks:                 # plumbing tests only (tests/test_multi_rank_plumbing.py): fewer blocks, the line's workload says so
+        nd, ns = (int(v) for v in args.blocks.split(','))
     B = args.batch or (4 if flux else 2)
     packed = random_packed(args.model, nd, ns, dev, joint_dim=joint, seed=0)
     g = torch.Generator(device=dev).manual_seed(1)
@@ -175,7 +177,8 @@ def train_main(args, rank, world, dev, dist):
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], device=dev)
+        from arcflow_amd.train import host_or_device
+        tt = torch.tensor([dt], device=host_or_device(dist, dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     if rank == 0:
@@ -195,7 +198,8 @@ def train_main(args, rank, world, dev, dist):
                       else 'bf16 (fp32 master weights / gradients / AdamW moments)'),
             'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt embeddings, data-free noise latents)',
             'config': {'workload': ('ArcFlow-FLUX distillation training (train_flux.sh), LoRA adapters' if flux else
-                                    'ArcFlow-Qwen-20B distillation training (train_qwen.sh), true-CFG teacher'),
+                                    'ArcFlow-Qwen-20B distillation training (train_qwen.sh), true-CFG teacher')
+                       + (f' -- REDUCED DEPTH {args.blocks} (plumbing test, not a measurement)' if args.blocks else ''),
                        'samples_per_gpu': B, 'global_batch': world * B, 'image_tokens': N_IMG, 'text_tokens': T,
                        'trainable_params': int(ds.params.numel()), 'lora_dropout': 0.05,
                        'parallelism': f'dp{world}: batch sharded over ranks, one flat-gradient all-reduce per iteration (RCCL), '
@@ -218,13 +222,15 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=None, help='untimed steps (default 2; 1 with --train)')
     ap.add_argument('--model', default='flux', choices=['flux', 'qwen'])
     ap.add_argument('--train', action='store_true', help='time the distillation iteration (configs[3] flux / configs[4] qwen) instead of inference')
+    ap.add_argument('--blocks', default=None, help='--train: "double,single" block counts for plumbing tests (the line is then labelled REDUCED DEPTH)')
     ap.add_argument('--batch', type=int, default=None, help='--train: samples per GPU (default: 4 flux, 2 qwen, the reference configs)')
     ap.add_argument('--student-fp8', action='store_true', help='--train: the student forward / recompute linears on the fp8 MFMA, gradients bf16 (configs[4]); says so in dtype')
     ap.add_argument('--teacher-fp8', action='store_true', help='--train: frozen teacher forwards on the fp8 MFMA (configs[4]); the line says so in dtype')
     ap.add_argument('--streams', type=int, default=1, help='images in flight per GPU (one HIP stream + engine context each, shared weights); '
                                                            '1 = the canonical line, 2 fills the under-filled last rounds: +3.8 % (r02)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-extras', action='store_true', help='N = 1 FLUX run: skip the extra objects (Qwen inference, one FLUX distillation iteration)')
+    ap.add_argument('--no-extras', action='store_true', help='N = 1 FLUX run: skip the extra objects (Qwen inference, the two distillation iterations, prompt -> image)')
+    ap.add_argument('--e2e', action='store_true', help='only the prompt -> image object of --model (encoders + 2 NFE + VAE)')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
     ap.add_argument('--no-prepare-steps', action='store_true', help='recompute the AdaLN conditioning inside every transformer call (A/B)')
     ap.add_argument('--fp8', action='store_true', help='OPTIONAL reduced-precision mode: block linears on the fp8 MFMA (not the headline: the line says dtype fp8)')
@@ -252,7 +258,7 @@ def launcher_cmd(args, argv, environ=None, device_count=None):
         return None
     if device_count is None:
         device_count = torch.cuda.device_count()
-    if device_count < args.gpus:
+    if device_count < args.gpus and environ.get('ARCFLOW_DIST_ONE_DEVICE', '0') != '1':
         raise SystemExit(f'bench.py: --gpus {args.gpus} requested but this box exposes {device_count} GPU(s)')
     port = args.master_port or (29500 + os.getpid() % 2000)
     return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
@@ -274,15 +280,14 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', 1))
     dist = None
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        from arcflow_amd.train import init_distributed
+        dist, dev = init_distributed(local_rank)       # RCCL, rank r on GPU r (one-GPU test boxes: see its docstring)
     else:
         torch.cuda.set_device(0)
-    dev = f'cuda:{local_rank if world > 1 else 0}'
-    if args.train:
+        dev = 'cuda:0'
+    if args.e2e:
+        line = {'e2e': {args.model: e2e_main(args.model, dev, steps=args.steps, warmup=args.warmup)}} if rank == 0 else None
+    elif args.train:
         line = train_main(args, rank, world, dev, dist)
     else:
         line = infer_main(args, args.model, rank, world, dev, dist)
@@ -301,7 +306,7 @@ def main(argv=None):
                                               'roofline', 'roofline_attention') if k in q}
             gc.collect()
             torch.cuda.empty_cache()
-            ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8, ex.student_fp8 = 1, 1, 'flux', None, False, False
+            ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8, ex.student_fp8 = 2, 1, 'flux', None, False, False
             t = train_main(ex, rank, world, dev, dist)
             line['train_flux'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
                                                     'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}
@@ -317,6 +322,12 @@ def main(argv=None):
             del t
             gc.collect()
             torch.cuda.empty_cache()
+            # prompt -> image (encoders + 2 NFE + VAE), both families: BASELINE.md section 2 "reported separately"
+            line['e2e'] = {}
+            for m in ('flux', 'qwen'):
+                line['e2e'][m] = e2e_main(m, dev)
+                gc.collect()
+                torch.cuda.empty_cache()
         if rank == 0 and not args.no_cpu_baseline and world == 1:
             line['cpu_baseline'] = cpu_baseline()
     if rank == 0:
@@ -324,6 +335,88 @@ def main(argv=None):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def e2e_main(model, dev, steps=5, warmup=2):
+    """Prompt -> image at 1024^2 on one GPU (BASELINE.md section 2 promised it next to the denoiser-only headline): the prompt
+    encoders (FLUX: T5-XXL at 512 tokens + CLIP-L at 77; Qwen-Image: the Qwen2.5-VL-7B language model at 34 template + 128 prompt
+    tokens), the 2-NFE denoiser loop and the VAE decode, all on the HIP library, random-init weights of the released sizes.
+    Starts from token ids (tokenisation is host-side string work on the snapshot's vocabulary files).  Three numbers:
+    `from_prompt_embeds` (pipe(prompt_embeds=...): denoiser + VAE), `from_token_ids` (pipe(prompt=...) minus the tokenizer),
+    `from_token_ids_vae_overlapped` (throughput mode: the VAE decode of image i on a second stream under the encoders + denoiser
+    of image i + 1).  Reference sequence: lakonlab/pipelines/arcflux_pipeline.py:385-534, arcqwen_pipeline.py:346-481."""
+    from arcflow_amd import ops, synthetic
+    from arcflow_amd.text_encoders import CLIPTextEncoder, Qwen25TextEncoder, T5Encoder
+    from arcflow_amd.vae import AutoencoderKLDecoder, AutoencoderKLQwenImageDecoder
+    eng, (_, _, ctx0, pooled0, guidance, hp, wp) = build_flux_engine(model, dev)
+    sig = [1.0, 0.7619047619, 0.0]
+    tv = [torch.full((1,), s, device=dev) for s in sig[:2]]
+    lat = torch.randn(1, N_IMG, 64, device=dev, generator=torch.Generator(device=dev).manual_seed(42))
+    if model == 'flux':
+        t5, clip = T5Encoder(synthetic.t5_state_dict(dev)), CLIPTextEncoder(synthetic.clip_state_dict(dev), eos_token_id=2)
+        vae = AutoencoderKLDecoder(synthetic.vae_kl_decoder_state_dict(dev), (128, 256, 512, 512))
+        ids5, idsc = torch.randint(0, 32000, (1, 512)), torch.randint(0, 49000, (1, 77))
+
+        def encode():
+            return t5(ids5), clip(idsc)[1]
+        enc_desc = 'T5-XXL encoder 512 tokens + CLIP-L text model 77 tokens'
+    else:
+        qw = Qwen25TextEncoder(synthetic.qwen25_state_dict(dev))
+        vae = AutoencoderKLQwenImageDecoder(synthetic.vae_qwen_decoder_state_dict(dev), [0.0] * 16, [1.0] * 16)
+        idsq = torch.randint(0, 150000, (1, 34 + 128))
+
+        def encode():
+            return qw(idsq)[:, 34:].contiguous(), None        # the 34 template tokens are dropped (arcqwen_pipeline.py prompt template)
+        enc_desc = 'Qwen2.5-VL-7B language model, 34 template + 128 prompt tokens'
+
+    def denoise(pe, pooled):
+        x = lat
+        prep = eng.prepare_steps(sig[:2], pooled, guidance, 1, N_IMG, int(pe.shape[1]))
+        for i in range(2):
+            out = eng(x.bfloat16(), tv[i], pe, pooled, guidance, hp, wp, prepared_step=i if prep else None)
+            x = ops.arcflow_step(x, out.means, out.logweights, out.loggammas, sig[i], sig[i], sig[i + 1])
+        return x
+
+    def timed(fn, n=steps, w=warmup):
+        for _ in range(w):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    pe0, pl0 = encode()
+    enc_ms, _ = timed(encode)
+    den_ms, x = timed(lambda: denoise(pe0, pl0))
+    vae_ms, img = timed(lambda: vae.decode_packed(x, hp, wp))
+    assert torch.isfinite(img.float()).all() and img.shape[-2:] == (1024, 1024), img.shape
+    emb_ms, _ = timed(lambda: vae.decode_packed(denoise(pe0, pl0), hp, wp))
+    ids_ms, _ = timed(lambda: vae.decode_packed(denoise(*encode()), hp, wp))
+    # throughput mode: image i's decode on a second stream under image i + 1's encoders + denoiser
+    side = torch.cuda.Stream(device=dev)
+    main_s = torch.cuda.current_stream()
+
+    def pipelined():
+        xx = denoise(*encode())
+        ev = torch.cuda.Event()
+        ev.record(main_s)
+        xx.record_stream(side)
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            out = vae.decode_packed(xx, hp, wp)
+        return out
+    ovl_ms, _ = timed(pipelined, n=max(steps, 6))
+    main_s.wait_stream(side)
+
+    def obj(ms):
+        return {'value': 1e3 / ms, 'unit': 'images/s', 'ms_per_image': ms}
+    return {'workload': f'prompt -> 1024x1024 image, 2 NFE, bs 1, one GPU, one image at a time ({enc_desc}; '
+                        f'{"FLUX-12B" if model == "flux" else "Qwen-Image-20B"} denoiser; '
+                        f'{"AutoencoderKL" if model == "flux" else "AutoencoderKLQwenImage"} decoder), random-init weights of the released sizes',
+            'from_prompt_embeds': obj(emb_ms), 'from_token_ids': obj(ids_ms), 'from_token_ids_vae_overlapped': obj(ovl_ms),
+            'stages_ms': {'text_encoders': enc_ms, 'denoiser_2nfe': den_ms, 'vae_decode': vae_ms}, 'steps': steps, 'warmup': warmup}
 
 
 def infer_main(args, model, rank, world, dev, dist):
@@ -384,7 +477,8 @@ def infer_main(args, model, rank, world, dev, dist):
     dt = time.perf_counter() - t0
     assert torch.isfinite(res).all()
     if dist is not None:
-        tt = torch.tensor([dt], device=dev)
+        from arcflow_amd.train import host_or_device
+        tt = torch.tensor([dt], device=host_or_device(dist, dev))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     # the analytic transport step alone (SURVEY 8d asks for its GB/s): 50 launches between two events on the launch stream -- includes

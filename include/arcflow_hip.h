@@ -98,7 +98,9 @@ int afx_set_workspace(afx_ctx* ctx, void* dptr, int64_t bytes);
  * x        [B, N, in_channels]      bf16  packed latents
  * ctx_emb  [B, T, joint_dim]        bf16  text-encoder states (Qwen: only the T real tokens)
  * pooled   [B, pooled_dim]          bf16  (FLUX) or NULL
- * t        [B] f32  sigma in [0,1] (the pipeline's timestep/1000);  g [B] f32 guidance or NULL
+ * t        [B] f32  sigma in [0,1] (the pipeline's timestep/1000);  g [B] f32 guidance or NULL.  As the reference's forward
+ *          does (arcflux.py:160-162 `timestep.to(hidden_states.dtype) * 1000`, arcqwen.py:128), t and g are cast to bf16 in
+ *          front of the sinusoid (FLUX: the x1000 product too -- sigma 0.76190 is embedded as 760, guidance 3.5 as 3504)
  * rope_cos/rope_sin [T+N, head_dim/2] f32 rotation tables of the joint [text; image] sequence
  *          (FluxPosEmbed / QwenEmbedRope angles; built by the host, see arcflow_amd/rope.py)
  * outputs (head_mode 0): means [B,N,K,in_channels], logw [B,N,K,lw] (log_softmax over K),

@@ -192,7 +192,7 @@ def momentum_step_packed(x_tok: Tensor, means_tok: Tensor, logw_tok: Tensor, log
     m = means_tok.to(torch.float32)
     lw = logw_tok.to(torch.float32)
     lg = logg_tok.to(torch.float32)
-    q = torch.arange(ch) % pp
+    q = torch.arange(ch, device=x.device) % pp
     lw_c = lw[..., q]                       # [B,N,K,ch]
     lg_c = lg[..., q]                       # [B,N,K-1,ch]
     w = torch.softmax(lw_c, dim=2)

@@ -190,6 +190,16 @@ def _dp_worker(rank, world, port, tmp):
         caught = 'disagree' in str(e)
     red.broadcast_(state)
     red.check_consistent(state)
+    # a NaN on ONE rank: both ranks must raise the "non-finite" error (not "disagree"), and neither may hang in the collectives
+    poisoned = state.clone()
+    if rank == 1:
+        poisoned[17] = float('nan')
+    nonfinite = False
+    try:
+        red.check_consistent(poisoned)
+    except RuntimeError as e:
+        nonfinite = 'non-finite' in str(e)
+    assert nonfinite
     torch.save(dict(local=local, reduced=buf, mx=red.all_reduce_max(float(rank + 1), 'cpu'), caught=caught, state=state, mine=mine),
                os.path.join(tmp, f'r{rank}.pt'))
     dist.barrier()

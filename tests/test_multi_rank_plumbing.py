@@ -1,0 +1,84 @@
+"""The multi-GPU launch lines, end to end, as TWO ranks on the one GPU of the test pool (VERDICT r03 "Next round" 8).
+
+The driver's 8-GPU runs are `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` and the reference's training launch
+is `torchrun ... train.py <config> --launcher pytorch --diff_seed` (train_flux.sh:1-3, train.py:182-185).  RCCL refuses two ranks on one
+device, so these tests run the SAME commands with ARCFLOW_DIST_BACKEND=gloo + ARCFLOW_DIST_ONE_DEVICE=1 (arcflow_amd.train.init_distributed):
+rendezvous, per-rank seeds, the construction broadcast + checksum guard, the per-block slice launch order of the gradient exchange, the
+bytes counter, the barrier / MAX-over-ranks timing and the one JSON line of rank 0 all execute; only the transport differs from the
+production run (host-staged gloo instead of RCCL over xGMI -- whose branch runs on a one-rank group in tests/test_distill.py).
+No scaling number comes out of this: it exists so that the first real multi-GPU run cannot die on plumbing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _torchrun(script_args, nproc=2, timeout=900):
+    port = 29500 + (os.getpid() * 7 + len(script_args)) % 2000
+    env = dict(os.environ, ARCFLOW_DIST_BACKEND='gloo', ARCFLOW_DIST_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), *script_args]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith('{')]
+
+
+def test_bench_train_two_ranks_line():
+    """bench.py --train --gpus 2 as the driver launches it: 2 double + 2 single blocks at the production width, one sample per rank."""
+    r = _torchrun([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--train', '--steps', '1', '--warmup', '1', '--batch', '1', '--blocks', '2,2'])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE line
+    ln = lines[0]
+    assert ln['n_gpus'] == 2 and ln['config']['global_batch'] == 2 and ln['config']['samples_per_gpu'] == 1
+    assert ln['allreduce_bytes_per_step'] == ln['config']['trainable_params'] * 4 > 0       # the whole trainable set, once per iteration
+    assert ln['value'] > 0 and ln['last_step']['loss'] == ln['last_step']['loss']
+    assert 'REDUCED DEPTH' in ln['config']['workload']
+
+
+def test_bench_inference_two_replicas_line():
+    """bench.py --gpus 2 (inference = independent replicas, no data-path collective): barrier + MAX over ranks + one line."""
+    r = _torchrun([os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--no-cpu-baseline'])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 2 and lines[0]['value'] > 0
+    assert 'qwen' not in lines[0] and 'e2e' not in lines[0]     # N > 1 runs never carry the extras
+
+
+_TINY_CFG = """
+name = 'tiny_dp'
+model = dict(diffusion=dict(type='ArcFlowImitationDataFree', policy_type='ArcFlow', policy_kwargs=dict(),
+    denoising=dict(type='ArcFluxTransformer2DModel', num_gaussians=16, logweights_channels=4, in_channels=64, num_layers=1,
+        num_single_layers=1, attention_head_dim=128, num_attention_heads=2, joint_attention_dim=128, pooled_projection_dim=64,
+        guidance_embeds=True, use_lora=True, lora_rank=64, lora_dropout=0.05),
+    flow_loss=dict(type='DiffusionMSELoss', rescale_cfg=dict(scale=30.0)), timestep_sampler=dict(shift=3.2)))
+train_cfg = dict(num_decay_iters=4, window_substeps=3, gm_dropout=0.1, num_intermediate_states=4, nfe=2, timestep_ratio=1.0,
+                 total_substeps=128, diffusion_grad_clip=50.0, diffusion_grad_clip_begin_iter=1)
+optimizer = {'diffusion': dict(type='AdamW8bit', lr=1e-4, betas=(0.9, 0.95), weight_decay=0.0)}
+lr_config = dict(warmup_iters=2, warmup_ratio=0.001)
+runner = dict(ckpt_fp16=True, ckpt_fp16_ema=True)
+data = dict(train_dataloader=dict(samples_per_gpu=1))
+checkpoint_config = dict(interval=2, out_dir='checkpoints/')
+total_iters = 2
+custom_hooks = [dict(type='ExponentialMovingAverageHookMod', start_iter=1, momentum_cfg=dict(gamma=7.0))]
+"""
+
+
+def test_train_cli_launcher_pytorch_two_ranks(tmp_path):
+    """tools/train.py <config> --launcher pytorch --diff_seed under torchrun: two ranks step in lock-step (the checksum guard at the
+    checkpoint interval passes), rank 0 logs and saves."""
+    cfgp = tmp_path / 'tiny.py'
+    cfgp.write_text(_TINY_CFG)
+    r = _torchrun([os.path.join(ROOT, 'tools', 'train.py'), str(cfgp), '--launcher', 'pytorch', '--diff_seed', '--synthetic', '--work-dir',
+                   str(tmp_path / 'w'), '--latent-tokens', '8', '8', '--iters', '2'])
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    logs = _json_lines(r.stdout)
+    assert [l['iter'] for l in logs] == [1, 2] and all(l['loss'] == l['loss'] for l in logs)
+    assert (tmp_path / 'w' / 'checkpoints' / 'iter_2.pth').exists()

@@ -79,7 +79,7 @@ def test_flux_embedders_and_norm_out_vs_diffusers():
     ref = D.flux_temb(w, cfg, t, gd, pooled)
     m = _load(emb.CombinedTimestepGuidanceTextProjEmbeddings(embedding_dim=cfg.dim, pooled_projection_dim=64), w, 'time_text_embed.')
     with torch.no_grad():
-        out = m(t * 1000, gd * 1000, pooled)
+        out = m(D.cond_cast(D.cond_cast(t) * 1000), D.cond_cast(D.cond_cast(gd) * 1000), pooled)   # arcflux.py:160-162
     assert _rel(ref, out) < TOL
     x = torch.randn(3, 10, cfg.dim, generator=g)
     no = _load(norm.AdaLayerNormContinuous(cfg.dim, cfg.dim, elementwise_affine=False, eps=1e-6), w, 'norm_out.')

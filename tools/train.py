@@ -61,13 +61,12 @@ def main():
     cfg = config.apply_options(config.load_config(args.config), _options(args.cfg_options))
     family, eng, dc, run = config.distill_setup(cfg)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local)
-    dev = f'cuda:{local}'
+    torch.cuda.set_device(local if os.environ.get('ARCFLOW_DIST_ONE_DEVICE', '0') != '1' else 0)
+    dev = f'cuda:{torch.cuda.current_device()}'
     pg = None
     if args.launcher == 'pytorch' or world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        from arcflow_amd.train import init_distributed
+        dist, dev = init_distributed(local)           # RCCL, rank r on GPU r (train.py:182-185 init_dist('pytorch', backend='nccl'))
         pg = dist.group.WORLD
     seed = args.seed + (rank if args.diff_seed else 0)              # train.py:222-225
     rng = torch.Generator(device=dev).manual_seed(seed)
