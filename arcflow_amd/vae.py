@@ -253,7 +253,7 @@ class AutoencoderKLQwenImageDecoder:
         self.config = type('cfg', (), dict(latents_mean=self.latents_mean, latents_std=self.latents_std, z_dim=z_dim))()
         self.w: Dict[str, torch.Tensor] = {}
         self.creal: Dict[str, int] = {}
-        sd = state_dict
+        sd = {k: v.detach().cpu() for k, v in state_dict.items()}          # repacked on the host (a few hundred MB, once), then uploaded
         for k in [k for k in sd if k.startswith('decoder.') and k.endswith('.weight') and 'time_conv' not in k]:
             name = k[:-len('.weight')]
             wt, b = sd[k].float(), sd[name + '.bias'].float()
