@@ -92,7 +92,7 @@ hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int 
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
                             hipStream_t stream, float* lse = nullptr);
-// one-wave-per-SIMD kernel (afx_attn3.hip): S % 64 == 0; launch_attention dispatches to it (AFX_ATTN_IMPL=1 / attn_set_impl(1): 4-wave kernel)
+// one-wave-per-SIMD kernel (afx_attn3.hip): any S > 64 (ragged tails handled); launch_attention dispatches to it (AFX_ATTN_IMPL=1 / attn_set_impl(1): 4-wave kernel)
 bool attention_v3_eligible(int S);
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
                                int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse);

@@ -543,6 +543,7 @@ __global__ __launch_bounds__(256) void cfg_kernel(const float* __restrict__ pos,
 // correction B A (x . delta), delta = keep / (1 - p) - 1).  keep(row, col) is a counter-based hash of (seed, global row, col):
 // the batched forward and the per-sample recompute / backward regenerate identical masks from the seed.
 //   mode 0: dst = src . delta      mode 1: dst = src . (1 + delta) = dropout(src)      mode 2: dst += src . delta
+//   mode 3: dst += src . (1 + delta)      (the input gradient of the LoRA branch: dx += ((dy B) A) . keep/(1-p))
 AFX_DEV uint32_t mix32(uint32_t h) {
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(256) void lora_dropout_kernel(const bf16_t* __restr
   const int c = (int)(g % cpr);
   float a[8], o[8];
   unpack8(*reinterpret_cast<const u32x4_t*>(src + m * lds_ + c * 8), a);
-  if (mode == 2) unpack8(*reinterpret_cast<const u32x4_t*>(dst + m * ldd + c * 8), o);
+  if (mode >= 2) unpack8(*reinterpret_cast<const u32x4_t*>(dst + m * ldd + c * 8), o);
   const uint32_t hr = mix32(seed ^ (uint32_t)((row0 + m) * 0x9e3779b1u));
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
@@ -566,7 +567,8 @@ __global__ __launch_bounds__(256) void lora_dropout_kernel(const bf16_t* __restr
     const float delta = keep ? inv_keep - 1.0f : -1.0f;
     if (mode == 0) o[e] = a[e] * delta;
     else if (mode == 1) o[e] = a[e] * (1.0f + delta);
-    else o[e] += a[e] * delta;
+    else if (mode == 2) o[e] += a[e] * delta;
+    else o[e] += a[e] * (1.0f + delta);
   }
   *reinterpret_cast<u32x4_t*>(dst + m * ldd + c * 8) = pack8(o);
 }
@@ -1035,7 +1037,7 @@ int afx_add_scale_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, c
 
 int afx_lora_dropout_bf16(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t N, int64_t row0, float p,
                           uint32_t seed, int32_t mode, void* stream) {
-  if (!src || !dst || M < 1 || N % 8 || lds_ % 8 || ldd % 8 || !(p >= 0.f && p < 1.f) || mode < 0 || mode > 2)
+  if (!src || !dst || M < 1 || N % 8 || lds_ % 8 || ldd % 8 || !(p >= 0.f && p < 1.f) || mode < 0 || mode > 3)
     return fail(AFX_E_INVALID, "bad argument to afx_lora_dropout_bf16");
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   hipLaunchKernelGGL(lora_dropout_kernel, dim3((unsigned)((M * (N >> 3) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,

@@ -80,11 +80,11 @@ def stream_k_workspace(device='cuda') -> torch.Tensor:
 
 def lora_dropout(src: torch.Tensor, p: float, seed: int, row0: int = 0, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Counter-based LoRA input dropout (keep probability 1-p, delta = keep/(1-p) - 1):
-    mode 0: out = src * delta;  1: out = src * (1 + delta) = dropout(src);  2: out += src * delta."""
+    mode 0: out = src * delta;  1: out = src * (1 + delta) = dropout(src);  2: out += src * delta;  3: out += src * (1 + delta)."""
     lib = _lib.load()
     M, N = src.shape
     if out is None:
-        assert mode != 2
+        assert mode < 2
         out = torch.empty(M, N, dtype=torch.bfloat16, device=src.device)
     _lib.check(lib.afx_lora_dropout_bf16(_p(src), src.stride(0), _p(out), out.stride(0), M, N, row0, float(p), int(seed) & 0xffffffff, mode, _s()))
     return out

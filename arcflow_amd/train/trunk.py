@@ -3,16 +3,18 @@ lakonlab/models/architecture/arcflow/arcflux.py:294-302 with the target lists of
 and configs/qwen/arcqwen_2nfe_k16.py:47-58; gradient checkpointing of every block arcflux.py:181-189).
 
 Design for MI355X:
-  * The student FORWARD is the inference engine on merged weights W' = W + B A (one fp32-accumulated GEMM per adapted
-    linear after every optimizer step) -- no side GEMMs on the hot path; the engine stores each block's input
-    (checkpoint) while it runs.
+  * peft's forward  y = W x + b + B (A dropout(x))  is evaluated UNMERGED but as ONE GEMM per adapted linear: the rank-r product
+    t = dropout(x) A^T is written into r extra columns of the activation buffer and the frozen weight carries B in r extra columns,
+    y = [x | t] [W | B]^T  (K-extension; "wcat").  W stays the frozen tensor's values (nothing is re-merged after an optimizer
+    step: only the B columns are refreshed), and small updates of B A are not lost in W's bf16 grid.
   * BACKWARD walks the blocks in reverse; each block is recomputed from its checkpoint with the same HIP kernels
-    (bit-identical to the forward) keeping the intermediates, then differentiated by hand:
-    dgrad GEMMs on pre-transposed weights, flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
-  * LoRA gradients per adapted linear  y = x W'^T:   t = x A^T,  dT = dy B,  dB += dy^T t,  dA += dT^T x
-    (rank-r skinny GEMMs on the MFMA kernel, fp32 accumulate-into output).
-  * LoRA input dropout (0.05 in the reference config): the merged-weight product gets the correction B A (x . delta),
-    delta = keep/(1-p) - 1, from a counter-hash mask regenerated wherever it is needed (forward, recompute, backward).
+    (bit-identical to the forward) keeping the intermediates (incl. dropout(x) and t of every adapter), then differentiated by
+    hand: the input gradient and dT = dy B come out of ONE GEMM on the transposed frozen weight with r extra rows
+    [dx0 | dT] = dy [W^T ; B^T]^T  (N-extension; "wtcat"), then dx = dx0 + ((dT A) . keep/(1-p));
+    flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
+  * LoRA gradients per adapted linear:   dB += dy^T t,  dA += dT^T dropout(x)   (rank-r skinny GEMMs, fp32 accumulate-into).
+  * LoRA input dropout (0.05 in the reference config): a counter-hash mask regenerated wherever it is needed (forward,
+    recompute, backward) from (step seed, adapter, global token row, column); nothing is stored across the forward.
   * The timestep-embedder LoRA pair is trained too: its gradient is the sum of EVERY block's AdaLN modulation gradients
     (d_shift / d_scale / d_gate, accumulated per sample into a [n_mod] vector during the block backwards) pulled back
     through the stacked modulation matrix; the two [B <= 4]-row linears run on the gemv kernels.
@@ -88,20 +90,34 @@ class LoraTrunk:
         self.by_key: Dict[str, List[LoraSpec]] = {}
         for sp in self.specs:
             self.by_key.setdefault(sp.packed_key, []).append(sp)
-        # frozen originals of the adapted weights + private merged copies bound to the student
-        self.base: Dict[str, torch.Tensor] = {}
+        # adapted block linears: the frozen weight with r (padded to the GEMM's K granule) extra columns for B, and its transpose
+        # with as many extra rows for B^T.  The frozen tensors in `packed` stay shared with the teacher and are never written.
+        self.rp = (rank + 63) // 64 * 64
+        self.base: Dict[str, torch.Tensor] = {}          # the timestep-embedder pair's frozen weights (gemv path)
+        self.wcat: Dict[str, torch.Tensor] = {}          # key -> [out_total, in + rp] bf16 = [W | B | 0]
+        self.wtcat: Dict[str, torch.Tensor] = {}         # key -> [in + rp, out_total] bf16 = [W^T ; B^T ; 0]
         for key in self.by_key:
-            self.base[key] = packed[key + '.weight']
-            packed[key + '.weight'] = packed[key + '.weight'].clone()
+            w = packed[key + '.weight']
+            if key.startswith('temb.'):
+                self.base[key] = w
+                continue
+            o, i = w.shape
+            wc = torch.zeros(o, i + self.rp, dtype=torch.bfloat16, device=self.dev)
+            wc[:, :i].copy_(w)
+            wt = torch.zeros(i + self.rp, o, dtype=torch.bfloat16, device=self.dev)
+            wt[:i].copy_(ops.transpose(w))
+            self.wcat[key], self.wtcat[key] = wc, wt
         # peft init_lora_weights='gaussian': A ~ N(0, 1/r), B = 0
         for sp in self.specs:
             a = torch.randn(rank, sp.in_f, generator=generator, device=self.dev if generator is None or generator.device.type == 'cuda' else 'cpu') / rank
             self.A(sp).copy_(a.to(self.dev))
             self.B(sp).zero_()
-        self.wt: Dict[str, torch.Tensor] = {}        # transposed weights for the dgrad GEMMs
+        self.wt: Dict[str, torch.Tensor] = {}        # transposed FROZEN weights of the un-adapted linears (dgrad GEMMs)
         self.a16: Dict[str, torch.Tensor] = {}
         self.b16: Dict[str, torch.Tensor] = {}
         self.at16: Dict[str, torch.Tensor] = {}
+        self.a16p: Dict[str, torch.Tensor] = {}      # A padded to rp rows ([rp, in]) and its transpose ([in, rp]) for the block GEMMs
+        self.at16p: Dict[str, torch.Tensor] = {}
         self.bt16: Dict[str, torch.Tensor] = {}
         self.ybuf: Optional[torch.Tensor] = None     # [2 nd + ns, B*S, D] pre-gate branch outputs of the last training forward
         self.dmod: Optional[torch.Tensor] = None     # [n_mod] fp32: modulation gradients of the sample being back-propagated
@@ -110,8 +126,9 @@ class LoraTrunk:
         self.seed = 0
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
         self._ones: Dict[int, torch.Tensor] = {}
+        self._merged: Dict[str, torch.Tensor] = {}   # bind_merged(): private merged copies for the student engine, on request
         self.fp8 = False            # block linears' forward / recompute on the fp8 MFMA (enable_fp8)
-        self.wq: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}     # packed key -> (e4m3 [out, in], row scales fp32 [out])
+        self.wq: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}     # packed key -> (e4m3 [out, in], row scales fp32 [out]) of the FROZEN weight
         self._build_frozen_transposes()
         self.refresh()
 
@@ -133,30 +150,28 @@ class LoraTrunk:
             for s in ('img', 'txt'):
                 for nm in ('qkv', 'out', 'mlp1', 'mlp2'):
                     k = f'd{i}.{s}_{nm}'
-                    if k not in self.by_key:                     # adapted weights are (re)transposed in refresh()
+                    if k not in self.by_key:                     # adapted linears use wtcat (frozen W^T + the B^T rows)
                         self.wt[k] = ops.transpose(self.packed[k + '.weight'])
 
     def refresh(self):
-        """Re-merge W' = W + B A, refresh the transposed copies and the bf16 working copies (after an optimizer step)."""
-        for key, sps in self.by_key.items():
-            w = self.packed[key + '.weight']
-            if sps[0].row0 > 0:                                  # fused single-block weight: frozen k|v|q rows in front
-                w[:sps[0].row0].copy_(self.base[key][:sps[0].row0])
-            for sp in sps:
-                a16 = ops.cast_bf16(self.A(sp))
-                b16 = ops.cast_bf16(self.B(sp))
-                self.a16[sp.name] = a16
-                self.b16[sp.name] = b16
-                self.bt16[sp.name] = ops.transpose(b16)          # [r, out]
-                at = ops.transpose(a16)                          # [in, r]
-                self.at16[sp.name] = at
-                ones = self._ones.setdefault(sp.in_f, torch.ones(1, sp.in_f, dtype=torch.float32, device=self.dev))
-                rows = slice(sp.row0, sp.row0 + sp.out_f)
-                ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=self.base[key][rows], rows_per_batch=sp.out_f,
-                           out=w[rows])                          # W' = W + B A  (fp32 accumulate, one rounding)
-            self.wt[key] = ops.transpose(w)
-            if self.fp8:
-                self.wq[key] = ops.quant_rows_fp8(w)
+        """After an optimizer step (or a checkpoint load): bf16 working copies of A / B and the B columns / B^T rows of the extended
+        weights.  Nothing else changes -- W is frozen."""
+        r = self.r
+        for sp in self.specs:
+            a16 = ops.cast_bf16(self.A(sp))
+            b16 = ops.cast_bf16(self.B(sp))
+            self.a16[sp.name], self.b16[sp.name] = a16, b16
+            self.bt16[sp.name] = ops.transpose(b16)              # [r, out]
+            self.at16[sp.name] = ops.transpose(a16)              # [in, r]
+            if sp.packed_key in self.wcat:
+                if self.rp == r:
+                    self.a16p[sp.name], self.at16p[sp.name] = a16, self.at16[sp.name]
+                else:                                            # rank below the GEMM's K granule: zero rows / columns up to rp
+                    ap = torch.zeros(self.rp, sp.in_f, dtype=torch.bfloat16, device=self.dev)
+                    ap[:r] = a16
+                    self.a16p[sp.name], self.at16p[sp.name] = ap, ops.transpose(ap)
+                self.wcat[sp.packed_key][sp.row0:sp.row0 + sp.out_f, sp.in_f:sp.in_f + r].copy_(b16)
+                self.wtcat[sp.packed_key][sp.in_f:sp.in_f + r, sp.row0:sp.row0 + sp.out_f].copy_(self.bt16[sp.name])
 
     # ------------------------------------------------------------------ fp8 forward (BASELINE.json configs[4]: "fp8 MFMA fwd + bf16 grads")
     def _linear_keys(self) -> List[str]:
@@ -165,36 +180,65 @@ class LoraTrunk:
 
     def enable_fp8(self, shared: Optional[Dict[str, torch.Tensor]] = None) -> None:
         """Run every block linear of the student's FORWARD (and of the backward's recompute, which must reproduce it) as
-        y = s_a[m] s_w[n] (e4m3(x) . e4m3(W')^T) on the fp8 MFMA: activations quantised per token right before each GEMM, the merged
-        weights W' = W + B A per output row -- the adapted ones again after every optimizer step (refresh()).  The BACKWARD is
-        unchanged: dgrad on the bf16 W'^T, LoRA gradients from the bf16 activations (straight-through: the quantiser has no
-        gradient of its own).  shared: a weight dict that already holds '<key>.weight_q' / '<key>.wscale' of the FROZEN linears
+        y = s_a[m] s_w[n] (e4m3(x) . e4m3(W)^T) on the fp8 MFMA: activations quantised per token right before each GEMM, the FROZEN
+        weights per output row, once; the LoRA branch B (A dropout(x)) stays a bf16 rank-r product added to it.  The BACKWARD is
+        unchanged: dgrad on the bf16 W^T, LoRA gradients from the bf16 activations (straight-through: the quantiser has no
+        gradient of its own).  shared: a weight dict that already holds '<key>.weight_q' / '<key>.wscale' of the frozen linears
         (the teacher engine after enable_fp8()) -- reused instead of a second copy."""
         self.fp8 = True
         for key in self._linear_keys():
-            if key in self.by_key or shared is None or key + '.weight_q' not in shared:
+            if shared is None or key + '.weight_q' not in shared:
                 self.wq[key] = ops.quant_rows_fp8(self.packed[key + '.weight'])
             else:
                 self.wq[key] = (shared[key + '.weight_q'], shared[key + '.wscale'])
 
-    def _lin(self, x: torch.Tensor, key: str, rows: Optional[slice] = None, out: Optional[torch.Tensor] = None,
-             pre: Optional[torch.Tensor] = None, xq=None, **kw) -> torch.Tensor:
-        """x [M, K] @ packed[key].weight[rows].T + bias[rows] (+ pre) through the bf16 or the fp8 GEMM.  xq: (q, scale) of x when
-        the caller already quantised it for another linear."""
+    def _lin(self, x: torch.Tensor, key: str, out: Optional[torch.Tensor] = None, **kw) -> torch.Tensor:
+        """An UN-adapted block linear: x [M, K] @ packed[key].weight.T + bias through the bf16 or the fp8 GEMM."""
         w, b = self.packed[key + '.weight'], self.packed[key + '.bias']
-        if rows is not None:
-            w, b = w[rows], b[rows]
         if not self.fp8:
-            return ops.linear(x, w, b, out=out, pre=pre, **kw)
+            return ops.linear(x, w, b, out=out, **kw)
         q, sc = self.wq[key]
-        if rows is not None:
-            q, sc = q[rows], sc[rows]
-        aq, asc = xq if xq is not None else ops.quant_rows_fp8(x)
-        y = ops.linear_fp8(aq, asc, q, sc, b, out=out, **kw)
-        if pre is not None:                                      # the fp8 kernel has no pre-add input: one more pass, same value up to a rounding
-            assert kw.get('epilogue', 'none') == 'none'
-            ops.add_scale(y, b=pre, out=y)
-        return y
+        aq, asc = ops.quant_rows_fp8(x)
+        return ops.linear_fp8(aq, asc, q, sc, b, out=out, **kw)
+
+    def _xe(self, rows: int, in_f: int) -> torch.Tensor:
+        """[rows, in_f + rp] activation buffer of an adapted linear: x goes into [:, :in_f], t = dropout(x) A^T into the next rp
+        columns (A is zero-padded to rp rows, so the columns past r come out as exact zeros)."""
+        return torch.empty(rows, in_f + self.rp, dtype=torch.bfloat16, device=self.dev)
+
+    def _adapted(self, sp: LoraSpec, xe: torch.Tensor, row_off: int, out: Optional[torch.Tensor] = None, main: bool = True):
+        """peft LoRA linear on xe = [x | . ] ([M, in + rp], x already in place):  xd = dropout(x);  t = xd A^T -> xe[:, in:in+r];
+        out = [x | t] [W | B]^T + bias for ALL rows of the packed weight (the fused single-block weight carries zero B columns on its
+        k|v|q rows).  main=False: only xd and t (the recompute of a branch's last linear, whose output the backward does not need).
+        Returns (xd, t, out)."""
+        i, r, key = sp.in_f, self.r, sp.packed_key
+        x, t = xe[:, :i], xe[:, i:i + r]
+        xd = x if self.p_drop <= 0 else ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
+        self._skinny(xd, self.a16p[sp.name], out=xe[:, i:])
+        if not main:
+            return xd, t, None
+        b = self.packed[key + '.bias']
+        if not self.fp8:
+            return xd, t, ops.linear(xe, self.wcat[key], b, out=out)
+        q, sc = self.wq[key]
+        aq, asc = ops.quant_rows_fp8(x)
+        y = ops.linear_fp8(aq, asc, q, sc, b, out=out)
+        yl = y[:, sp.row0:sp.row0 + sp.out_f]
+        corr = ops.linear(xe[:, i:], self.wcat[key][sp.row0:sp.row0 + sp.out_f, i:])      # t B^T  (K = rp)
+        ops.add_scale(yl, b=corr, out=yl)
+        return xd, t, y
+
+    def _adapted_backward(self, sp: LoraSpec, dy: torch.Tensor, xd: torch.Tensor, t: torch.Tensor, grads: torch.Tensor, row_off: int):
+        """dy [M, out_total] (all rows of the packed weight), xd = dropout(x) [M, in], t = xd A^T [M, r] from the recompute.
+        dB += dy^T t;  dA += (dy B)^T xd;  returns dx = dy W + ((dy B) A) . keep/(1-p)  as a view [M, in] of an [M, in + rp] buffer."""
+        i, r = sp.in_f, self.r
+        dxe = ops.linear(dy, self.wtcat[sp.packed_key])                       # [dx0 | dT | 0]
+        dx, dT = dxe[:, :i], dxe[:, i:i + r]
+        dyl = dy[:, sp.row0:sp.row0 + sp.out_f]
+        ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)     # contraction over the tokens
+        ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
+        ops.lora_dropout(ops.linear(dxe[:, i:], self.at16p[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=3, out=dx)
+        return dx
 
     def block_slice(self, block: int) -> Tuple[int, int]:
         """[a, b) of the flat parameter / gradient buffer holding the adapters of transformer block ``block``
@@ -206,7 +250,34 @@ class LoraTrunk:
         return (min(sp.off_a for sp in sps), max(sp.off_b + sp.out_f * self.r for sp in sps))
 
     def merged_state(self) -> Dict[str, torch.Tensor]:
-        return {sp.name: self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f] for sp in self.specs}
+        """W + B A per adapted linear (fp32 accumulate, one rounding) -- built on request (export, tests); training never merges."""
+        out = {}
+        for sp in self.specs:
+            w = self.packed[sp.packed_key + '.weight'][sp.row0:sp.row0 + sp.out_f]
+            ones = self._ones.setdefault(sp.in_f, torch.ones(1, sp.in_f, dtype=torch.float32, device=self.dev))
+            if self.r % 64 == 0:
+                b16, at = self.b16[sp.name], self.at16[sp.name]
+            else:
+                b16 = torch.zeros(sp.out_f, self.rp, dtype=torch.bfloat16, device=self.dev)
+                b16[:, :self.r] = self.b16[sp.name]
+                at = torch.zeros(sp.in_f, self.rp, dtype=torch.bfloat16, device=self.dev)
+                at[:, :self.r] = self.at16[sp.name]
+            out[sp.name] = ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=w.contiguous(), rows_per_batch=sp.out_f)
+        return out
+
+    def bind_merged(self) -> None:
+        """Give the student ENGINE the merged weights W + B A of the live adapters (validation / inference with the distiller's own
+        student; the training step itself never needs them: its blocks run through this trunk on the extended frozen weights)."""
+        ms = self.merged_state()
+        upd = {}
+        for key, sps in self.by_key.items():
+            m = self._merged.get(key)
+            if m is None:
+                m = self._merged[key] = self.packed[key + '.weight'].clone()
+            for sp in sps:
+                m[sp.row0:sp.row0 + sp.out_f].copy_(ms[sp.name])
+            upd[key + '.weight'] = m
+        self.eng.bind_packed(upd)
 
     # ------------------------------------------------------------------ LoRA gradients of one linear
     def _dmod_ln(self, x: torch.Tensor, dxn: torch.Tensor, off_scale: int, off_shift: int) -> None:
@@ -277,39 +348,13 @@ class LoraTrunk:
         return (self.seed * 0x9E3779B1 + (sp.off_a * 2654435761 % (1 << 32))) & 0xffffffff
 
     @staticmethod
-    def _skinny(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    def _skinny(x: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """x [M, K] @ w[r, K].T with r = the LoRA rank (256 columns): a launch of 8-72 tiles whose time is the length of its K loop.  For the
-        K >= 8192 sites (mlp1's dy B, mlp2's / proj_out's x A^T) eight K chunks into fp32 slabs + one fold pass halve it (101 -> 49 us at
+        K >= 8192 sites (mlp2's / proj_out's x A^T) eight K chunks into fp32 slabs + one fold pass halve it (101 -> 49 us at
         4096 x 256 x 12288, 98 -> 34 us for the 512-row text stream; at K = 3072 the plain launch is as fast: tools/skinny_bench.py)."""
         if w.shape[1] >= 8192 and _LORA_SPLITK:
-            return ops.linear_splitk(x, w, split_k=8 if x.shape[0] > 1024 else 16)
-        return ops.linear(x, w)
-
-    def _corr(self, sp: Optional[LoraSpec], x: torch.Tensor, row_off: int) -> Optional[torch.Tensor]:
-        """B A (x . delta): what lora_dropout adds to the merged-weight product (None without dropout / adapter)."""
-        if sp is None or self.p_drop <= 0:
-            return None
-        xd = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=0)
-        return ops.linear(self._skinny(xd, self.a16[sp.name]), self.b16[sp.name])
-
-    def _dx_extra(self, sp: Optional[LoraSpec], dT: Optional[torch.Tensor], dx: torch.Tensor, row_off: int) -> None:
-        """dx += ((dy B) A) . delta -- the input gradient of the dropout correction."""
-        if sp is None or dT is None or self.p_drop <= 0:
-            return
-        ops.lora_dropout(ops.linear(dT, self.at16[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=2, out=dx)
-
-    def _lora_grad(self, sp: LoraSpec, x: torch.Tensor, dy: torch.Tensor, grads: torch.Tensor, row_off: int = 0):
-        """x [M, in], dy [M, out] bf16 (row-strided views).  dA += (dy B)^T x~ ;  dB += dy^T (x~ A^T), x~ = dropout(x).
-        Returns dy B [M, r]."""
-        if self.p_drop > 0:
-            x = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
-        t = self._skinny(x, self.a16[sp.name])                   # [M, r]
-        dT = self._skinny(dy, self.bt16[sp.name])                # [M, r]
-        xt, dyt = ops.transpose(x, 64), ops.transpose(dy, 64)    # contraction over the M tokens
-        tt, dTt = ops.transpose(t, 64), ops.transpose(dT, 64)
-        ops.linear_f32out(dyt, tt, out=self.B(sp, grads), accumulate=True)
-        ops.linear_f32out(dTt, xt, out=self.A(sp, grads), accumulate=True)
-        return dT
+            return ops.linear_splitk(x, w, out=out, split_k=8 if x.shape[0] > 1024 else 16)
+        return ops.linear(x, w, out=out)
 
     # ------------------------------------------------------------------ helpers on strided 2-D views
     def _rope(self, x, y, w_txt, w_img, cos, sin, S, T, dy=None):
@@ -343,9 +388,13 @@ class LoraTrunk:
         self._rope(Kp, K, qkn[3], qkn[1], cos, sin, S, T)
         self._rope(Qp, Q, qkn[2], qkn[0], cos, sin, S, T)
         lse = ops.attention_fwd_lse_2d(Q, K, V, O, 1, S, self.H)
-        X1, Xn2 = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
-        Pre, Hh = torch.empty(S, 4 * D, **bf), torch.empty(S, 4 * D, **bf)
+        X1 = torch.empty(S, D, **bf)
+        Xe2 = self._xe(S, D)                                     # [Xn2 | t1]: the mlp1 operand
+        He = self._xe(S, 4 * D)                                  # [gelu(Pre) | t2]: the mlp2 operand
+        Xn2, Hh = Xe2[:, :D], He[:, :4 * D]
+        Pre = torch.empty(S, 4 * D, **bf)
         Xo = torch.empty(S, D, **bf) if fwd_only else None
+        keep = {}                                                # per stream: (xd1, t1, xd2, t2) of the two adapters
         for s, rows, _ in self._streams(T, S):
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
             if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
@@ -355,12 +404,22 @@ class LoraTrunk:
             else:
                 self._lin(O[rows], p + s + '_out', epilogue='gate_res', gate=mv[(s, 2)], residual=X[rows], out=X1[rows])
             ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-            self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows], pre=self._corr(sp1, Xn2[rows], rows.start))
+            if sp1 is not None:
+                xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows])
+            else:
+                xd1 = t1 = None
+                self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows])
             ops.gelu(Pre[rows], out=Hh[rows])
+            y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows] if fwd_only else None
+            if sp2 is not None:
+                xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only)
+            else:
+                xd2 = t2 = None
+                if fwd_only:
+                    self._lin(Hh[rows], p + s + '_mlp2', out=y2)
             if fwd_only:
-                y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows]
-                self._lin(Hh[rows], p + s + '_mlp2', out=y2, pre=self._corr(sp2, Hh[rows], rows.start))
                 ops.gate_residual(y2, mv[(s, 5)], X1[rows], out=Xo[rows])
+            keep[s] = (xd1, t1, xd2, t2)
         if fwd_only:
             return Xo
         # ---- backward ----
@@ -369,13 +428,16 @@ class LoraTrunk:
         for s, rows, _ in self._streams(T, S):
             dY2 = ops.add_scale(dXo[rows], gate=mv[(s, 5)])
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-            dT2 = self._lora_grad(sp2, Hh[rows], dY2, grads, rows.start) if sp2 is not None else None
-            dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
-            self._dx_extra(sp2, dT2, dH, rows.start)
+            xd1, t1, xd2, t2 = keep[s]
+            if sp2 is not None:
+                dH = self._adapted_backward(sp2, dY2, xd2, t2, grads, rows.start)
+            else:
+                dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
             dPre = ops.gelu(Pre[rows], dh=dH)
-            dT1 = self._lora_grad(sp1, Xn2[rows], dPre, grads, rows.start) if sp1 is not None else None
-            dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
-            self._dx_extra(sp1, dT1, dXn2, rows.start)
+            if sp1 is not None:
+                dXn2 = self._adapted_backward(sp1, dPre, xd1, t1, grads, rows.start)
+            else:
+                dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
             ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
             if self.dmod is not None:      # d(shift3, scale4, gate5, gate2) of this stream
                 so = m0 + (0 if s == 'img' else 6) * D
@@ -408,40 +470,33 @@ class LoraTrunk:
         qkn = pk[p + 'qknorm']                                   # [q, k]
         bf = dict(dtype=torch.bfloat16, device=dev)
         sp_out, sp_mlp = self._spec(p + 'out'), self._spec(p + 'fused')
-        Xn = ops.norm_modulate(X, sc, sh)
-        corr = self._corr(sp_mlp, Xn, 0)
-        if corr is None:
-            Fp = self._lin(Xn, p + 'fused')                      # [S, 7D] pre-activation k|v|q|mlp
-        else:                                                    # the correction only touches the proj_mlp columns
-            Fp = torch.empty(S, 7 * D, **bf)
-            xq = ops.quant_rows_fp8(Xn) if self.fp8 else None
-            self._lin(Xn, p + 'fused', rows=slice(0, 3 * D), out=Fp[:, :3 * D], xq=xq)
-            self._lin(Xn, p + 'fused', rows=slice(3 * D, 7 * D), out=Fp[:, 3 * D:], pre=corr, xq=xq)
+        Xe = self._xe(S, D)                                      # [Xn | t_mlp]: operand of the fused k|v|q|mlp launch
+        Xn = Xe[:, :D]
+        ops.norm_modulate(X, sc, sh, out=Xn)
+        Fp = torch.empty(S, 7 * D, **bf)                         # pre-activation k|v|q|mlp
+        xd_m, t_m, _ = self._adapted(sp_mlp, Xe, 0, out=Fp)      # (the k|v|q rows of wcat carry zero B columns)
         Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
-        G = torch.empty(S, 5 * D, **bf)                          # [O | gelu(mlp)] = proj_out operand
+        Ge = self._xe(S, 5 * D)                                  # [O | gelu(mlp) | t_out] = proj_out operand
+        G = Ge[:, :5 * D]
         self._rope(Kp, K, qkn[1], qkn[1], cos, sin, S, T)
         self._rope(Qp, Q, qkn[0], qkn[0], cos, sin, S, T)
         lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
         ops.gelu(Mp, out=G[:, D:])
+        y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S] if fwd_only else None
+        xd_o, t_o, _ = self._adapted(sp_out, Ge, 0, out=y, main=fwd_only)
         if fwd_only:
-            y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S]
-            self._lin(G, p + 'out', out=y, pre=self._corr(sp_out, G, 0))
             return ops.gate_residual(y, gt, X)
         # ---- backward ----
         dY = ops.add_scale(dXo, gate=gt)
-        dT_out = self._lora_grad(sp_out, G, dY, grads) if sp_out is not None else None
-        dG = ops.linear(dY, self.wt[p + 'out'])                  # [S, 5D]
-        self._dx_extra(sp_out, dT_out, dG, 0)
+        dG = self._adapted_backward(sp_out, dY, xd_o, t_o, grads, 0)          # [S, 5D] (view)
         dFp = torch.empty(S, 7 * D, **bf)
         ops.gelu(Mp, dh=dG[:, D:], out=dFp[:, 3 * D:])
-        dT_mlp = self._lora_grad(sp_mlp, Xn, dFp[:, 3 * D:], grads) if sp_mlp is not None else None
         dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         ops.attention_bwd_2d(Q, K, V, G[:, :D], dG[:, :D], lse, dQ, dK, dFp[:, D:2 * D], 1, S, self.H)
         self._rope(Kp, dFp[:, :D], qkn[1], qkn[1], cos, sin, S, T, dy=dK)
         self._rope(Qp, dFp[:, 2 * D:3 * D], qkn[0], qkn[0], cos, sin, S, T, dy=dQ)
-        dXn = ops.linear(dFp, self.wt[p + 'fused'])
-        self._dx_extra(sp_mlp, dT_mlp, dXn, 0)
+        dXn = self._adapted_backward(sp_mlp, dFp, xd_m, t_m, grads, 0)        # dgrad over all 7D columns; dT / dB from the mlp columns
         if self.dmod is not None:          # d(shift, scale, gate) of the single-stream AdaLN
             ops.coldot(dXo, self.ybuf[2 * self.nd + i, self.row0:self.row0 + S], self.dmod[m0 + 2 * D:m0 + 3 * D])
             self._dmod_ln(X, dXn, m0 + D, m0)

@@ -381,7 +381,7 @@ int afx_linear_sk_last_split(void);
  * AFX_GEMM_IMPL / AFX_GEMM_TILE environment variables, which it overrides.  Returns 0. */
 int afx_gemm_set_mode(int32_t impl, int32_t tile);
 /* Kernel choice of every joint attention launch (process-wide; same meaning as AFX_ATTN_IMPL, which it overrides): 0 (default) = the
- * one-wave-per-SIMD kernel (afx_attn3.hip: 64 queries per wave, S % 64 == 0) where eligible, else the 4-wave kernel; 1 = 4-wave kernel
+ * one-wave-per-SIMD kernel (afx_attn3.hip: 64 queries per wave, any S > 64: ragged tails handled) where eligible, else the 4-wave kernel; 1 = 4-wave kernel
  * always; 2 = 8-wave ping-pong kernel (experimental).  For A/B runs and the parity tests.  Returns 0. */
 int afx_attn_set_impl(int32_t impl);
 int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
@@ -389,7 +389,7 @@ int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, c
                        int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
                        int32_t rows_per_batch, const void* res, int64_t ldr, void* sk_ws, void* stream);
 /* LoRA input dropout masks from a counter-based hash of (seed, row0 + row, col), keep probability 1 - p, delta = keep/(1-p) - 1:
- * mode 0: dst = src * delta;  1: dst = src * (1 + delta) (= dropout(src));  2: dst += src * delta */
+ * mode 0: dst = src * delta;  1: dst = src * (1 + delta) (= dropout(src));  2: dst += src * delta;  3: dst += src * (1 + delta) */
 int afx_lora_dropout_bf16(const void* src, int64_t lds_, void* dst, int64_t ldd, int64_t M, int32_t N, int64_t row0, float p,
                           uint32_t seed, int32_t mode, void* stream);
 

@@ -174,12 +174,13 @@ def test_exported_adapter_loads_into_the_pipeline(tmp_path):
     pipe = ArcFluxPipeline.from_state_dict(tcfg, base, student=False)
     assert pipe.load_arcflow_adapter(out) == 'transformer_arcflow'
     assert pipe.policy_config == {'denoising_mean_mode': 'U', 'type': 'ArcFlow'}
-    # the adapted student of the pipeline (LoRA folded at load) == the distiller's live student (LoRA merged per step)
+    # the adapted student of the pipeline (LoRA folded at load) == the distiller's live student (LoRA merged on request)
     g = torch.Generator().manual_seed(11)
     x = torch.randn(1, 64, 64, generator=g).bfloat16().cuda()
     c = _cond(B=1)
     t = torch.tensor([0.7], device='cuda')
     gd = torch.full((1,), 3.5, device='cuda')
+    d.trunk.bind_merged()              # training runs the adapters unmerged; the engine gets W + B A on request
     o1 = d.student.forward(x, t, c['prompt_embeds'], c['pooled'], gd, 8, 8)
     o2 = pipe.transformer.forward(x, t, c['prompt_embeds'], c['pooled'], gd, 8, 8)
     for k in ('means', 'logweights', 'loggammas'):

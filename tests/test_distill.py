@@ -731,7 +731,7 @@ def test_student_fp8_forward_bf16_grads_step(family):
         for sp in tr.specs:
             tr.B(sp).copy_(Bs[sp.name].cuda())
         tr.refresh()
-        if fp8:     # the adapted weights were re-quantised from the merged copies; frozen ones come from the fp8 teacher when it has them
+        if fp8:     # every block linear's FROZEN weight is quantised once (the LoRA branch stays a bf16 rank-r product); shared with the fp8 teacher when it has them
             key = tr.specs[0].packed_key
             q, sc = tr.wq[key]
             wm = tr.packed[key + '.weight'].float()
@@ -743,7 +743,7 @@ def test_student_fp8_forward_bf16_grads_step(family):
         info = dist.train_step(cond, B, x_init=x0.cuda(), draws=draws)
         assert not info['skipped']
         res[fp8] = (info['loss'], dist.grads[0].clone(), dist.last_x.clone())
-        # the optimizer step re-merged and re-quantised the adapted weights
+        # an optimizer step leaves the quantised frozen weights alone
         if fp8:
             q2, sc2 = tr.wq[key]
             wm2 = tr.packed[key + '.weight'].float()

@@ -3,7 +3,7 @@
 
 The kernel's main loop is a hand-placed stream: every instruction is its own `asm volatile` statement, so the
 source order is the issue order.  All wide operands are ASM-OWNED: they appear by literal register name in the
-instruction text, hipcc never sees a variable behind them.  The kernel carries `amdgpu_num_vgpr(192)`, which
+instruction text, hipcc never sees a variable behind them.  The kernel carries `amdgpu_num_vgpr(96)`, which
 confines hipcc's own allocation to v[0:95] (and a[0:95], which it must never need: arcflow_amd/build.py audits the
 ISA for accumulator moves / scratch traffic outside the asm statements); everything above is this file's:
 
