@@ -143,6 +143,9 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
     asm volatile("" : "+v"(qf[s]));
     asm volatile("" : "+v"(dof[s]));
   }
+  // (Measured in round 4, same box, S = 4608 / H = 24: this compiler-scheduled form with two waves per SIMD 434-450 us; fragments requested
+  // as one batch per 16-MFMA group behind sched_barrier fences 531 us; one wave per SIMD with the dK / dV kernel's five regions 628 us.
+  // With two waves the partner's MFMAs already cover the ds_read -> mfma latency and the fences only remove overlap.)
   for (int t = 0; t < ntiles; ++t) {
     const char* ks = smem + (t & 1) * DQ_STAGE;
     const char* vs = ks + ROWMAJ_BYTES;
@@ -264,6 +267,92 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     asm volatile("" : "+v"(kf[s]));
     asm volatile("" : "+v"(vf[s]));
   }
+  // One KV-stationary wave per SIMD: the loop is laid out in five scheduling regions per query tile so that every LDS fragment is
+  // requested a whole MFMA group (16 x 32 cycles) before its first use -- left alone hipcc emits ds_read / s_waitcnt lgkmcnt(0) / mfma
+  // triples (the full LDS latency in front of every one of the 64 MFMAs of a tile: 7.7 k cycles per tile for 2 k of matrix work) --
+  // and so that the exp / dS arithmetic of one 32-query half sits in the same region as the other half's MFMAs:
+  //   R0  read F1 (Q, dO rows of half 0)
+  //   R1  read F3 (half 1)                  | S0 = Q0 K^T, dP0 = dO0 V^T
+  //   R2  read F2 (dO^T, Q^T cols of half 0) | S1, dP1                       | P0 = exp2(S0 c - L), dS0 = P0 (dP0 - delta) / sqrt(d)
+  //   R3  read F4 (half 1)                  | dV^T += dO0^T P0, dK^T += Q0^T dS0 | P1, dS1
+  //   R4                                     | dV^T += dO1^T P1, dK^T += Q1^T dS1
+  auto load_rows = [&](bf16x8_t (&f)[16], f32x4_t (&l4)[4], f32x4_t (&d4)[4], const char* qs, const char* dos, const float* lst,
+                       const float* dst, int qb) {
+    const int qrow = qb * 32 + kl;                         // A-operand row of this lane = a query of the tile
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      f[s] = frag_rowmaj(qs, qrow, s * 2 + hi);
+      f[8 + s] = frag_rowmaj(dos, qrow, s * 2 + hi);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {                          // L / delta of the half's queries this lane's registers hold (broadcast reads)
+      l4[g] = *reinterpret_cast<const f32x4_t*>(lst + qb * 32 + 8 * g + 4 * hi);
+      d4[g] = *reinterpret_cast<const f32x4_t*>(dst + qb * 32 + 8 * g + 4 * hi);
+    }
+  };
+  auto load_cols = [&](bf16x8_t (&f)[16], const char* dots, const char* qts, int qb) {
+#pragma unroll
+    for (int ksub = 0; ksub < 2; ++ksub) {
+      const int chunk = (qb * 2 + ksub) * 2 + hi;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        f[ksub * 8 + d] = frag_trans(dots, d * 32 + kl, chunk);
+        f[ksub * 8 + 4 + d] = frag_trans(qts, d * 32 + kl, chunk);
+      }
+    }
+  };
+  auto sdp = [&](const bf16x8_t (&f)[16], f32x16_t& sa, f32x16_t& dp) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[s], kf[s], sa, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[8 + s], vf[s], dp, 0, 0, 0);
+    }
+  };
+  // lane = key (column), register r = query 32 qb + (r&3) + 8 (r>>2) + 4 hi
+  auto softmax_grad = [&](const f32x16_t& sa, const f32x16_t& dp, const f32x4_t (&l4)[4], const f32x4_t (&d4)[4], bf16x8_t (&pf)[2],
+                          bf16x8_t (&df)[2]) {
+    float pv[16], dsv[16];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const float p = k_ok ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - l4[g][e]) : 0.f;
+        pv[r] = p;
+        dsv[r] = p * (dp[r] - d4[g][e]) * SCALE;
+      }
+    }
+#pragma unroll
+    for (int ksub = 0; ksub < 2; ++ksub) {
+      float t0[8], t1[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        t0[j] = pv[ksub * 8 + j];
+        t1[j] = dsv[ksub * 8 + j];
+      }
+      pf[ksub] = __builtin_bit_cast(bf16x8_t, pack8(t0));
+      df[ksub] = __builtin_bit_cast(bf16x8_t, pack8(t1));
+    }
+  };
+  auto dvdk = [&](const bf16x8_t (&f)[16], const bf16x8_t (&pf)[2], const bf16x8_t (&df)[2]) {
+#pragma unroll
+    for (int ksub = 0; ksub < 2; ++ksub)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ksub * 8 + d], pf[ksub], dva[d], 0, 0, 0);
+        dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f[ksub * 8 + 4 + d], df[ksub], dka[d], 0, 0, 0);
+      }
+  };
+  // (MFMA, LDS read, VALU) triples: one matrix instruction, one fragment read for the next group and a slice of the other half's
+  // arithmetic per 32-cycle MFMA slot
+#define AFX_BWD_INTERLEAVE(NV)                                   \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {            \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
+    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);          \
+  }
   for (int t = 0; t < ntiles; ++t) {
     const char* qs = smem + (t & 1) * DKV_STAGE;
     const char* dos = qs + ROWMAJ_BYTES;
@@ -272,52 +361,28 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     const float* lst = reinterpret_cast<const float*>(dots + TRANS_BYTES);
     const float* dst = lst + TB;
     if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      f32x16_t sa, dp;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sa[r] = dp[r] = 0.f;
-      const int qrow = qb * 32 + kl;                       // A-operand row of this lane = a query of the tile
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        sa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(qs, qrow, s * 2 + hi), kf[s], sa, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_rowmaj(dos, qrow, s * 2 + hi), vf[s], dp, 0, 0, 0);
-      }
-      // lane = key (column), register r = query 32 qb + (r&3) + 8 (r>>2) + 4 hi
-      float pv[16], dsv[16];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4_t l4 = *reinterpret_cast<const f32x4_t*>(lst + qb * 32 + 8 * g + 4 * hi);
-        const f32x4_t d4 = *reinterpret_cast<const f32x4_t*>(dst + qb * 32 + 8 * g + 4 * hi);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float p = k_ok ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - l4[e]) : 0.f;
-          pv[r] = p;
-          dsv[r] = p * (dp[r] - d4[e]) * SCALE;
-        }
-      }
-#pragma unroll
-      for (int ksub = 0; ksub < 2; ++ksub) {
-        float t0[8], t1[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          t0[j] = pv[ksub * 8 + j];
-          t1[j] = dsv[ksub * 8 + j];
-        }
-        const u32x4_t w0 = pack8(t0), w1 = pack8(t1);
-        const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, w0);
-        const bf16x8_t df = __builtin_bit_cast(bf16x8_t, w1);
-        const int chunk = (qb * 2 + ksub) * 2 + hi;
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          dva[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(dots, d * 32 + kl, chunk), pf, dva[d], 0, 0, 0);
-          dka[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_trans(qts, d * 32 + kl, chunk), df, dka[d], 0, 0, 0);
-        }
-      }
-    }
+    bf16x8_t fa[16], fb[16], pf0[2], df0[2], pf1[2], df1[2];
+    f32x16_t sa0, dp0, sa1, dp1;
+    f32x4_t l0[4], d0[4], l1[4], d1[4];
+    load_rows(fa, l0, d0, qs, dos, lst, dst, 0);             // R0
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(fb, l1, d1, qs, dos, lst, dst, 1);             // R1
+    sdp(fa, sa0, dp0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_cols(fa, dots, qts, 0);                             // R2
+    sdp(fb, sa1, dp1);
+    softmax_grad(sa0, dp0, l0, d0, pf0, df0);
+    AFX_BWD_INTERLEAVE(9)
+    __builtin_amdgcn_sched_barrier(0);
+    load_cols(fb, dots, qts, 1);                             // R3
+    dvdk(fa, pf0, df0);
+    softmax_grad(sa1, dp1, l1, d1, pf1, df1);
+    AFX_BWD_INTERLEAVE(9)
+    __builtin_amdgcn_sched_barrier(0);
+    dvdk(fb, pf1, df1);                                      // R4
     AFX_SYNC_DMA();
   }
+#undef AFX_BWD_INTERLEAVE
   if (k_ok) {
     bf16_t* kp_o = dk + ((int64_t)b * S + k0 + kl) * lddk + h * HD;
     bf16_t* vp_o = dv + ((int64_t)b * S + k0 + kl) * lddv + h * HD;
