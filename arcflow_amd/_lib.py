@@ -22,7 +22,7 @@ EXPORTS = [
     'afx_norm_modulate_bf16', 'afx_qk_norm_rope_bf16', 'afx_gemv_bf16',
     'afx_attention_fwd_lse_bf16', 'afx_attention_bwd_ws_bytes', 'afx_attention_bwd_bf16',
     'afx_ln_modulate_backward', 'afx_qk_norm_rope_oop_bf16', 'afx_gelu_bf16', 'afx_add_scale_bf16',
-    'afx_conv3x3_bf16', 'afx_conv3x3_bf16_stats', 'afx_groupnorm_nhwc_from_stats', 'afx_conv_stats_available', 'afx_upconv3x3_bf16', 'afx_groupnorm_nhwc', 'afx_upsample2x_nhwc', 'afx_interior_nhwc', 'afx_softmax_rows_f32',
+    'afx_conv3x3_bf16', 'afx_conv3x3_bf16_stats', 'afx_groupnorm_nhwc_from_stats', 'afx_conv_stats_available', 'afx_upconv3x3_bf16', 'afx_groupnorm_nhwc', 'afx_groupnorm_ws_bytes', 'afx_upsample2x_nhwc', 'afx_interior_nhwc', 'afx_softmax_rows_f32',
     'afx_latent_to_nhwc', 'afx_nhwc_to_image', 'afx_latent_to_nhwc_affine', 'afx_rmsnorm_nhwc',
     'afx_embed_rows_bf16', 'afx_norm_rows_bf16', 'afx_act_mul_bf16', 'afx_rope_half_bf16', 'afx_attention_ext_ws_bytes',
     'afx_attention_ext_bf16', 'afx_linear_bf16_splitk', 'afx_finish_f32_bf16', 'afx_linear_splitk_chunks', 'afx_quant_rows_fp8', 'afx_linear_fp8',
@@ -91,6 +91,8 @@ def load() -> C.CDLL:
     lib.afx_add_scale_bf16.argtypes = [vp, i64, vp, i64, vp, i64, i32, vp, i64, i64, i32, vp]
     lib.afx_conv3x3_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.afx_groupnorm_nhwc.argtypes = [vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, i32, vp]
+    lib.afx_groupnorm_ws_bytes.argtypes = [i32, i32]
+    lib.afx_groupnorm_ws_bytes.restype = i64
     lib.afx_conv3x3_bf16_stats.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, i32, vp]
     lib.afx_groupnorm_nhwc_from_stats.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp, vp, f32, i32, vp]
     lib.afx_conv_stats_available.argtypes = []

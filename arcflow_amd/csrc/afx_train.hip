@@ -730,12 +730,26 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
   hipStream_t st = (hipStream_t)stream;
   // [waves][2][D] fp32 scratch, kept per stream and grown on demand (hipMallocAsync / hipFreeAsync per call cost ~20 us of the 30 us a 512-row
   // call took); calls on one stream are ordered, so the buffer is free again when the next call's first kernel starts
-  static std::mutex ws_mu;
-  static std::map<hipStream_t, std::pair<float*, size_t>> ws_map;
+  // keyed by (device, stream): the NULL stream and recycled stream handles exist on every device of a process, and a buffer of device 0
+  // must never serve a call on device 1.  The buffers live until the library is unloaded (NormoutScratch's destructor).
+  // Growing one calls hipFree / hipMalloc -- device-synchronising, illegal under stream capture -- so it only happens when a LARGER
+  // shape shows up on that (device, stream); the split reduction below ends in float atomics over 8 splits: d_mod is reproducible to
+  // the rounding of that sum's order, not bit for bit (documented in include/arcflow_hip.h).
+  struct NormoutScratch {
+    std::mutex mu;
+    std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> map;
+    ~NormoutScratch() {
+      for (auto& kv : map)
+        if (kv.second.first != nullptr) (void)hipFree(kv.second.first);
+    }
+  };
+  static NormoutScratch ws;
+  int dev_id = 0;
+  HIP_TRY(hipGetDevice(&dev_id));
   float* part = nullptr;
   {
-    std::lock_guard<std::mutex> lk(ws_mu);
-    auto& e = ws_map[st];
+    std::lock_guard<std::mutex> lk(ws.mu);
+    auto& e = ws.map[std::make_pair(dev_id, st)];
     const size_t need = (size_t)waves * 2 * D * sizeof(float);
     if (e.second < need) {
       if (e.first != nullptr) HIP_TRY(hipFree(e.first));          // (synchronises: only when a larger shape shows up)

@@ -398,6 +398,11 @@ int afx_upconv3x3_bf16(const void* x, const void* w4, const void* bias, void* y,
 int afx_conv_stats_available(void) { return gemm_conv_stats_available() ? 1 : 0; }
 
 
+int64_t afx_groupnorm_ws_bytes(int32_t C, int32_t groups) {
+  if (C < 8 || C > 2048 || groups < 1 || groups > 64) return AFX_E_INVALID;
+  return (int64_t)sizeof(double) * ((2 + 2 * GN_SLOTS) * (int64_t)groups + C);
+}
+
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream) {
   // stats_ws layout (doubles): [0, 2 groups) the sums | [2 groups, 2 groups + C) the 2 C float coefficients | then AFX_GN_SLOTS x 2 groups slot partials

@@ -151,7 +151,7 @@ class AutoencoderKLDecoder:
         if self._fold_up:
             for k in [k for k in self.w if '.upsamplers.0.conv.weight' in k]:
                 self.w[k[:-len('.weight')] + '.weight4'] = phase_weights(self.w[k], self.w[k].shape[1] // 9)
-        self._stats = torch.zeros((2 + 2 * 64) * self.groups + 2048, dtype=torch.float64, device=self.dev)   # afx_groupnorm_nhwc's scratch
+        self._stats = torch.zeros(int(self.lib.afx_groupnorm_ws_bytes(2048, self.groups)) // 8, dtype=torch.float64, device=self.dev)   # afx_groupnorm_nhwc's scratch, sized by the library
         self._pool = _GridPool(self.dev)
         # GroupNorm sums out of the producing convolution's epilogue: a ring of slotted buffers (a grid's sums live until its norm ran:
         # at most the block input + conv1 output at a time; 4 is generous)

@@ -40,9 +40,12 @@ def merge_lora(sd: Dict[str, Tensor], lora: Optional[Dict[str, Tensor]], scale: 
 
 
 def _merge_one(w: Tensor, a: Tensor, b: Tensor, scale: float) -> Tensor:
-    """W + scale * B A, accumulated in fp32, rounded once.  On the GPU this is the library's own fp32-accumulating GEMM
-    (`afx_linear_bf16_f32out`, C += B . (A^T)^T with the rank as the contraction, zero-padded to the kernel's K granule); the
-    host branch only serves weights that are packed on a machine without a device (the CPU tests)."""
+    """W + scale * B A, the sum accumulated in fp32 and rounded once to W's dtype.  On the GPU this is the library's own
+    fp32-accumulating GEMM (`afx_linear_bf16_f32out`, C += B . (A^T)^T with the rank as the contraction, zero-padded to the
+    kernel's K granule): its OPERANDS are bf16, so `B * scale` and `A` are rounded to bf16 first -- exact for the released bf16
+    adapters, a 2^-9 relative perturbation of the delta B A for fp32 / fp16 adapter files (the same rounding the training engine
+    applies to its bf16 working copies of A and B; bounded in tests/test_pipeline.py::test_lora_merge_gpu_vs_host_branch).  The host
+    branch forms the delta from the fp32 tensors; it only serves weights packed on a machine without a device (the CPU tests)."""
     if not (w.is_cuda or (torch.cuda.is_available() and a.is_cuda)):
         delta = (b.to(torch.float32) @ a.to(torch.float32)) * scale
         return (w.float() + delta).to(w.dtype)

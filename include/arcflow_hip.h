@@ -201,7 +201,9 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
                            int32_t N, int32_t K, int32_t accumulate, void* stream);
 int afx_transpose_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, void* stream);
 int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, int32_t cols, void* stream);
-/* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn) */
+/* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn).  Keeps a per-(device, stream)
+ * scratch inside the library (grown with hipFree / hipMalloc when a larger shape shows up: not capturable into a graph on that call);
+ * long row ranges are folded in 8 splits that meet in float atomics, so the result is reproducible to the rounding of that sum's order. */
 int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
                          int32_t D, int32_t rows_per_batch, void* stream);
 /* Modulation gradients of the blocks (needed by the timestep-embedder LoRA pair, configs/flux/arcflux_2nfe_k16.py:46-47):
@@ -276,12 +278,17 @@ int afx_cast_f32_bf16(const float* x, void* y, int64_t n, void* stream);
 int afx_conv3x3_bf16(const void* x, const void* w, const void* bias, void* y, int32_t H, int32_t W, int32_t Cin,
                      int32_t Cout, const void* res, void* stream);
 #define AFX_GN_SLOTS 64
-/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: (2 + 2*AFX_GN_SLOTS)*groups + C doubles of scratch; act 1 = SiLU;
+/* Bytes of the stats_ws scratch afx_groupnorm_nhwc / afx_groupnorm_nhwc_from_stats need for (C, groups): (2 + 2*AFX_GN_SLOTS)*groups + C
+ * doubles.  (The requirement GREW in round 3 -- it was 2*groups doubles + 2*C floats -- when the per-slot partial sums moved into it:
+ * size the buffer with this call, not with a constant.)  Negative status on bad arguments. */
+int64_t afx_groupnorm_ws_bytes(int32_t C, int32_t groups);
+/* y = act(GroupNorm(x)) on the interior, 0 on the border; stats_ws: afx_groupnorm_ws_bytes(C, groups) of scratch; act 1 = SiLU;
  * C/8 must divide 256 (C = 64, 128, 256, 512, 1024, 2048) */
 int afx_groupnorm_nhwc(const void* x, void* y, double* stats_ws, int32_t H, int32_t W, int32_t C, int32_t groups,
                        const float* gamma, const float* beta, float eps, int32_t act, void* stream);
-/* The same convolution, and the GroupNorm sums of ITS OUTPUT accumulated by the GEMM epilogue: gn_stats = AFX_GN_SLOTS x groups x 2 doubles
- * (zeroed by the call; partial sums spread over the slots by tile), Cout <= 128 (the 256x128-tile kernel: the full-resolution stage, whose
+/* The same convolution, and the GroupNorm sums of ITS OUTPUT accumulated by the GEMM epilogue from the fp32 accumulators BEFORE the bf16
+ * rounding of the stored values (mean / variance differ from sums over the stored grid by that rounding: ~2^-9 relative, bounded in
+ * tests/test_vae.py): gn_stats = AFX_GN_SLOTS x groups x 2 doubles (zeroed by the call; partial sums spread over the slots by tile), Cout <= 128 (the 256x128-tile kernel: the full-resolution stage, whose
  * grids are the largest), Cout / groups = 4, 8 or a multiple of 8.  afx_groupnorm_nhwc_from_stats
  * then normalises y without a statistics pass of its own (diffusers' ResnetBlock2D order norm -> act -> conv: every GroupNorm input of the
  * decoder except the attention output is a convolution output).  afx_conv_stats_available(): 0 when the GEMM kernel override in force has no

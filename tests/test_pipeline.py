@@ -127,3 +127,27 @@ def test_qwen_pipeline_runs_vs_oracle():
         x = R.momentum_step_packed(x, m, lw, lg, sig[i], sig[i], sig[i + 1])
     err = ((out.cpu() - x).norm() / x.norm()).item()
     assert err < 2.5e-2, err
+
+
+@pytest.mark.gpu
+def test_lora_merge_gpu_vs_host_branch():
+    """the device branch of weights._merge_one rounds B * scale and A to bf16 (its GEMM's operand type), the host branch
+    forms B A from the fp32 tensors.  bf16 adapters: the two agree to the final rounding; fp32 adapters: the DELTA differs by the
+    operand rounding (<= 2^-8 relative in L2), the merged weight by at most one bf16 ulp per entry."""
+    from arcflow_amd import weights as W
+    g = torch.Generator().manual_seed(0)
+    w = (torch.randn(256, 384, generator=g) * 0.02).bfloat16()
+    a32, b32 = torch.randn(48, 384, generator=g) * 0.05, torch.randn(256, 48, generator=g) * 0.05
+    for a, b, tol in ((a32.bfloat16(), b32.bfloat16(), 1e-6), (a32, b32, 2.0 ** -8)):
+        host = W._merge_one(w, a, b, 1.0).float()
+        dev = W._merge_one(w.cuda(), a.cuda(), b.cuda(), 1.0).float().cpu()
+        exact = w.double() + b.double() @ a.double()
+        # both are one bf16 rounding away from their own fp32 sums: compare the sums' deltas through the exact value
+        d_host, d_dev = host.double() - w.double(), dev.double() - w.double()
+        d_ref = exact - w.double()
+        assert ((d_host - d_ref).norm() / d_ref.norm()).item() < 6e-3          # output rounding of W + delta to bf16
+        assert ((d_dev - d_ref).norm() / d_ref.norm()).item() < 6e-3 + tol
+        if tol < 1e-3:
+            assert (host != dev).float().mean().item() < 0.001                 # bf16 adapters: the same sums up to the accumulation order
+        else:                                                                    # fp32 adapters: entries move by at most one bf16 ulp of the merged weight
+            assert ((host - dev).abs() <= 2.0 ** -7 * host.abs().clamp(min=1e-3)).all()

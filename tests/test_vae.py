@@ -60,7 +60,8 @@ def test_conv3x3_epilogue_groupnorm_sums(H, W, ci, co, groups, with_res):
     assert ((got[:, 0] - ref[:, 0]).abs() <= 2.0 ** -8 * (n * ref[:, 1]).sqrt()).all(), (got[:, 0] - ref[:, 0]).abs().max().item()
     assert ((got[:, 1] - ref[:, 1]).abs() <= 2e-3 * ref[:, 1]).all(), ((got[:, 1] - ref[:, 1]).abs() / ref[:, 1]).max().item()
     gamma, beta = torch.randn(co, generator=g).cuda(), torch.randn(co, generator=g).cuda()
-    ws = torch.zeros((2 + 2 * 64) * groups + co, dtype=torch.float64, device='cuda')
+    ws = torch.zeros(lib.afx_groupnorm_ws_bytes(co, groups) // 8, dtype=torch.float64, device='cuda')
+    assert lib.afx_groupnorm_ws_bytes(co, groups) == 8 * ((2 + 2 * 64) * groups + co)
     ya, yb = _Grid(H, W, co, 'cuda'), _Grid(H, W, co, 'cuda')
     _lib.check(lib.afx_groupnorm_nhwc_from_stats(_p(gy.t), _p(ya.t), _p(slots), _p(ws), H, W, co, groups, _p(gamma), _p(beta), 1e-6, 1, _s()))
     _lib.check(lib.afx_groupnorm_nhwc(_p(gy.t), _p(yb.t), _p(ws), H, W, co, groups, _p(gamma), _p(beta), 1e-6, 1, _s()))
