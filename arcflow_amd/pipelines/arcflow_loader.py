@@ -86,4 +86,44 @@ class ArcFlowLoaderMixin:
         setattr(self, target_module_name, student)
         self.policy_config = json.loads(meta['policy_config']) if 'policy_config' in meta else {'type': 'ArcFlow'}
         self._adapters = getattr(self, '_adapters', []) + [adapter_name]
+        # kept for a runtime LoRA scale (`joint_attention_kwargs={'scale': s}` / `set_adapters(..., adapter_weights=s)`): see _apply_lora_scale
+        self._adapter_state = dict(target=target_module_name, base=base, lora=lora, merged_scale=1.0, weight=1.0)
         return adapter_name
+
+    # ------------------------------------------------------------------ runtime LoRA scale
+    def set_adapters(self, adapter_names, adapter_weights=None) -> None:
+        """diffusers' `pipe.set_adapters(names, adapter_weights=w)` for the ArcFlow adapter (inference_flux.py:9 mentions it): the adapter's
+        LoRA branch is weighted by w from now on.  Only the loaded ArcFlow adapter is known here (style LoRAs would be further
+        `lora` dicts folded the same way)."""
+        names = [adapter_names] if isinstance(adapter_names, str) else list(adapter_names)
+        known = getattr(self, '_adapters', [])
+        for n in names:
+            if n not in known:
+                raise ValueError(f'adapter {n!r} is not loaded (loaded: {known})')
+        if adapter_weights is None:
+            w = 1.0
+        elif isinstance(adapter_weights, (int, float)):
+            w = float(adapter_weights)
+        else:
+            w = float(list(adapter_weights)[0])
+        self._adapter_state['weight'] = w
+        self._apply_lora_scale(1.0)
+
+    def _apply_lora_scale(self, call_scale: float) -> None:
+        """The reference scales every LoRA layer by `joint_attention_kwargs['scale']` around the forward (`scale_lora_layers` /
+        `unscale_lora_layers`, lakonlab/models/architecture/arcflow/arcflux.py:147-154, :251-252): y = W x + s (alpha / r) B A x.  Here the
+        adapter is folded into the weights, so a different s means folding again: W + s B A from the kept base and LoRA tensors (one
+        fp32-accumulating GEMM per adapted linear on the device + a re-pack, about a second for FLUX-12B), cached until s changes --
+        a call with the same scale as the previous one costs nothing.  Deviation of the folded forward from the un-folded one:
+        tests/test_distill.py::test_unmerged_trunk_forward_matches_merged_engine."""
+        st = getattr(self, '_adapter_state', None)
+        if st is None:
+            if call_scale != 1.0:
+                raise RuntimeError('a LoRA scale was passed but no ArcFlow adapter is loaded')
+            return
+        s = float(call_scale) * st['weight']
+        if s == st['merged_scale']:
+            return
+        from ..weights import merge_lora
+        getattr(self, st['target']).load_state_dict(merge_lora(st['base'], st['lora'], scale=s))
+        st['merged_scale'] = s

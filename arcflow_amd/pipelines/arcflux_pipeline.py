@@ -283,8 +283,7 @@ class ArcFluxPipeline(_PipelineBase):
         self.check_inputs(prompt, height, width, prompt_embeds, pooled_prompt_embeds, max_sequence_length)
         if ip_adapter_image is not None or ip_adapter_image_embeds is not None:
             raise NotImplementedError('IP-Adapter inputs are outside the ArcFlow hot path')
-        if joint_attention_kwargs and joint_attention_kwargs.get('scale', 1.0) != 1.0:
-            raise NotImplementedError('LoRA is merged at load time; a runtime lora scale is not supported')
+        self._apply_lora_scale(float((joint_attention_kwargs or {}).get('scale', 1.0)))      # arcflux.py:147-154: scale_lora_layers around the forward
         if self.transformer is None or self.transformer.teacher_head:
             raise RuntimeError('load_arcflow_adapter() must be called before sampling (the plain FLUX head '
                                'predicts a single velocity, not an ArcFlow policy)')

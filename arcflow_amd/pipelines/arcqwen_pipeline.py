@@ -123,8 +123,7 @@ class ArcQwenImagePipeline(_PipelineBase):
             if prompt is None:
                 raise ValueError('Provide either `prompt` or `prompt_embeds`.')
             prompt_embeds, prompt_embeds_mask = self.encode_prompt(prompt, max_sequence_length=max_sequence_length)
-        if attention_kwargs and attention_kwargs.get('scale', 1.0) != 1.0:
-            raise NotImplementedError('LoRA is merged at load time; a runtime lora scale is not supported')
+        self._apply_lora_scale(float((attention_kwargs or {}).get('scale', 1.0)))      # arcflux.py:147-154: scale_lora_layers around the forward
         if self.transformer is None or self.transformer.teacher_head:
             raise RuntimeError('load_arcflow_adapter() must be called before sampling')
         self._interrupt = False

@@ -258,6 +258,36 @@ class ArcFlowDistiller:
         neg = self.teacher(xb, sigma, cond['negative_prompt_embeds'], cond.get('negative_pooled'), g, cond['hp'], cond['wp']).float()
         return ops.cfg_combine(pos, neg, self.cfg.teacher_guidance_scale)
 
+    def student_forward_unmerged(self, x_src, sigma_src, cond, p_drop: float = 0.0, seed: int = 0):
+        """The student's forward as peft evaluates it -- y = W x + B (A dropout(x)) per adapted linear, NOT folded into W -- on the
+        LoRA trunk: the engine runs conditioning + embedders (stage 1, with the timestep embedding of the LoRA-adapted embedder
+        handed in) and norm_out + head (stage 2); the blocks in between go through the trunk's own block forward, which also keeps
+        every block's input (checkpoint) and the pre-gate branch outputs the modulation gradients need.  Returns
+        (ArcFlowModelOutput, mod_all [B, n_mod])."""
+        B, N, _ = x_src.shape
+        T = cond['prompt_embeds'].shape[1]
+        dev = self.device
+        nb = self.student.num_double + self.student.num_single
+        if self._ckpt is None or self._ckpt.shape[1] != B * (T + N):
+            self._ckpt = torch.empty(nb, B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
+        self.trunk.p_drop = p_drop
+        self.trunk.seed = seed
+        self.student.set_checkpoint_buffer(None)
+        temb_t = self.trunk.temb_forward(sigma_src)
+        self.student.set_temb_override(temb_t)
+        args = (x_src.to(torch.bfloat16), sigma_src, cond['prompt_embeds'], cond.get('pooled'), self._guid(B), cond['hp'], cond['wp'])
+        self.student(*args, stage=1)
+        xt = torch.empty(B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
+        mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
+        self.student.export('x_tokens', xt, B, N, T)
+        self.student.export('mod_all', mod_all, B, N, T)
+        for b in range(B):
+            self.trunk.forward_sample(xt, self._ckpt, b, mod_all, T, N, cond['hp'], cond['wp'])
+        self.student.import_tokens(xt, B, N, T)
+        out = self.student(*args, stage=2)
+        self.student.set_temb_override(None)
+        return out, mod_all
+
     # ------------------------------------------------------------------ one student segment
     def _segment(self, step_id: int, x_src, raw_src, cond, teacher_ratio: float, segment: float, rng, draws=None,
                  batch_total: Optional[int] = None, final: bool = False):
@@ -280,28 +310,7 @@ class ArcFlowDistiller:
                 self._ckpt = torch.empty(nb, B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
         mod_all = None
         if self.trunk is not None:
-            # With adapters the student's blocks run through the trunk's own block forward: it adds the LoRA-dropout correction
-            # B A (x . delta) per adapter and keeps the pre-gate branch outputs the modulation gradients need.  The engine
-            # runs conditioning + embedders (stage 1, with the timestep embedding of the LoRA-adapted embedder handed in) and
-            # norm_out + head (stage 2).
-            self.trunk.p_drop = c.lora_dropout
-            self.trunk.seed = self.dropout_seed(step_id)
-            self.student.set_checkpoint_buffer(None)
-            temb_t = self.trunk.temb_forward(sigma_src)
-            self.student.set_temb_override(temb_t)
-            args = (x_src.to(torch.bfloat16), sigma_src, cond['prompt_embeds'], cond.get('pooled'), self._guid(B), cond['hp'], cond['wp'])
-            self.student(*args, stage=1)
-            xt = torch.empty(B * (T + N), self.D, dtype=torch.bfloat16, device=dev)
-            mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
-            temb_sum = torch.empty(B, self.D, dtype=torch.float32, device=dev)
-            self.student.export('x_tokens', xt, B, N, T)
-            self.student.export('mod_all', mod_all, B, N, T)
-            self.student.export('temb', temb_sum, B, N, T)
-            for b in range(B):
-                self.trunk.forward_sample(xt, self._ckpt, b, mod_all, T, N, cond['hp'], cond['wp'])
-            self.student.import_tokens(xt, B, N, T)
-            out = self.student(*args, stage=2)
-            self.student.set_temb_override(None)
+            out, mod_all = self.student_forward_unmerged(x_src, sigma_src, cond, c.lora_dropout, self.dropout_seed(step_id))
         else:
             out = self._student(x_src, sigma_src, cond)
         means, logw, logg = out.means, out.logweights, out.loggammas
@@ -311,6 +320,9 @@ class ArcFlowDistiller:
         self.student.export('head_in', xn, B, N, T)
         self.student.export('x_final', xf, B, N, T)
         self.student.export('silu_temb', semb, B, N, T)
+        if self.trunk is not None:
+            temb_sum = torch.empty(B, self.D, dtype=torch.float32, device=dev)       # pre-SiLU conditioning sum: d silu for the embedder pair
+            self.student.export('temb', temb_sum, B, N, T)
         if self.trunk is not None and mod_all is None:
             mod_all = torch.empty(B, self.student.n_mod, dtype=torch.float32, device=dev)
             self.student.export('mod_all', mod_all, B, N, T)

@@ -819,3 +819,42 @@ def test_rccl_branch_of_the_exchange_executes_on_one_rank(tmp_path):
     r = subprocess.run([sys.executable, str(script)], cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'RCCL_ONE_RANK_OK' in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.gpu
+def test_unmerged_trunk_forward_matches_merged_engine():
+    """the reference keeps LoRA un-fused at inference (base GEMM + two rank-r GEMMs per adapted linear); the
+    inference engine folds W + B A once.  The training trunk evaluates the un-fused form (y = [x | x A^T] [W | B]^T), so the two can be
+    compared on one device with the live adapters: deviation of the folded forward from the un-fused one, and of both from the fp32
+    oracle with the LoRA branch evaluated separately (peft's op order)."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    from oracle import dit_ref as D
+    cfg, w = _setup()
+    B, hp, wp, T, r = 2, 8, 8, 64, 64
+    g = torch.Generator().manual_seed(77)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16()
+    x = torch.randn(B, hp * wp, 64, generator=g)
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r)
+    d = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+    tr = d.trunk
+    for sp in tr.specs:                                   # adapters of the size a trained checkpoint has, not the B = 0 initialisation
+        tr.B(sp).copy_((torch.randn(sp.out_f, r, generator=g) * 0.05).cuda())
+    tr.refresh()
+    cond = dict(prompt_embeds=pe.cuda(), pooled=pooled.cuda(), hp=hp, wp=wp)
+    sigma = torch.tensor([0.7619, 0.7619], device='cuda')
+    un, _ = d.student_forward_unmerged(x.cuda(), sigma, cond, 0.0, 0)
+    un = [t.float().cpu() for t in (un.means, un.logweights, un.loggammas)]
+    tr.bind_merged()
+    mg = d.student.forward(x.cuda().bfloat16(), sigma, cond['prompt_embeds'], cond['pooled'], torch.full((B,), 3.5, device='cuda'), hp, wp)
+    mg = [t.float().cpu() for t in (mg.means, mg.logweights, mg.loggammas)]
+    # fp32 oracle, LoRA as a separate branch (dit_ref.lin's '.lora' entry = peft's forward)
+    wl = {k: v.float() for k, v in w.items()}
+    for sp in tr.specs:
+        wl[sp.name + '.lora'] = (tr.A(sp).cpu().bfloat16().float(), tr.B(sp).cpu().bfloat16().float(), 1.0)
+    ref = D.flux_forward(wl, cfg, x.bfloat16().float(), pe.float(), pooled.float(), sigma.cpu(), torch.full((B,), 3.5), hp, wp)
+    rel = lambda a, b: ((a - b).norm() / b.norm()).item()          # noqa: E731
+    dev_means, dev_logg = rel(mg[0], un[0]), rel(mg[2], un[2])
+    assert dev_means < 1.5e-2 and dev_logg < 1.5e-2, (dev_means, dev_logg)           # folded vs un-fused: bf16 rounding of W + B A
+    for got in (un, mg):
+        assert rel(got[0], ref[0]) < 2.5e-2 and rel(got[2], ref[2]) < 2.5e-2 and (got[1] - ref[1]).abs().max().item() < 0.1

@@ -94,6 +94,32 @@ def test_flux_pipeline_two_nfe_vs_oracle(tmp_path):
     err = ((out.cpu() - x).norm() / x.norm()).item()
     assert err < 2.5e-2, err
 
+    # runtime LoRA scale (arcflux.py:147-154 scale_lora_layers): y = W x + s B A x for this call, scale 1 again on the next one
+    def ref_latents(scale):
+        wr = dict(wm)
+        wr[name + '.weight'] = (w[name + '.weight'].float() + scale * (lora[name + '.lora_B.weight'].float() @ lora[name + '.lora_A.weight'].float())).bfloat16()
+        xr = R.pack_latents(noise)
+        for i in range(2):
+            m, lw, lg = D.flux_forward(wr, cfg, xr.bfloat16().float(), pe.float(), pp.float(), torch.tensor([sig[i]]), torch.tensor([3.5]), 8, 8)
+            xr = R.momentum_step_packed(xr, m, lw, lg, sig[i], sig[i], sig[i + 1])
+        return xr
+
+    def run(**kw):
+        return pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, num_inference_steps=2, timestep_ratio=1.0,
+                    generator=torch.Generator(device='cuda').manual_seed(42), output_type='latent', **kw).images.cpu()
+    half = run(joint_attention_kwargs={'scale': 0.5})
+    x_half = ref_latents(0.5)
+    assert ((half - x_half).norm() / x_half.norm()).item() < 2.5e-2
+    assert ((half - out.cpu()).norm() / x.norm()).item() > 1e-3                   # the scale really changed the network
+    assert torch.equal(run(), out.cpu())                                           # un-scaled again (the fold is redone and cached)
+    pipe.set_adapters(name_ret, adapter_weights=0.0)                               # weight 0: the base trunk + the adapter's heads / norm_out
+    x_zero = ref_latents(0.0)
+    assert ((run() - x_zero).norm() / x_zero.norm()).item() < 2.5e-2
+    pipe.set_adapters([name_ret])
+    assert torch.equal(run(), out.cpu())
+    with pytest.raises(ValueError, match='not loaded'):
+        pipe.set_adapters('style_lora')
+
     # nfe=4 / ratio 0.5 default path also runs and the callback sees every step
     seen = []
     pipe(prompt_embeds=pe, pooled_prompt_embeds=pp, width=128, height=128, output_type='latent',
@@ -149,5 +175,5 @@ def test_lora_merge_gpu_vs_host_branch():
         assert ((d_dev - d_ref).norm() / d_ref.norm()).item() < 6e-3 + tol
         if tol < 1e-3:
             assert (host != dev).float().mean().item() < 0.001                 # bf16 adapters: the same sums up to the accumulation order
-        else:                                                                    # fp32 adapters: entries move by at most one bf16 ulp of the merged weight
-            assert ((host - dev).abs() <= 2.0 ** -7 * host.abs().clamp(min=1e-3)).all()
+        else:       # fp32 adapters: entries move by the operand rounding (2^-9 sum |b| |a| ~ 1.5e-4 here) plus at most one bf16 ulp of the result
+            assert (host - dev).abs().max().item() < 6e-4 and (host - dev).abs().mean().item() < 5e-5
