@@ -1209,7 +1209,11 @@ AFX_DEV uint64_t v3_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit valu
 constexpr int V3_THREADS = 256;
 constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (32 * NJ) * 128; }
 
-template <int MI, int NJ, bool CONV = false>
+// PERSIST (round 4, DESIGN 4.1 "persistent tile loop"): a work-group walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... of the launch (grid =
+// the CU count, a multiple of 8: the walk stays on the work-group's XCD chunk) and issues the NEXT tile's first four DMA batches
+// (A(0) W(0) W(1) A(1)) between its last K-tile and its epilogue, so their latency -- and the launch of a fresh work-group -- hide
+// behind the epilogue's stores.  VMEM operations retire in order: the epilogue's own residual loads then queue behind those batches.
+template <int MI, int NJ, bool CONV = false, int PERSIST = 0>      // PERSIST 1: next tile's DMA in front of the epilogue, 2: behind it
 __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_kernel_v3(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ;
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
@@ -1222,29 +1226,65 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;
-  int wg = xcd_remap(blockIdx.x, gridDim.x);
-  int pi = 0;
+  // ---- per-tile state (set by setup(); PERSIST re-runs it for every tile of the walk) --------------------------------------------
+  int pi_cur = 0;                         // (an index, not a pointer: a loop-carried pointer into the by-value kernel argument makes hipcc copy the whole GemmBatch to scratch)
+  int m0 = 0, n0 = 0, nk = 1;
+  uint32_t aoff[MI], woff[NJ];
+  const char* abase = nullptr;
+  const char* wbase = nullptr;
+  float inv_ct = 0.f;
+  int up = 0;
+  auto setup = [&](int vt, int tid_) {
+    int wg = xcd_remap(vt, PERSIST != 0 ? batch.total_tiles : (int)gridDim.x);
+    int pi = 0;
 #pragma unroll
-  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
-    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
-  const GemmProblem& P = batch.p[pi];
-  wg -= P.tile_start;
-  const int GM_ = batch.group_m;
-  const int per_group = GM_ * P.tiles_n;
-  const int grp = wg / per_group;
-  const int first_m = grp * GM_;
-  const int gsz = min(P.tiles_m - first_m, GM_);
-  const int in_grp = wg - grp * per_group;
-  const int tm = first_m + in_grp % gsz;
-  const int tn = in_grp / gsz;
-  const int m0 = tm * TM, n0 = tn * TN;
-  const int nk = P.K / BK;
+    for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+      if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
+    const GemmProblem& Q = batch.p[pi];
+    pi_cur = pi;
+    wg -= Q.tile_start;
+    const int GM_ = batch.group_m;
+    const int per_group = GM_ * Q.tiles_n;
+    const int grp = wg / per_group;
+    const int first_m = grp * GM_;
+    const int gsz = min(Q.tiles_m - first_m, GM_);
+    const int in_grp = wg - grp * per_group;
+    const int tm = first_m + in_grp % gsz;
+    const int tn = in_grp / gsz;
+    m0 = tm * TM; n0 = tn * TN;
+    nk = Q.K / BK;
+    inv_ct = CONV ? 1.0f / (float)Q.conv_cin_tiles : 0.f;
+    up = CONV ? Q.up_phase : 0;                           // 0: 3x3 taps from (-1, -1); 1 + 2 py + px: 2x2 taps from (py - 1, px - 1)
+    // per-lane byte offsets of this lane's chunks of an A tile (MI pieces of 32 rows) / a W tile (NJ pieces), k = 0
+    const int prow = tid_ >> 3;                                       // + 32 i
+    const int pc = ((tid_ & 7) ^ ((prow >> 1) & 7)) * 16;             // logical 16-byte chunk stored at physical chunk tid & 7
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int ar = m0 + prow + 32 * i;
+      ar = ar < Q.M ? ar : Q.M - 1;
+      aoff[i] = (uint32_t)((int64_t)ar * Q.lda * 2 + pc);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      int br = n0 + prow + 32 * i;
+      if (Q.w_perm16) br = (br & ~15) + 4 * ((br & 15) >> 3) + (br & 3) + 8 * ((br >> 2) & 1);   // key_of_pos: column p <- key of position p
+      br = br < Q.N ? br : Q.N - 1;
+      woff[i] = (uint32_t)((int64_t)br * Q.ldw * 2 + pc);
+    }
+    abase = reinterpret_cast<const char*>(Q.A);
+    // (Measured and dropped, r02u: W stored TILE-MAJOR -- the TN x 64 block of a (column tile, K-tile) as one contiguous run, so a
+    // tile's weight stream is sequential in HBM instead of 128-byte pieces 6 KB apart.  With weights streaming from HBM the loop loses
+    // its DMA waits, 2561 -> 2388 cycles per K-tile at N = 12288, and the launch takes the same 287 us: the clock drops by what the
+    // stall cycles had saved in power.)
+    wbase = reinterpret_cast<const char*>(Q.W);
+  };
+  int vt = blockIdx.x;
+  setup(vt, tid);
   // CONV (the VAE decoders' 3x3 convolutions, afx_vae.hip): implicit GEMM on a zero-bordered NHWC grid -- K-tile t = (tap, 64-channel chunk)
   // reads the SAME pixel rows shifted by dy * row pitch + dx, so the A stream's K offset becomes a (uniform) row shift + channel offset.
-  const float inv_ct = CONV ? 1.0f / (float)P.conv_cin_tiles : 0.f;
-  const int up = CONV ? P.up_phase : 0;                           // 0: 3x3 taps from (-1, -1); 1 + 2 py + px: 2x2 taps from (py - 1, px - 1)
   auto ka = [&](int t) -> int64_t {
     if constexpr (!CONV) return (int64_t)t * (BK * 2);
+    const GemmProblem& P = batch.p[pi_cur];
     const int ct = P.conv_cin_tiles;
     const int tap = (int)(((float)t + 0.5f) * inv_ct);            // t / ct for t < 9 ct <= 72
     const int cc = t - tap * ct;
@@ -1257,30 +1297,6 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     }
     return ((int64_t)(dy * P.conv_wp + dx) * P.lda + cc * BK) * 2;
   };
-
-  // per-lane byte offsets of this lane's chunks of an A tile (MI pieces of 32 rows) / a W tile (NJ pieces), k = 0
-  const int prow = tid >> 3;                                       // + 32 i
-  const int pc = ((tid & 7) ^ ((prow >> 1) & 7)) * 16;             // logical 16-byte chunk stored at physical chunk tid & 7
-  uint32_t aoff[MI], woff[NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i) {
-    int ar = m0 + prow + 32 * i;
-    ar = ar < P.M ? ar : P.M - 1;
-    aoff[i] = (uint32_t)((int64_t)ar * P.lda * 2 + pc);
-  }
-#pragma unroll
-  for (int i = 0; i < NJ; ++i) {
-    int br = n0 + prow + 32 * i;
-    if (P.w_perm16) br = (br & ~15) + 4 * ((br & 15) >> 3) + (br & 3) + 8 * ((br >> 2) & 1);   // key_of_pos: column p <- key of position p
-    br = br < P.N ? br : P.N - 1;
-    woff[i] = (uint32_t)((int64_t)br * P.ldw * 2 + pc);
-  }
-  const char* abase = reinterpret_cast<const char*>(P.A);
-  // (Measured and dropped, r02u: W stored TILE-MAJOR -- the TN x 64 block of a (column tile, K-tile) as one contiguous run, so a
-  // tile's weight stream is sequential in HBM instead of 128-byte pieces 6 KB apart.  With weights streaming from HBM the loop loses
-  // its DMA waits, 2561 -> 2388 cycles per K-tile at N = 12288, and the launch takes the same 287 us: the clock drops by what the
-  // stall cycles had saved in power.)
-  const char* wbase = reinterpret_cast<const char*>(P.W);
   auto stage_a = [&](int t) {
     t = t < nk ? t : nk - 1;
     const char* src = abase + ka(t);
@@ -1299,11 +1315,6 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   };
 
   f32x4_t acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
 
@@ -1315,6 +1326,13 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #endif
   // prologue: A(0) W(0) | W(1) A(1) stay in flight
   stage_a(0); stage_w(0); stage_w(1); stage_a(1);
+  for (;;) {        // one pass per tile (PERSIST: the walk; otherwise left by the break behind the epilogue)
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  // (PERSIST, second tile on: in-order retirement -- at most MI + NJ operations outstanding means the four batches issued in front of
+  // the previous epilogue have landed, whatever that epilogue issued behind them)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
   __builtin_amdgcn_s_barrier();
   bf16x8_t a0[MI], b0[NJ], a1[MI], b1[NJ];
@@ -1416,21 +1434,41 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
+    const GemmProblem& P = batch.p[pi_cur];  // this tile's problem and origin (setup() below moves pi_cur / m0 / n0 on to the next tile)
+    const int m0e = m0, n0e = n0;
+    bool has_next = false;
+    auto next_tile = [&]() {
+      int vn = vt + (int)gridDim.x;
+      asm volatile("" : "+v"(vn));           // opaque: the next tile's address arithmetic must not be hoisted above the main loop
+      vn = __builtin_amdgcn_readfirstlane(vn);
+      has_next = vn < batch.total_tiles;
+      if (has_next) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();        // every wave has finished its fragment reads: the LDS slots are free
+        vt = vn;
+        setup(vn, tid2);
+        stage_a(0); stage_w(0); stage_w(1); stage_a(1);
+      }
+    };
+    if constexpr (PERSIST == 1) next_tile();
     AFX_TRC(20)
 #ifndef V3_EPI_SWAP
 #define V3_EPI_SWAP 1
 #endif
     if constexpr (CONV) {      // bias (+ residual) + re-zeroing of the border pixels: the output grid is the next layer's padded input
-      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
-      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
+      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
     } else
-    epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+    epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
 #ifdef AFX_GEMM_TRACE
     AFX_TRC(21)
     tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
     if ((blockIdx.x == 0 || blockIdx.x == 300) && lane2 == 0)
       for (int i = 0; i < 24; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave2][i] = tr[i];
 #endif
+    if constexpr (PERSIST == 2) next_tile();
+    if (!has_next) break;
+  }
   }
 }
 
@@ -1495,21 +1533,47 @@ static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
   return total;
 }
 
-template <int MI, int NJ, bool CONV = false>
-static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
+template <int MI, int NJ, bool CONV = false, int PERSIST = 0>
+static hipError_t launch_v3_impl(GemmBatch& batch, int total, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ, CONV>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ, CONV, PERSIST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        v3_lds_bytes(MI, NJ));
     if (r != hipSuccess) return r;
     attr = true;
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
-    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
+    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV, PERSIST>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
                           launch_timer().stop, 0, batch);
   else
-    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
+    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV, PERSIST>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
   return hipGetLastError();
+}
+
+// AFX_GEMM_PERSIST=1 (or afx_gemm_set_persist(1)): launches with more tiles than resident work-groups run the persistent tile walk
+// (grid = CUs x resident work-groups per CU); off by default -- see DESIGN 4.1 for the same-box A/B.
+int& gemm_persist() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("AFX_GEMM_PERSIST");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+template <int MI, int NJ, bool CONV = false>
+static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const int slots = cus * (4 * MI * NJ <= 64 ? 2 : 1);
+  if constexpr (!CONV) {
+    if (gemm_persist() == 1 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 1>(batch, slots, stream);
+    if (gemm_persist() == 2 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
+  }
+  return launch_v3_impl<MI, NJ, CONV, 0>(batch, total, stream);
 }
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
