@@ -80,6 +80,8 @@ struct afx_ctx {
   int prep_steps = 0, prep_B = 0, prep_use = -1;
   // optional per-launch-class timing (HIP events on the forward's stream)
   bool prof_on = false;
+  int prof_stride = 1;          // time one launch in prof_stride (afx_profile_enable(ctx, N)): an event pair on a dispatch costs ~4 us
+  uint64_t prof_count = 0;
   struct ProfRec { hipEvent_t a, b; int klass; double flops; };
   std::vector<ProfRec> prof_pool;
   size_t prof_used = 0;
@@ -186,6 +188,7 @@ struct ProfScope {
   afx_ctx* c; hipStream_t st; afx_ctx::ProfRec* r = nullptr;
   ProfScope(afx_ctx* c_, hipStream_t st_, int klass, double flops) : c(c_), st(st_) {
     if (!c->prof_on) return;
+    if ((c->prof_count++ % (uint64_t)c->prof_stride) != 0) return;      // sampled: the forward has an odd number of launches, so the sample walks every launch position
     if (c->prof_used == c->prof_pool.size()) {
       afx_ctx::ProfRec n{};
       if (hipEventCreate(&n.a) != hipSuccess || hipEventCreate(&n.b) != hipSuccess) return;
@@ -791,6 +794,8 @@ int afx_set_checkpoint_buffer(afx_ctx* ctx, void* dptr) {
 int afx_profile_enable(afx_ctx* ctx, int32_t on) {
   if (!ctx) return fail(AFX_E_INVALID, "null ctx");
   ctx->prof_on = on != 0;
+  ctx->prof_stride = on > 1 ? on : 1;
+  ctx->prof_count = 0;
   ctx->prof_used = 0;
   return AFX_OK;
 }

@@ -139,7 +139,8 @@ class MMDiTEngine:
         return (self.num_double * 12 + self.num_single * 3 + 2) * self.dim
 
     # ------------------------------------------------------------------ instrumentation
-    def profile(self, on: bool) -> None:
+    def profile(self, on) -> None:
+        """False / True: off / an event pair on every GEMM and attention launch; an int N > 1: on one launch in N (sampled)."""
         _lib.check(self.lib.afx_profile_enable(self._ctx, int(on)))
 
     def profile_read(self, klass: int):

@@ -232,6 +232,7 @@ def parse_args(argv=None):
     ap.add_argument('--no-extras', action='store_true', help='N = 1 FLUX run: skip the extra objects (Qwen inference, the two distillation iterations, prompt -> image)')
     ap.add_argument('--e2e', action='store_true', help='only the prompt -> image object of --model (encoders + 2 NFE + VAE)')
     ap.add_argument('--no-profile', action='store_true', help='do not record per-launch HIP events')
+    ap.add_argument('--profile-stride', type=int, default=8, help='HIP event pair on one GEMM / attention launch in N inside the timed region (1: every launch, which costs 1.8 %% of the step)')
     ap.add_argument('--no-prepare-steps', action='store_true', help='recompute the AdaLN conditioning inside every transformer call (A/B)')
     ap.add_argument('--fp8', action='store_true', help='OPTIONAL reduced-precision mode: block linears on the fp8 MFMA (not the headline: the line says dtype fp8)')
     ap.add_argument('--master-port', type=int, default=None, help='rendezvous port of the self-launch (default: derived from the pid)')
@@ -468,7 +469,8 @@ def infer_main(args, model, rank, world, dev, dist):
     for _ in range(args.warmup):
         one_image()
     prof = not args.no_profile and len(engines) == 1      # per-launch durations overlap with several images in flight
-    eng.profile(prof)
+    stride = max(1, getattr(args, 'profile_stride', 8))
+    eng.profile(stride if prof else False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -527,7 +529,8 @@ def infer_main(args, model, rank, world, dev, dist):
                 'unit': 'TFLOP/s', 'frac': ach / (MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1)), 'traffic': None if args.fp8 else _traffic(model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,
-                'share_of_step_time': gemm_ms * 1e-3 / dt,
+                'sampling': f'HIP event pair on 1 launch in {stride} of the timed region (every launch position is visited: 211 launches per forward)',
+                'share_of_step_time': gemm_ms * stride * 1e-3 / dt,
                 # what the power cap leaves of `peak`: a loop of nothing but 16x16x32 bf16 MFMAs on random operands runs at
                 # 1.93-1.98 GHz / 1927-1984 TFLOP/s on this part (tools/gemm_trace.hip mfma_burn_rand, profiles/r02s_gemm_trace.txt)
                 'power_capped_mfma_peak': POWER_CAPPED_MFMA_TF,
@@ -538,7 +541,7 @@ def infer_main(args, model, rank, world, dev, dist):
                 line['roofline_attention'] = {
                     'bound': 'mfma', 'kernel': 'afx::a3::attention_v3_kernel', 'achieved': a2, 'peak': MFMA_BF16_PEAK_TF,
                     'unit': 'TFLOP/s', 'frac': a2 / MFMA_BF16_PEAK_TF, 'launches': att_n,
-                    'avg_launch_us': att_ms * 1e3 / att_n, 'share_of_step_time': att_ms * 1e-3 / dt}
+                    'avg_launch_us': att_ms * 1e3 / att_n, 'share_of_step_time': att_ms * stride * 1e-3 / dt}
         line['roofline_step'] = step_gbs
         return line
     return None

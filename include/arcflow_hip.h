@@ -133,7 +133,9 @@ int afx_set_checkpoint_buffer(afx_ctx* ctx, void* dptr);
 /* Optional instrumentation for bench.py's roofline line: when enabled, afx_mmdit_forward records a HIP
  * event pair on its stream around every GEMM launch (klass 0) and attention launch (klass 1).
  * afx_profile_read waits for the recorded events and returns the summed duration, the number of
- * launches and their algorithmic FLOPs since the last afx_profile_enable(ctx, 1). */
+ * launches and their algorithmic FLOPs since the last afx_profile_enable(ctx, 1).  on = N > 1 times ONE launch in N (a counter over both
+ * classes; a forward has an odd number of launches, so over several forwards the sample covers every launch position): an event pair on a
+ * dispatch costs ~4 us, 1.8 % of the FLUX forward when every launch carries one (round 4, profiles/r04a_no_profile_ab.txt). */
 int afx_profile_enable(afx_ctx* ctx, int32_t on);
 int afx_profile_read(afx_ctx* ctx, int32_t klass, double* total_ms, int64_t* launches, double* flops);
 
