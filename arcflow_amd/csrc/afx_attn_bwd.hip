@@ -166,9 +166,10 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
       float dsv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = t * TB + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float p = key < S ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - Lq) : 0.f;
-        dsv[r] = p * (dp[r] - Dq) * SCALE;
+        // no key mask: rows past S of the K / V tiles are clamped copies of the last key (finite scores, p <= 1) and the matching columns
+        // of the zero-padded K^T tile are zeros, so their dS never reaches dQ.  1 / sqrt(d) is applied once, in the epilogue.
+        const float p = __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - Lq);
+        dsv[r] = p * (dp[r] - Dq);
       }
 #pragma unroll
       for (int ksub = 0; ksub < 2; ++ksub) {
@@ -193,14 +194,20 @@ __global__ __launch_bounds__(DQ_THREADS, 2) void attn_bwd_dq_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t w;
-        w[0] = pack_bf16x2(acc[d][4 * g + 0], acc[d][4 * g + 1]);
-        w[1] = pack_bf16x2(acc[d][4 * g + 2], acc[d][4 * g + 3]);
+        w[0] = pack_bf16x2(acc[d][4 * g + 0] * SCALE, acc[d][4 * g + 1] * SCALE);
+        w[1] = pack_bf16x2(acc[d][4 * g + 2] * SCALE, acc[d][4 * g + 3] * SCALE);
         *reinterpret_cast<u32x2_t*>(op + d * 32 + g * 8 + hi * 4) = w;
       }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
+#ifdef AFX_BWD_TRACE        // tools/attn_bwd_trace.py: cycle stamps of one query tile (t = 36) of two work-groups, per wave
+__device__ unsigned g_bwd_trace[2 * 4 * 12];
+#define BWD_TR(i) if (t == 36) tr[i] = (unsigned)__builtin_readcyclecounter();
+#else
+#define BWD_TR(i)
+#endif
 constexpr int DKV_WAVES = 4;
 constexpr int DKV_THREADS = DKV_WAVES * 64;
 constexpr int DKV_STAT = 2 * TB * 4;                                       // L | delta of the 64 queries
@@ -254,12 +261,58 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     else if (wave_u == 1)
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(dbase + t * TB + lane), (lds_void_t*)(st + TB * 4), 4, 0, 0);
   };
+  // Full tiles (all but a ragged last one) are staged PIECE BY PIECE inside the MFMA regions below (one LDS-DMA per four MFMAs): issued as a
+  // burst at the top of a tile the 17 pieces cost ~1600 of a tile's 5700 cycles (tools/attn_bwd_trace.py) -- a 64-lane x 16-byte request
+  // occupies the CU's address unit for ~90 cycles and a lone wave has nothing to overlap it with.  Per-lane 32-bit offsets are computed
+  // once; the tile base is wave-uniform.
+  uint32_t o_sw[4], o_t[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int seed = i * DKV_THREADS + tid;
+    const int r = seed >> 4, cp = seed & 15;
+    o_sw[i] = (uint32_t)(((cp ^ (r & 15)) << 3) * 2);                      // swizzled chunk inside the row (bytes)
+    const int d = seed >> 3, vp = seed & 7;
+    o_t[i] = (uint32_t)(((int64_t)d * S_pad + ((vp ^ ((d >> 1) & 7)) << 3)) * 2);
+  }
+  // which: 0 Q rows, 1 dO rows, 2 Q^T cols, 3 dO^T cols (+ the L / delta rows).  UNCONDITIONAL (a branch would fence the pieces off from
+  // the region's MFMAs): past the last tile the caller passes the last tile again, into the buffer nobody reads any more.  Rows past S of a
+  // ragged last tile are clamped to S - 1 per piece (the transposed tensors are zero-padded to S_pad).
+  auto stage_piece = [&](int which, int t, int buf) {
+    char* base = smem + buf * DKV_STAGE;
+    const int rmax = S - 1 - t * TB;                                        // (uniform) last existing row of this tile
+    const char* src = which == 0 ? (const char*)qbase + (int64_t)t * TB * ldq * 2
+                    : which == 1 ? (const char*)dobase + (int64_t)t * TB * lddo * 2
+                    : which == 2 ? (const char*)qtbase + (int64_t)t * TB * 2 : (const char*)dotbase + (int64_t)t * TB * 2;
+    char* dst = base + (which == 0 ? 0 : which == 1 ? ROWMAJ_BYTES : which == 2 ? 2 * ROWMAJ_BYTES : 2 * ROWMAJ_BYTES + TRANS_BYTES);
+    const int ld2 = (int)((which == 0 ? ldq : lddo) * 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t off;
+      if (which < 2) off = (uint32_t)(min((i * DKV_THREADS + tid) >> 4, rmax) * ld2) + o_sw[i];
+      else off = o_t[i];
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + off), (lds_void_t*)(dst + (i * DKV_THREADS + wave_u * 64) * 16), 16, 0, 0);
+    }
+    if (which == 3) {
+      char* st = base + 2 * ROWMAJ_BYTES + 2 * TRANS_BYTES;
+      if (wave_u == 0)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(lbase + t * TB + lane), (lds_void_t*)st, 4, 0, 0);
+      else if (wave_u == 1)
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)(dbase + t * TB + lane), (lds_void_t*)(st + TB * 4), 4, 0, 0);
+    }
+  };
   f32x16_t dva[4], dka[4];
 #pragma unroll
   for (int d = 0; d < 4; ++d)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dva[d][r] = dka[d][r] = 0.f;
 
+#ifdef AFX_BWD_TRACE
+  unsigned tr[12];
+  for (int i = 0; i < 12; ++i) tr[i] = 0;
+  tr[7] = (unsigned)__builtin_readcyclecounter();
+  tr[10] = (unsigned)__builtin_amdgcn_s_memrealtime();
+  tr[11] = (unsigned)ntiles;
+#endif
   stage(0, 0);
   AFX_SYNC_DMA();
 #pragma unroll
@@ -319,9 +372,10 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int r = 4 * g + e;
-        const float p = k_ok ? __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - l4[g][e]) : 0.f;
+        // (no key mask: a lane past S holds a clamped copy of the last key and its dK / dV column is never stored; 1 / sqrt(d) once, in the epilogue)
+        const float p = __builtin_amdgcn_exp2f(sa[r] * C_LOG2 - l4[g][e]);
         pv[r] = p;
-        dsv[r] = p * (dp[r] - d4[g][e]) * SCALE;
+        dsv[r] = p * (dp[r] - d4[g][e]);
       }
     }
 #pragma unroll
@@ -347,12 +401,15 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
   };
   // (MFMA, LDS read, VALU) triples: one matrix instruction, one fragment read for the next group and a slice of the other half's
   // arithmetic per 32-cycle MFMA slot
-#define AFX_BWD_INTERLEAVE(NV)                                   \
+#define AFX_BWD_INTERLEAVE(NR, NV, NDMA)                         \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {            \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           \
-    __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);          \
+    if (NR) __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);  \
+    if ((i_ % (NDMA)) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* one LDS-DMA piece per NDMA MFMAs */ \
+    if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  \
   }
+  // (Measured and not taken, round 4: the loop ROTATED so that R4 runs behind the barrier in one region with the next tile's R0 requests --
+  // the barrier then comes one region earlier and waits ~1100 cycles for the DMA pieces instead of ~100: the same time per call.)
   for (int t = 0; t < ntiles; ++t) {
     const char* qs = smem + (t & 1) * DKV_STAGE;
     const char* dos = qs + ROWMAJ_BYTES;
@@ -360,28 +417,47 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     const char* dots = qts + TRANS_BYTES;
     const float* lst = reinterpret_cast<const float*>(dots + TRANS_BYTES);
     const float* dst = lst + TB;
-    if (t + 1 < ntiles) stage(t + 1, (t + 1) & 1);
+    const int tn = min(t + 1, ntiles - 1), bn = (t + 1) & 1;  // next tile and its buffer (past the end: the last tile again, into the free buffer)
     bf16x8_t fa[16], fb[16], pf0[2], df0[2], pf1[2], df1[2];
     f32x16_t sa0, dp0, sa1, dp1;
     f32x4_t l0[4], d0[4], l1[4], d1[4];
+    BWD_TR(0)
     load_rows(fa, l0, d0, qs, dos, lst, dst, 0);             // R0
     __builtin_amdgcn_sched_barrier(0);
+    BWD_TR(1)
     load_rows(fb, l1, d1, qs, dos, lst, dst, 1);             // R1
     sdp(fa, sa0, dp0);
+    stage_piece(0, tn, bn);                                  // (every piece is issued >= 2 regions ahead of the barrier that retires it)
+    stage_piece(3, tn, bn);
+    AFX_BWD_INTERLEAVE(2, 0, 2)
     __builtin_amdgcn_sched_barrier(0);
+    BWD_TR(2)
     load_cols(fa, dots, qts, 0);                             // R2
     sdp(fb, sa1, dp1);
     softmax_grad(sa0, dp0, l0, d0, pf0, df0);
-    AFX_BWD_INTERLEAVE(9)
+    stage_piece(1, tn, bn);
+    AFX_BWD_INTERLEAVE(1, 7, 4)
     __builtin_amdgcn_sched_barrier(0);
+    BWD_TR(3)
     load_cols(fb, dots, qts, 1);                             // R3
     dvdk(fa, pf0, df0);
     softmax_grad(sa1, dp1, l1, d1, pf1, df1);
-    AFX_BWD_INTERLEAVE(9)
+    stage_piece(2, tn, bn);
+    AFX_BWD_INTERLEAVE(1, 7, 4)
     __builtin_amdgcn_sched_barrier(0);
+    BWD_TR(4)
     dvdk(fb, pf1, df1);                                      // R4
+    __builtin_amdgcn_sched_barrier(0);
+    BWD_TR(5)
     AFX_SYNC_DMA();
+    BWD_TR(6)
   }
+#ifdef AFX_BWD_TRACE
+  tr[8] = (unsigned)__builtin_readcyclecounter() - tr[7];
+  tr[9] = (unsigned)__builtin_amdgcn_s_memrealtime() - tr[10];
+  if ((blockIdx.x == 0 || blockIdx.x == 1000) && lane == 0)
+    for (int i = 0; i < 12; ++i) g_bwd_trace[((blockIdx.x ? 1 : 0) * 4 + wave) * 12 + i] = tr[i];
+#endif
 #undef AFX_BWD_INTERLEAVE
   if (k_ok) {
     bf16_t* kp_o = dk + ((int64_t)b * S + k0 + kl) * lddk + h * HD;
@@ -391,8 +467,8 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         u32x2_t w;
-        w[0] = pack_bf16x2(dka[d][4 * g + 0], dka[d][4 * g + 1]);
-        w[1] = pack_bf16x2(dka[d][4 * g + 2], dka[d][4 * g + 3]);
+        w[0] = pack_bf16x2(dka[d][4 * g + 0] * SCALE, dka[d][4 * g + 1] * SCALE);
+        w[1] = pack_bf16x2(dka[d][4 * g + 2] * SCALE, dka[d][4 * g + 3] * SCALE);
         *reinterpret_cast<u32x2_t*>(kp_o + d * 32 + g * 8 + hi * 4) = w;
         w[0] = pack_bf16x2(dva[d][4 * g + 0], dva[d][4 * g + 1]);
         w[1] = pack_bf16x2(dva[d][4 * g + 2], dva[d][4 * g + 3]);
@@ -443,3 +519,12 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
 }
 
 }  // namespace afx
+
+extern "C" int afx_debug_bwd_trace(unsigned* host_out) {      // [2 blocks][4 waves][12]: region stamps of tile 36, whole-kernel cycles / 100 MHz ticks / tiles
+#ifdef AFX_BWD_TRACE
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(afx::g_bwd_trace), 2 * 4 * 12 * sizeof(unsigned)) == hipSuccess ? 0 : -1;
+#else
+  (void)host_out;
+  return -1;
+#endif
+}
