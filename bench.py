@@ -301,36 +301,48 @@ def main(argv=None):
             gc.collect()
             torch.cuda.empty_cache()
             ex = argparse.Namespace(**vars(args))
-            ex.steps, ex.warmup = min(args.steps, 5), min(args.warmup, 2)
-            q = infer_main(ex, 'qwen', rank, world, dev, dist)
-            line['qwen'] = {k: q[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'config', 'mfma_frac_end_to_end',
-                                              'roofline', 'roofline_attention') if k in q}
-            gc.collect()
-            torch.cuda.empty_cache()
-            ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8, ex.student_fp8 = 2, 1, 'flux', None, False, False
-            t = train_main(ex, rank, world, dev, dist)
-            line['train_flux'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
-                                                    'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}
-            gc.collect()
-            torch.cuda.empty_cache()
-            del t
-            # configs[4]: Qwen-Image distillation, true-CFG teacher, "fp8 MFMA fwd + bf16 grads" (teacher and student forwards on the e4m3 MFMA;
-            # says so in its dtype -- reduced precision, an extra object, never the headline)
-            ex.model, ex.teacher_fp8, ex.student_fp8 = 'qwen', True, True
-            t = train_main(ex, rank, world, dev, dist)
-            line['train_qwen_fp8'] = {k: t[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline',
-                                                        'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb') if k in t}
-            del t
-            gc.collect()
-            torch.cuda.empty_cache()
+            KEYS_T = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline', 'allreduce_exposed_ms_per_step',
+                      'allreduce_bytes_per_step', 'max_mem_gb')
+
+            def extra(name, fn):
+                """An extra object must never cost the headline its line: a failure is recorded under its key and the run goes on."""
+                try:
+                    line[name] = fn()
+                except Exception as e:              # noqa: BLE001
+                    import traceback
+                    line[name] = {'error': f'{type(e).__name__}: {e}', 'where': traceback.format_exc().strip().splitlines()[-3:]}
+                gc.collect()
+                torch.cuda.empty_cache()
+
+            def qwen_infer():
+                ex.steps, ex.warmup = min(args.steps, 5), min(args.warmup, 2)
+                q = infer_main(ex, 'qwen', rank, world, dev, dist)
+                return {k: q[k] for k in ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'config', 'mfma_frac_end_to_end', 'roofline',
+                                          'roofline_attention') if k in q}
+
+            def train(model, fp8):
+                # configs[4]: Qwen-Image distillation, true-CFG teacher, "fp8 MFMA fwd + bf16 grads" (teacher and student forwards on the e4m3
+                # MFMA; says so in its dtype -- reduced precision, an extra object, never the headline)
+                ex.steps, ex.warmup, ex.model, ex.batch, ex.teacher_fp8, ex.student_fp8 = 2, 1, model, None, fp8, fp8
+                t = train_main(ex, rank, world, dev, dist)
+                return {k: t[k] for k in KEYS_T if k in t}
+            extra('qwen', qwen_infer)
+            extra('train_flux', lambda: train('flux', False))
+            extra('train_qwen_fp8', lambda: train('qwen', True))
             # prompt -> image (encoders + 2 NFE + VAE), both families: BASELINE.md section 2 "reported separately"
             line['e2e'] = {}
             for m in ('flux', 'qwen'):
-                line['e2e'][m] = e2e_main(m, dev)
+                try:
+                    line['e2e'][m] = e2e_main(m, dev)
+                except Exception as e:              # noqa: BLE001
+                    line['e2e'][m] = {'error': f'{type(e).__name__}: {e}'}
                 gc.collect()
                 torch.cuda.empty_cache()
         if rank == 0 and not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline()
+            try:
+                line['cpu_baseline'] = cpu_baseline()
+            except Exception as e:                  # noqa: BLE001  (the headline line must still be printed)
+                line['cpu_baseline'] = {'error': f'{type(e).__name__}: {e}'}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
