@@ -14,14 +14,18 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python $R/bench.py
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_train -- python $R/bench.py --train --steps 1 --warmup 1 > $O/train_under_rocprof.log 2>/dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_attn_bwd -- python $R/tools/attn_bwd_bench.py > $O/attn_bwd_under_rocprof.log 2>/dev/null
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_fwd -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras --no-profile > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma_bwd -- python $R/tools/attn_bwd_bench.py > /dev/null 2>&1
 cd $R
+( echo '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- bench.py (forward) / tools/attn_bwd_bench.py: mean per dispatch by (kernel, grid)'; python tools/pmc_by_grid.py "$O/mfma_fwd/*/*counter_collection.csv" "$O/mfma_bwd/*/*counter_collection.csv" ) > $O/pmc_mfma_busy.txt 2>&1
 ( echo '== FETCH_SIZE (KiB per dispatch, mean)'; python tools/pmc_summary.py $(ls $O/fetch/*/*counter_collection.csv | head -1) | grep -A1 'gemm_kernel\|attention_v3' ;
   echo '== WRITE_SIZE'; python tools/pmc_summary.py $(ls $O/write/*/*counter_collection.csv | head -1) | grep -A1 'gemm_kernel\|attention_v3' ) > $O/pmc_fetch_write_size.txt 2>&1
 python tools/attn_bwd_bench.py > $O/attn_bwd_bench.txt 2>/dev/null
 # the headline with and without the per-launch HIP events, interleaved
 for i in 1 2; do
-  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python tools/bench_brief.py "profile-events on  " >> $O/no_profile_ab.txt
-  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python tools/bench_brief.py "profile-events off " >> $O/no_profile_ab.txt
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --profile-stride 1 2>/dev/null | python tools/bench_brief.py "events on every launch " >> $O/no_profile_ab.txt
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | python tools/bench_brief.py "events on 1 launch in 8 " >> $O/no_profile_ab.txt
+  python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-profile 2>/dev/null | python tools/bench_brief.py "events off             " >> $O/no_profile_ab.txt
 done
 python bench.py > $O/bench_default_line.json 2>/dev/null
 python bench.py --model qwen --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_qwen.json 2>/dev/null
@@ -30,5 +34,5 @@ python bench.py --train --steps 2 --warmup 1 > $O/bench_train_flux.json 2>$O/ben
 python bench.py --train --model qwen --steps 2 --warmup 1 > $O/bench_train_qwen.json 2>$O/bench_train_qwen.err
 python bench.py --train --model qwen --teacher-fp8 --student-fp8 --steps 2 --warmup 1 > $O/bench_train_qwen_fp8.json 2>$O/bench_train_qwen_fp8.err
 for f in $O/bench_*.json; do echo $f; python tools/bench_brief.py < $f 2>/dev/null || head -c 400 $f; done
-cat $O/no_profile_ab.txt $O/attn_bwd_bench.txt $O/pmc_fetch_write_size.txt
+cat $O/no_profile_ab.txt $O/attn_bwd_bench.txt $O/pmc_fetch_write_size.txt $O/pmc_mfma_busy.txt
 ls $O/*/* | head -40
