@@ -173,3 +173,38 @@ def test_fp8_linear_mode_tracks_bf16(family):
         a, b = outs[0][k].float(), outs[1][k].float()
         rel = ((a - b).norm() / a.norm()).item()
         assert 0 < rel < 8e-2, (k, rel)          # different (fp8) but close
+
+
+@pytest.mark.gpu
+def test_profile_events_every_launch_and_sampled():
+    """afx_profile_enable(ctx, N): an event pair on every GEMM / attention launch (N = 1) or on one launch in N (bench.py's default 8: the pairs cost
+    ~4 us each).  The sampled sums must cover 1 / N of the launches and give the same FLOP / time ratio within the launch-to-launch spread."""
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    cfg = D.FluxCfg(num_layers=2, num_single_layers=3, heads=2, joint_dim=128, pooled_dim=64)
+    w = D.make_flux_weights(cfg, seed=0)
+    eng = MMDiTEngine('flux', 2, 3, heads=2, joint_dim=128, pooled_dim=64)
+    eng.load_state_dict(w)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 256, 64, generator=g).bfloat16().cuda()
+    ctx = torch.randn(1, 64, 128, generator=g).bfloat16().cuda()
+    pooled = torch.randn(1, 64, generator=g).bfloat16().cuda()
+    t, gd = torch.tensor([0.5]).cuda(), torch.tensor([3.5]).cuda()
+
+    def run(n, stride):
+        eng.profile(stride)
+        for _ in range(n):
+            eng(x, t, ctx, pooled, gd, 16, 16)
+        torch.cuda.synchronize()
+        r = eng.profile_read(0), eng.profile_read(1)
+        eng.profile(False)
+        return r
+    (ms_g, n_g, fl_g), (ms_a, n_a, fl_a) = run(6, 1)
+    assert n_a == 6 * 5 and n_g > n_a and ms_g > 0 and ms_a > 0 and fl_g > 0        # one attention launch per block and forward
+    per_fwd = (n_g + n_a) // 6
+    (ms_g3, n_g3, fl_g3), (ms_a3, n_a3, fl_a3) = run(6, 3)
+    assert n_g3 + n_a3 == (6 * per_fwd + 2) // 3                                     # launches 0, 3, 6, ... of the counter over both classes
+    assert 0.2 < (n_g3 / max(n_g, 1)) < 0.5 and abs(fl_g3 / n_g3 - fl_g / n_g) < 0.5 * fl_g / n_g
+    out = eng(x, t, ctx, pooled, gd, 16, 16)                                         # profiling off again: nothing recorded
+    torch.cuda.synchronize()
+    assert eng.profile_read(0)[1] == 0 and torch.isfinite(out.means.float()).all()
