@@ -127,6 +127,13 @@ class LoraTrunk:
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
         self._ones: Dict[int, torch.Tensor] = {}
         self._merged: Dict[str, torch.Tensor] = {}   # bind_merged(): private merged copies for the student engine, on request
+        # Keep instead of recompute (288 GB HBM): the training forward leaves the outputs of every block's GEMMs and attention in `stash`
+        # and the backward reads them back; only element-wise work (LayerNorm-modulate, RoPE, GELU, dropout) is redone.  The reference
+        # checkpoints every block and recomputes its whole forward (arcflux.py:181-189) because it has to fit 80 GB.  ARCFLOW_TRAIN_RECOMPUTE=1
+        # (or use_stash = False) selects the recompute path (A/B runs, the parity tests run both).
+        self.use_stash = os.environ.get('ARCFLOW_TRAIN_RECOMPUTE', '0') != '1'
+        self.stash: Optional[Dict[str, torch.Tensor]] = None
+        self._lse: Dict[Tuple[int, int], torch.Tensor] = {}
         self.fp8 = False            # block linears' forward / recompute on the fp8 MFMA (enable_fp8)
         self.wq: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}     # packed key -> (e4m3 [out, in], row scales fp32 [out]) of the FROZEN weight
         self._build_frozen_transposes()
@@ -227,6 +234,12 @@ class LoraTrunk:
         corr = ops.linear(xe[:, i:], self.wcat[key][sp.row0:sp.row0 + sp.out_f, i:])      # t B^T  (K = rp)
         ops.add_scale(yl, b=corr, out=yl)
         return xd, t, y
+
+    def _dropped(self, sp: LoraSpec, x: torch.Tensor, row_off: int) -> torch.Tensor:
+        """dropout(x) of adapter `sp` (x itself without dropout): the mask is regenerated from (step seed, adapter, global row, column)."""
+        if self.p_drop <= 0:
+            return x
+        return ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
 
     def _adapted_backward(self, sp: LoraSpec, dy: torch.Tensor, xd: torch.Tensor, t: torch.Tensor, grads: torch.Tensor, row_off: int):
         """dy [M, out_total] (all rows of the packed weight), xd = dropout(x) [M, in], t = xd A^T [M, r] from the recompute.
@@ -365,6 +378,22 @@ class LoraTrunk:
     def _streams(self, T: int, S: int):
         return (('img', slice(T, S), 0), ('txt', slice(0, T), 1))
 
+    # ------------------------------------------------------------------ the stash of one student forward
+    def stash_bytes(self, rows: int) -> int:
+        D = self.D
+        return 2 * rows * (self.nd * 9 * D + self.ns * 8 * D + 2 * (self.nd + self.ns) * self.rp)
+
+    def _stash_for(self, rows: int) -> Dict[str, torch.Tensor]:
+        """Per (block, token): double blocks k|v|q pre-norm (3D), O (D), X1 (D), the mlp pre-activation (4D); single blocks the fused
+        k|v|q|mlp pre-activation (7D) and O (D); t = dropout(x) A^T of both adapters of every block (2 rp).  FLUX at 4 samples: 54 GB."""
+        if self.stash is None or self.stash['rows'] != rows:
+            D, bf = self.D, dict(dtype=torch.bfloat16, device=self.dev)
+            self.stash = None
+            self.stash = dict(rows=rows, qkv=torch.empty(self.nd, rows, 3 * D, **bf), o=torch.empty(self.nd + self.ns, rows, D, **bf),
+                              x1=torch.empty(self.nd, rows, D, **bf), pre=torch.empty(self.nd, rows, 4 * D, **bf),
+                              fp=torch.empty(self.ns, rows, 7 * D, **bf), t=torch.empty(2 * (self.nd + self.ns), rows, self.rp, **bf))
+        return self.stash
+
     # ------------------------------------------------------------------ block forward / recompute + backward (one sample)
     def _double_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: Optional[torch.Tensor], grads,
                       fwd_only: bool = False) -> torch.Tensor:
@@ -378,25 +407,46 @@ class LoraTrunk:
         mv.update({('txt', c): mod[m0 + (6 + c) * D:m0 + (7 + c) * D] for c in range(6)})
         qkn = pk[p + 'qknorm']                                   # [img_q, img_k, txt_q, txt_k]
         bf = dict(dtype=torch.bfloat16, device=dev)
-        Xn1 = torch.empty(S, D, **bf)
-        QKVp = torch.empty(S, 3 * D, **bf)                       # pre-norm k | v | q
-        for s, rows, _ in self._streams(T, S):
-            ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
-            self._lin(Xn1[rows], p + s + '_qkv', out=QKVp[rows])
+        R = slice(self.row0, self.row0 + S)
+        st = self.stash if self.use_stash else None
+        restore = st is not None and not fwd_only           # backward with the forward's GEMM / attention outputs at hand
+        keepf = st is not None and fwd_only                 # forward that leaves them there
+        QKVp = st['qkv'][i, R] if st is not None else torch.empty(S, 3 * D, **bf)       # pre-norm k | v | q
+        if not restore:
+            Xn1 = torch.empty(S, D, **bf)
+            for s, rows, _ in self._streams(T, S):
+                ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
+                self._lin(Xn1[rows], p + s + '_qkv', out=QKVp[rows])
         Kp, V, Qp = QKVp[:, :D], QKVp[:, D:2 * D], QKVp[:, 2 * D:]
-        K, Q, O = torch.empty(S, D, **bf), torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
+        O = st['o'][i, R] if st is not None else torch.empty(S, D, **bf)
         self._rope(Kp, K, qkn[3], qkn[1], cos, sin, S, T)
         self._rope(Qp, Q, qkn[2], qkn[0], cos, sin, S, T)
-        lse = ops.attention_fwd_lse_2d(Q, K, V, O, 1, S, self.H)
-        X1 = torch.empty(S, D, **bf)
+        if restore:
+            lse = self._lse[(i, self.row0)]
+        else:
+            lse = ops.attention_fwd_lse_2d(Q, K, V, O, 1, S, self.H)
+            if keepf:
+                self._lse[(i, self.row0)] = lse
+        X1 = st['x1'][i, R] if st is not None else torch.empty(S, D, **bf)
         Xe2 = self._xe(S, D)                                     # [Xn2 | t1]: the mlp1 operand
         He = self._xe(S, 4 * D)                                  # [gelu(Pre) | t2]: the mlp2 operand
         Xn2, Hh = Xe2[:, :D], He[:, :4 * D]
-        Pre = torch.empty(S, 4 * D, **bf)
+        Pre = st['pre'][i, R] if st is not None else torch.empty(S, 4 * D, **bf)
         Xo = torch.empty(S, D, **bf) if fwd_only else None
         keep = {}                                                # per stream: (xd1, t1, xd2, t2) of the two adapters
         for s, rows, _ in self._streams(T, S):
             sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
+            if restore:         # element-wise work only: Xn2 -> dropout, gelu(Pre) -> dropout; t1 / t2 come back from the stash
+                xd1 = t1 = xd2 = t2 = None
+                if sp1 is not None:
+                    ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
+                    xd1, t1 = self._dropped(sp1, Xn2[rows], rows.start), st['t'][2 * i, R][rows][:, :self.r]
+                if sp2 is not None:
+                    ops.gelu(Pre[rows], out=Hh[rows])
+                    xd2, t2 = self._dropped(sp2, Hh[rows], rows.start), st['t'][2 * i + 1, R][rows][:, :self.r]
+                keep[s] = (xd1, t1, xd2, t2)
+                continue
             if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
                 y1 = self.ybuf[2 * i, self.row0:self.row0 + S][rows]
                 self._lin(O[rows], p + s + '_out', out=y1)
@@ -406,6 +456,8 @@ class LoraTrunk:
             ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
             if sp1 is not None:
                 xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows])
+                if keepf:
+                    st['t'][2 * i, R][rows].copy_(Xe2[rows][:, D:])
             else:
                 xd1 = t1 = None
                 self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows])
@@ -413,6 +465,8 @@ class LoraTrunk:
             y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows] if fwd_only else None
             if sp2 is not None:
                 xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only)
+                if keepf:
+                    st['t'][2 * i + 1, R][rows].copy_(He[rows][:, 4 * D:])
             else:
                 xd2 = t2 = None
                 if fwd_only:
@@ -470,21 +524,43 @@ class LoraTrunk:
         qkn = pk[p + 'qknorm']                                   # [q, k]
         bf = dict(dtype=torch.bfloat16, device=dev)
         sp_out, sp_mlp = self._spec(p + 'out'), self._spec(p + 'fused')
+        R = slice(self.row0, self.row0 + S)
+        st = self.stash if self.use_stash else None
+        restore = st is not None and not fwd_only
+        keepf = st is not None and fwd_only
+        bi = self.nd + i                                         # block index in the o / t / lse stashes
         Xe = self._xe(S, D)                                      # [Xn | t_mlp]: operand of the fused k|v|q|mlp launch
         Xn = Xe[:, :D]
         ops.norm_modulate(X, sc, sh, out=Xn)
-        Fp = torch.empty(S, 7 * D, **bf)                         # pre-activation k|v|q|mlp
-        xd_m, t_m, _ = self._adapted(sp_mlp, Xe, 0, out=Fp)      # (the k|v|q rows of wcat carry zero B columns)
+        Fp = st['fp'][i, R] if st is not None else torch.empty(S, 7 * D, **bf)          # pre-activation k|v|q|mlp
+        if restore:
+            xd_m, t_m = self._dropped(sp_mlp, Xn, 0), st['t'][2 * bi, R][:, :self.r]
+        else:
+            xd_m, t_m, _ = self._adapted(sp_mlp, Xe, 0, out=Fp)  # (the k|v|q rows of wcat carry zero B columns)
+            if keepf:
+                st['t'][2 * bi, R].copy_(Xe[:, D:])
         Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         Ge = self._xe(S, 5 * D)                                  # [O | gelu(mlp) | t_out] = proj_out operand
         G = Ge[:, :5 * D]
         self._rope(Kp, K, qkn[1], qkn[1], cos, sin, S, T)
         self._rope(Qp, Q, qkn[0], qkn[0], cos, sin, S, T)
-        lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
+        if restore:
+            lse = self._lse[(bi, self.row0)]
+            G[:, :D].copy_(st['o'][bi, R])
+        else:
+            lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
+            if keepf:
+                self._lse[(bi, self.row0)] = lse
+                st['o'][bi, R].copy_(G[:, :D])
         ops.gelu(Mp, out=G[:, D:])
         y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S] if fwd_only else None
-        xd_o, t_o, _ = self._adapted(sp_out, Ge, 0, out=y, main=fwd_only)
+        if restore:
+            xd_o, t_o = self._dropped(sp_out, G, 0), st['t'][2 * bi + 1, R][:, :self.r]
+        else:
+            xd_o, t_o, _ = self._adapted(sp_out, Ge, 0, out=y, main=fwd_only)
+            if keepf:
+                st['t'][2 * bi + 1, R].copy_(Ge[:, 5 * D:])
         if fwd_only:
             return ops.gate_residual(y, gt, X)
         # ---- backward ----
@@ -517,6 +593,8 @@ class LoraTrunk:
         cos, sin = self.eng.rope_tables(hp, wp, T)
         if self.ybuf is None or self.ybuf.shape[1] != x_tokens.shape[0]:
             self.ybuf = torch.empty(2 * self.nd + self.ns, x_tokens.shape[0], self.D, dtype=torch.bfloat16, device=self.dev)
+        if self.use_stash:
+            self._stash_for(x_tokens.shape[0])
         X = x_tokens[b * S:(b + 1) * S]
         for i in range(self.nd):
             ckpt[i, b * S:(b + 1) * S].copy_(X)
