@@ -7,9 +7,10 @@ Design for MI355X:
     t = dropout(x) A^T is written into r extra columns of the activation buffer and the frozen weight carries B in r extra columns,
     y = [x | t] [W | B]^T  (K-extension; "wcat").  W stays the frozen tensor's values (nothing is re-merged after an optimizer
     step: only the B columns are refreshed), and small updates of B A are not lost in W's bf16 grid.
-  * BACKWARD walks the blocks in reverse; each block is recomputed from its checkpoint with the same HIP kernels
-    (bit-identical to the forward) keeping the intermediates (incl. dropout(x) and t of every adapter), then differentiated by
-    hand: the input gradient and dT = dy B come out of ONE GEMM on the transposed frozen weight with r extra rows
+  * The training forward KEEPS every block's GEMM / attention outputs in HBM (the stash: 54 GB for FLUX at 4 samples; the reference
+    checkpoints and recomputes every block, arcflux.py:181-189, to fit 80 GB).  BACKWARD walks the blocks in reverse, reads them back, redoes
+    the element-wise work only (LayerNorm-modulate, RMSNorm + RoPE, GELU, dropout masks) and differentiates by hand (ARCFLOW_TRAIN_RECOMPUTE=1:
+    each block is recomputed from its checkpoint with the same kernels instead): the input gradient and dT = dy B come out of ONE GEMM on the transposed frozen weight with r extra rows
     [dx0 | dT] = dy [W^T ; B^T]^T  (N-extension; "wtcat"), then dx = dx0 + ((dT A) . keep/(1-p));
     flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
   * LoRA gradients per adapted linear:   dB += dy^T t,  dA += dT^T dropout(x)   (rank-r skinny GEMMs, fp32 accumulate-into).
@@ -383,12 +384,21 @@ class LoraTrunk:
         D = self.D
         return 2 * rows * (self.nd * 9 * D + self.ns * 8 * D + 2 * (self.nd + self.ns) * self.rp)
 
-    def _stash_for(self, rows: int) -> Dict[str, torch.Tensor]:
+    def _stash_for(self, rows: int) -> Optional[Dict[str, torch.Tensor]]:
         """Per (block, token): double blocks k|v|q pre-norm (3D), O (D), X1 (D), the mlp pre-activation (4D); single blocks the fused
         k|v|q|mlp pre-activation (7D) and O (D); t = dropout(x) A^T of both adapters of every block (2 rp).  FLUX at 4 samples: 54 GB."""
         if self.stash is None or self.stash['rows'] != rows:
             D, bf = self.D, dict(dtype=torch.bfloat16, device=self.dev)
             self.stash = None
+            free, _ = torch.cuda.mem_get_info(self.dev)
+            need = self.stash_bytes(rows)
+            if need > free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) - (8 << 30):
+                # not enough HBM for this batch / sequence: the reference's schedule (recompute every block from its checkpoint) still works
+                import warnings
+                warnings.warn(f'LoraTrunk: {need / 2**30:.0f} GiB of kept forward outputs do not fit ({free / 2**30:.0f} GiB free): '
+                              f'falling back to recomputing every block in the backward')
+                self.use_stash = False
+                return None
             self.stash = dict(rows=rows, qkv=torch.empty(self.nd, rows, 3 * D, **bf), o=torch.empty(self.nd + self.ns, rows, D, **bf),
                               x1=torch.empty(self.nd, rows, D, **bf), pre=torch.empty(self.nd, rows, 4 * D, **bf),
                               fp=torch.empty(self.ns, rows, 7 * D, **bf), t=torch.empty(2 * (self.nd + self.ns), rows, self.rp, **bf))
