@@ -401,6 +401,21 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
   };
   // (MFMA, LDS read, VALU) triples: one matrix instruction, one fragment read for the next group and a slice of the other half's
   // arithmetic per 32-cycle MFMA slot
+// Tuning knobs of the regions (build variants with -D...): VALU per MFMA slot in R2 / R3, LDS reads and DMA spacing in R1, no group barriers at all.
+// Swept in round 4 on one box (BWD_NV 4 / 7 / 10 / 13, BWD_R1_NR 1 / 2, BWD_R1_DMA 2 / 4, BWD_NO_GROUPS): 561-571 TF over the 5 matmuls for every
+// setting -- the order INSIDE a region is not what limits this kernel.
+#ifndef BWD_NV
+#define BWD_NV 7
+#endif
+#ifndef BWD_R1_NR
+#define BWD_R1_NR 2
+#endif
+#ifndef BWD_R1_DMA
+#define BWD_R1_DMA 2
+#endif
+#ifdef BWD_NO_GROUPS
+#define AFX_BWD_INTERLEAVE(NR, NV, NDMA)
+#else
 #define AFX_BWD_INTERLEAVE(NR, NV, NDMA)                         \
   _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) {            \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);           \
@@ -408,6 +423,7 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     if ((i_ % (NDMA)) == 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   /* one LDS-DMA piece per NDMA MFMAs */ \
     if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);  \
   }
+#endif
   // (Measured and not taken, round 4: the loop ROTATED so that R4 runs behind the barrier in one region with the next tile's R0 requests --
   // the barrier then comes one region earlier and waits ~1100 cycles for the DMA pieces instead of ~100: the same time per call.)
   for (int t = 0; t < ntiles; ++t) {
@@ -429,21 +445,21 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
     sdp(fa, sa0, dp0);
     stage_piece(0, tn, bn);                                  // (every piece is issued >= 2 regions ahead of the barrier that retires it)
     stage_piece(3, tn, bn);
-    AFX_BWD_INTERLEAVE(2, 0, 2)
+    AFX_BWD_INTERLEAVE(BWD_R1_NR, 0, BWD_R1_DMA)
     __builtin_amdgcn_sched_barrier(0);
     BWD_TR(2)
     load_cols(fa, dots, qts, 0);                             // R2
     sdp(fb, sa1, dp1);
     softmax_grad(sa0, dp0, l0, d0, pf0, df0);
     stage_piece(1, tn, bn);
-    AFX_BWD_INTERLEAVE(1, 7, 4)
+    AFX_BWD_INTERLEAVE(1, BWD_NV, 4)
     __builtin_amdgcn_sched_barrier(0);
     BWD_TR(3)
     load_cols(fb, dots, qts, 1);                             // R3
     dvdk(fa, pf0, df0);
     softmax_grad(sa1, dp1, l1, d1, pf1, df1);
     stage_piece(2, tn, bn);
-    AFX_BWD_INTERLEAVE(1, 7, 4)
+    AFX_BWD_INTERLEAVE(1, BWD_NV, 4)
     __builtin_amdgcn_sched_barrier(0);
     BWD_TR(4)
     dvdk(fb, pf1, df1);                                      // R4
