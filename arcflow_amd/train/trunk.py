@@ -387,9 +387,10 @@ class LoraTrunk:
     def _stash_for(self, rows: int) -> Optional[Dict[str, torch.Tensor]]:
         """Per (block, token): double blocks k|v|q pre-norm (3D), O (D), X1 (D), the mlp pre-activation (4D); single blocks the fused
         k|v|q|mlp pre-activation (7D) and O (D); t = dropout(x) A^T of both adapters of every block (2 rp).  FLUX at 4 samples: 54 GB."""
-        if self.stash is None or self.stash['rows'] != rows:
+        if self.stash is None or self.stash['rows'] < rows:      # grow-only: prompt lengths (Qwen-Image) vary from batch to batch, the row ranges used are [0, B S)
             D, bf = self.D, dict(dtype=torch.bfloat16, device=self.dev)
             self.stash = None
+            self._lse.clear()
             free, _ = torch.cuda.mem_get_info(self.dev)
             need = self.stash_bytes(rows)
             if need > free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) - (8 << 30):
