@@ -93,8 +93,9 @@ def main():
         sd = init_arcflow_heads_from_teacher(sd, K=eng['num_gaussians'], L=eng['logweights_channels'], generator=torch.Generator().manual_seed(args.seed))
         dist_ = ArcFlowDistiller(family, eng, sd, dc, device=dev, process_group=pg)
 
-    # ---- resume (resume_from of the config defaults to checkpoints/<name>/latest.pth) ----------------------
-    resume = args.resume_from or run['resume_from']
+    # ---- resume (resume_from of the config = checkpoints/<name>/latest.pth; with --work-dir the latest checkpoint under it) ----
+    ckpt_dir = os.path.join(args.work_dir, 'checkpoints') if args.work_dir else run['ckpt_dir']
+    resume = args.resume_from or (os.path.join(ckpt_dir, 'latest.pth') if args.work_dir else run['resume_from'])
     if resume and os.path.exists(resume):
         meta = checkpoint.load_checkpoint(dist_, resume)
         if rank == 0:
@@ -149,7 +150,6 @@ def main():
             synth['negative_prompt_embeds'] = (torch.randn(B, T, eng['joint_dim'], device=dev, generator=rng) * 0.1).bfloat16()
 
     total = args.iters if args.iters is not None else run['total_iters']
-    ckpt_dir = os.path.join(args.work_dir, 'checkpoints') if args.work_dir else run['ckpt_dir']
     t_last = time.perf_counter()
     while dist_.iteration < total:
         cond = next(loader) if loader is not None else synth
