@@ -22,6 +22,7 @@ Design for MI355X:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import os
 import math
@@ -123,6 +124,7 @@ class LoraTrunk:
         self.ybuf: Optional[torch.Tensor] = None     # [2 nd + ns, B*S, D] pre-gate branch outputs of the last training forward
         self.dmod: Optional[torch.Tensor] = None     # [n_mod] fp32: modulation gradients of the sample being back-propagated
         self._tmp2 = torch.zeros(2, self.D, dtype=torch.float32, device=self.dev)
+        self._tmp2_side = torch.zeros(2, self.D, dtype=torch.float32, device=self.dev)
         self.p_drop = 0.0           # LoRA input dropout (peft lora_dropout); masks are regenerated from (seed, site, row, col)
         self.seed = 0
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
@@ -133,6 +135,14 @@ class LoraTrunk:
         # checkpoints every block and recomputes its whole forward (arcflux.py:181-189) because it has to fit 80 GB.  ARCFLOW_TRAIN_RECOMPUTE=1
         # (or use_stash = False) selects the recompute path (A/B runs, the parity tests run both).
         self.use_stash = os.environ.get('ARCFLOW_TRAIN_RECOMPUTE', '0') != '1'
+        # The text stream of a double block (512 / <= 128 rows beside 4096) is a chain of launches that fill a fraction of the chip; between
+        # the two attention joins it is independent of the image stream, so it runs on a SIDE HIP stream and its work-groups take the
+        # compute units the image stream's launches leave idle in their last rounds (ARCFLOW_TRAIN_TXT_STREAM=0: one stream, for A/B runs).
+        self.side = torch.cuda.Stream(device=self.dev) if os.environ.get('ARCFLOW_TRAIN_TXT_STREAM', '1') != '0' else None
+        # The adapters' weight gradients (dB += dy^T t, dA += dT^T dropout(x): two transposes and a [r x .] product each) are needed by
+        # nobody until the block's slice is exchanged, and their launches have 12-60 tiles: they go to a THIRD stream behind the dgrad
+        # GEMM that produced dT and run beside the input-gradient chain (ARCFLOW_TRAIN_WGRAD_STREAM=0: in line).
+        self.aux = torch.cuda.Stream(device=self.dev) if os.environ.get('ARCFLOW_TRAIN_WGRAD_STREAM', '1') != '0' else None
         self.stash: Optional[Dict[str, torch.Tensor]] = None
         self._lse: Dict[Tuple[int, int], torch.Tensor] = {}
         self.fp8 = False            # block linears' forward / recompute on the fp8 MFMA (enable_fp8)
@@ -249,8 +259,14 @@ class LoraTrunk:
         dxe = ops.linear(dy, self.wtcat[sp.packed_key])                       # [dx0 | dT | 0]
         dx, dT = dxe[:, :i], dxe[:, i:i + r]
         dyl = dy[:, sp.row0:sp.row0 + sp.out_f]
-        ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)     # contraction over the tokens
-        ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
+        cur = torch.cuda.current_stream(self.dev)
+        if self.aux is not None:
+            self.aux.wait_stream(cur)
+            for x_ in (dy, t, xd, dxe):                    # the allocator must not hand their memory out again before the side work has read it
+                x_.record_stream(self.aux)
+        with (torch.cuda.stream(self.aux) if self.aux is not None else contextlib.nullcontext()):
+            ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)     # contraction over the tokens
+            ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
         ops.lora_dropout(ops.linear(dxe[:, i:], self.at16p[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=3, out=dx)
         return dx
 
@@ -296,10 +312,12 @@ class LoraTrunk:
     # ------------------------------------------------------------------ LoRA gradients of one linear
     def _dmod_ln(self, x: torch.Tensor, dxn: torch.Tensor, off_scale: int, off_shift: int) -> None:
         """xn = LN(x) (1 + scale) + shift:  d_scale += sum_rows dxn * LN(x),  d_shift += sum_rows dxn."""
-        self._tmp2.zero_()
-        ops.normout_backward(x, dxn, self._tmp2.view(1, 2, self.D), x.shape[0])
-        self.dmod[off_scale:off_scale + self.D] += self._tmp2[0]
-        self.dmod[off_shift:off_shift + self.D] += self._tmp2[1]
+        on_side = self.side is not None and torch.cuda.current_stream(self.dev) == self.side
+        tmp = self._tmp2_side if on_side else self._tmp2          # one scratch per stream: the two token streams run concurrently
+        tmp.zero_()
+        ops.normout_backward(x, dxn, tmp.view(1, 2, self.D), x.shape[0])
+        self.dmod[off_scale:off_scale + self.D] += tmp[0]
+        self.dmod[off_shift:off_shift + self.D] += tmp[1]
 
     # ------------------------------------------------------------------ timestep embedder with its LoRA pair (host-sized math)
     def _keep_scale(self, sp: LoraSpec, rows: int, cols: int) -> Optional[torch.Tensor]:
@@ -377,7 +395,24 @@ class LoraTrunk:
                                                  _p(w_txt), _p(w_img), _p(cos), _p(sin), 1, S, T, self.H, int(dy is not None), _s()))
 
     def _streams(self, T: int, S: int):
-        return (('img', slice(T, S), 0), ('txt', slice(0, T), 1))
+        """The two token streams of a double block as (name, rows, index, stream context): the text stream first, on the side stream --
+        it waits for everything enqueued on the current stream so far, and ``_join`` makes the current stream wait for it.  Tensors a
+        stream allocates inside its context are only used by that stream until the join (the caching allocator keeps them in that
+        stream's pool); tensors shared by both are allocated before the loop and outlive the join."""
+        if self.side is None or T == 0:
+            return (('img', slice(T, S), 0, contextlib.nullcontext()), ('txt', slice(0, T), 1, contextlib.nullcontext()))
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        return (('txt', slice(0, T), 1, torch.cuda.stream(self.side)), ('img', slice(T, S), 0, contextlib.nullcontext()))
+
+    def _join(self) -> None:
+        if self.side is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.side)
+
+    def _join_wgrad(self) -> None:
+        """The current stream waits for the weight-gradient stream: before a block's gradient slice is handed on, before the stash rows
+        it reads are overwritten."""
+        if self.aux is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.aux)
 
     # ------------------------------------------------------------------ the stash of one student forward
     def stash_bytes(self, rows: int) -> int:
@@ -425,9 +460,11 @@ class LoraTrunk:
         QKVp = st['qkv'][i, R] if st is not None else torch.empty(S, 3 * D, **bf)       # pre-norm k | v | q
         if not restore:
             Xn1 = torch.empty(S, D, **bf)
-            for s, rows, _ in self._streams(T, S):
-                ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
-                self._lin(Xn1[rows], p + s + '_qkv', out=QKVp[rows])
+            for s, rows, _, on_stream in self._streams(T, S):
+                with on_stream:
+                    ops.norm_modulate(X[rows], mv[(s, 1)], mv[(s, 0)], out=Xn1[rows])
+                    self._lin(Xn1[rows], p + s + '_qkv', out=QKVp[rows])
+            self._join()
         Kp, V, Qp = QKVp[:, :D], QKVp[:, D:2 * D], QKVp[:, 2 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         O = st['o'][i, R] if st is not None else torch.empty(S, D, **bf)
@@ -446,83 +483,89 @@ class LoraTrunk:
         Pre = st['pre'][i, R] if st is not None else torch.empty(S, 4 * D, **bf)
         Xo = torch.empty(S, D, **bf) if fwd_only else None
         keep = {}                                                # per stream: (xd1, t1, xd2, t2) of the two adapters
-        for s, rows, _ in self._streams(T, S):
-            sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-            if restore:         # element-wise work only: Xn2 -> dropout, gelu(Pre) -> dropout; t1 / t2 come back from the stash
-                xd1 = t1 = xd2 = t2 = None
+        for s, rows, _, on_stream in self._streams(T, S):
+            with on_stream:
+                sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
+                if restore:         # element-wise work only: Xn2 -> dropout, gelu(Pre) -> dropout; t1 / t2 come back from the stash
+                    xd1 = t1 = xd2 = t2 = None
+                    if sp1 is not None:
+                        ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
+                        xd1, t1 = self._dropped(sp1, Xn2[rows], rows.start), st['t'][2 * i, R][rows][:, :self.r]
+                    if sp2 is not None:
+                        ops.gelu(Pre[rows], out=Hh[rows])
+                        xd2, t2 = self._dropped(sp2, Hh[rows], rows.start), st['t'][2 * i + 1, R][rows][:, :self.r]
+                    keep[s] = (xd1, t1, xd2, t2)
+                    continue
+                if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
+                    y1 = self.ybuf[2 * i, self.row0:self.row0 + S][rows]
+                    self._lin(O[rows], p + s + '_out', out=y1)
+                    ops.gate_residual(y1, mv[(s, 2)], X[rows], out=X1[rows])
+                else:
+                    self._lin(O[rows], p + s + '_out', epilogue='gate_res', gate=mv[(s, 2)], residual=X[rows], out=X1[rows])
+                ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
                 if sp1 is not None:
-                    ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-                    xd1, t1 = self._dropped(sp1, Xn2[rows], rows.start), st['t'][2 * i, R][rows][:, :self.r]
+                    xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows])
+                    if keepf:
+                        st['t'][2 * i, R][rows].copy_(Xe2[rows][:, D:])
+                else:
+                    xd1 = t1 = None
+                    self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows])
+                ops.gelu(Pre[rows], out=Hh[rows])
+                y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows] if fwd_only else None
                 if sp2 is not None:
-                    ops.gelu(Pre[rows], out=Hh[rows])
-                    xd2, t2 = self._dropped(sp2, Hh[rows], rows.start), st['t'][2 * i + 1, R][rows][:, :self.r]
-                keep[s] = (xd1, t1, xd2, t2)
-                continue
-            if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
-                y1 = self.ybuf[2 * i, self.row0:self.row0 + S][rows]
-                self._lin(O[rows], p + s + '_out', out=y1)
-                ops.gate_residual(y1, mv[(s, 2)], X[rows], out=X1[rows])
-            else:
-                self._lin(O[rows], p + s + '_out', epilogue='gate_res', gate=mv[(s, 2)], residual=X[rows], out=X1[rows])
-            ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-            if sp1 is not None:
-                xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows])
-                if keepf:
-                    st['t'][2 * i, R][rows].copy_(Xe2[rows][:, D:])
-            else:
-                xd1 = t1 = None
-                self._lin(Xn2[rows], p + s + '_mlp1', out=Pre[rows])
-            ops.gelu(Pre[rows], out=Hh[rows])
-            y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows] if fwd_only else None
-            if sp2 is not None:
-                xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only)
-                if keepf:
-                    st['t'][2 * i + 1, R][rows].copy_(He[rows][:, 4 * D:])
-            else:
-                xd2 = t2 = None
+                    xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only)
+                    if keepf:
+                        st['t'][2 * i + 1, R][rows].copy_(He[rows][:, 4 * D:])
+                else:
+                    xd2 = t2 = None
+                    if fwd_only:
+                        self._lin(Hh[rows], p + s + '_mlp2', out=y2)
                 if fwd_only:
-                    self._lin(Hh[rows], p + s + '_mlp2', out=y2)
-            if fwd_only:
-                ops.gate_residual(y2, mv[(s, 5)], X1[rows], out=Xo[rows])
-            keep[s] = (xd1, t1, xd2, t2)
+                    ops.gate_residual(y2, mv[(s, 5)], X1[rows], out=Xo[rows])
+                keep[s] = (xd1, t1, xd2, t2)
+        self._join()
         if fwd_only:
             return Xo
         # ---- backward ----
         dX1 = torch.empty(S, D, **bf)
         dO = torch.empty(S, D, **bf)
-        for s, rows, _ in self._streams(T, S):
-            dY2 = ops.add_scale(dXo[rows], gate=mv[(s, 5)])
-            sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-            xd1, t1, xd2, t2 = keep[s]
-            if sp2 is not None:
-                dH = self._adapted_backward(sp2, dY2, xd2, t2, grads, rows.start)
-            else:
-                dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
-            dPre = ops.gelu(Pre[rows], dh=dH)
-            if sp1 is not None:
-                dXn2 = self._adapted_backward(sp1, dPre, xd1, t1, grads, rows.start)
-            else:
-                dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
-            ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
-            if self.dmod is not None:      # d(shift3, scale4, gate5, gate2) of this stream
-                so = m0 + (0 if s == 'img' else 6) * D
-                ops.coldot(dXo[rows], self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows], self.dmod[so + 5 * D:so + 6 * D])
-                self._dmod_ln(X1[rows], dXn2, so + 4 * D, so + 3 * D)
-                ops.coldot(dX1[rows], self.ybuf[2 * i, self.row0:self.row0 + S][rows], self.dmod[so + 2 * D:so + 3 * D])
-            dYo = ops.add_scale(dX1[rows], gate=mv[(s, 2)])
-            ops.linear(dYo, self.wt[p + s + '_out'], out=dO[rows])
+        for s, rows, _, on_stream in self._streams(T, S):
+            with on_stream:
+                dY2 = ops.add_scale(dXo[rows], gate=mv[(s, 5)])
+                sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
+                xd1, t1, xd2, t2 = keep[s]
+                if sp2 is not None:
+                    dH = self._adapted_backward(sp2, dY2, xd2, t2, grads, rows.start)
+                else:
+                    dH = ops.linear(dY2, self.wt[p + s + '_mlp2'])
+                dPre = ops.gelu(Pre[rows], dh=dH)
+                if sp1 is not None:
+                    dXn2 = self._adapted_backward(sp1, dPre, xd1, t1, grads, rows.start)
+                else:
+                    dXn2 = ops.linear(dPre, self.wt[p + s + '_mlp1'])
+                ops.ln_modulate_backward(X1[rows], dXn2, mv[(s, 4)], dres=dXo[rows], out=dX1[rows])
+                if self.dmod is not None:      # d(shift3, scale4, gate5, gate2) of this stream
+                    so = m0 + (0 if s == 'img' else 6) * D
+                    ops.coldot(dXo[rows], self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows], self.dmod[so + 5 * D:so + 6 * D])
+                    self._dmod_ln(X1[rows], dXn2, so + 4 * D, so + 3 * D)
+                    ops.coldot(dX1[rows], self.ybuf[2 * i, self.row0:self.row0 + S][rows], self.dmod[so + 2 * D:so + 3 * D])
+                dYo = ops.add_scale(dX1[rows], gate=mv[(s, 2)])
+                ops.linear(dYo, self.wt[p + s + '_out'], out=dO[rows])
+        self._join()
         dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
         dQKVp = torch.empty(S, 3 * D, **bf)
         ops.attention_bwd_2d(Q, K, V, O, dO, lse, dQ, dK, dQKVp[:, D:2 * D], 1, S, self.H)
         self._rope(Kp, dQKVp[:, :D], qkn[3], qkn[1], cos, sin, S, T, dy=dK)
         self._rope(Qp, dQKVp[:, 2 * D:], qkn[2], qkn[0], cos, sin, S, T, dy=dQ)
         dX = torch.empty(S, D, **bf)
-        for s, rows, _ in self._streams(T, S):
-            dXn1 = ops.linear(dQKVp[rows], self.wt[p + s + '_qkv'])
-            ops.ln_modulate_backward(X[rows], dXn1, mv[(s, 1)], dres=dX1[rows], out=dX[rows])
-            if self.dmod is not None:
-                so = m0 + (0 if s == 'img' else 6) * D
-                self._dmod_ln(X[rows], dXn1, so + D, so)
+        for s, rows, _, on_stream in self._streams(T, S):
+            with on_stream:
+                dXn1 = ops.linear(dQKVp[rows], self.wt[p + s + '_qkv'])
+                ops.ln_modulate_backward(X[rows], dXn1, mv[(s, 1)], dres=dX1[rows], out=dX[rows])
+                if self.dmod is not None:
+                    so = m0 + (0 if s == 'img' else 6) * D
+                    self._dmod_ln(X[rows], dXn1, so + D, so)
+        self._join()
         return dX
 
     def _single_block(self, i: int, X: torch.Tensor, mod: torch.Tensor, cos, sin, T: int, dXo: Optional[torch.Tensor], grads,
@@ -635,9 +678,12 @@ class LoraTrunk:
             X = ckpt[self.nd + i, b * S:(b + 1) * S]
             dX = self._single_block(i, X, mod, cos, sin, T, dX, grads)
             if on_block_done is not None:
+                self._join_wgrad()
                 on_block_done(self.nd + i)
         for i in reversed(range(self.nd)):
             X = ckpt[i, b * S:(b + 1) * S]
             dX = self._double_block(i, X, mod, cos, sin, T, dX, grads)
             if on_block_done is not None:
+                self._join_wgrad()
                 on_block_done(i)
+        self._join_wgrad()

@@ -913,3 +913,47 @@ def test_kept_forward_outputs_equal_recompute(family):
     print('stash vs recompute: gradient rel-L2', rel)
     assert rel < 5e-3, rel
     assert ((p1 - p0).abs().max() / p0.abs().max()).item() < 1e-3          # (AdamW turns a sign flip of a near-zero gradient into a 2 lr step)
+
+
+@pytest.mark.gpu
+def test_text_side_stream_equals_one_stream():
+    """The text stream of a double block runs on a side HIP stream beside the image stream (train/trunk.py `_streams`) and the adapters'
+    weight-gradient products on a third one (`_adapted_backward`).  Same iteration
+    with and without it, while a third stream keeps the chip busy (the interleaving that exposed a scratch tensor shared by the two
+    streams when this was built): gradients agree to the order of the float atomics."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    cfg, w = _setup()
+    B, hp, wp, T, r = 2, 8, 8, 64, 64
+    g = torch.Generator().manual_seed(15)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16().cuda()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16().cuda()
+    x0 = torch.randn(B, hp * wp, 64, generator=g).cuda()
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0, lora_rank=r)
+    Bm = {}
+    noise_stream, junk = torch.cuda.Stream(), torch.randn(1 << 22, device='cuda')
+
+    def run(side):
+        d = ArcFlowDistiller('flux', dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64), w, dc)
+        for sp in d.trunk.specs:
+            if sp.name not in Bm:
+                Bm[sp.name] = (torch.randn(sp.out_f, r, generator=g) * 0.02).cuda()
+            d.trunk.B(sp).copy_(Bm[sp.name])
+        d.trunk.refresh()
+        assert d.trunk.side is not None and d.trunk.aux is not None         # the defaults
+        if not side:
+            d.trunk.side = d.trunk.aux = None
+        d.iteration = 1
+        with torch.cuda.stream(noise_stream):
+            for _ in range(200):
+                junk.mul_(1.0001)
+        info = d.train_step(dict(prompt_embeds=pe, pooled=pooled, hp=hp, wp=wp), B, x_init=x0, draws=draws)
+        torch.cuda.synchronize()
+        return d.grad.clone(), info['loss']
+
+    ref, loss_ref = run(False)
+    assert ref.abs().max().item() > 0
+    for _ in range(4):
+        got, loss = run(True)
+        assert ((got - ref).norm() / ref.norm()).item() < 1e-6
+        assert abs(loss - loss_ref) <= 1e-6 * abs(loss_ref)
