@@ -26,6 +26,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -1472,6 +1474,187 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   }
 }
 
+// =================================================================================================
+// v3 / fp8: the one-wave-per-SIMD kernel for OCP e4m3 operands (v_mfma_f32_16x16x128_f8f6f4: 2x the bf16 rate).  LDS rings, DMA stream,
+// swizzle and the ONE mid-tile barrier are gemm_kernel_v3's -- a 128-byte LDS row is now 128 k-values, so a K-tile is a single MFMA per
+// 16x16 output tile, and that MFMA needs BOTH chunk halves (fq and 4 + fq: the contraction order inside the instruction is free as long
+// as the two operands agree) of its operands.  The two phases of a tile therefore split the COLUMN tiles instead of K:
+//   phase 0   MFMAs (i, j <  NJ/2) from A(t) and W_lo(t)   | LDS: W_hi(t)               | DMA: W(t+2) -> the slot W(t-1) left
+//   mid-tile  every LDS read of tile t is done; A(t+1), W(t+1) have landed (W(t+2), just issued, may still fly)
+//   phase 1   MFMAs (i, j >= NJ/2) from A(t) and W_hi(t)   | LDS: A(t+1), W_lo(t+1)     | DMA: A(t+2) -> the slot A(t) left
+// A(t) is needed by both phases, so the A fragments are double-buffered in registers: 2 x MI x 8 (A) + NJ x 8 (W) = 192 arch VGPRs at
+// 8 x 8 beside the 256 accumulators.  Per wave and K-tile: 64 MFMAs of 32 cycles, 48 fragment reads (16 bytes), 16 DMA issues -- exactly one
+// memory instruction behind every MFMA of phase 1, one behind every second MFMA of phase 0.  A K-tile costs the matrix pipe what the bf16
+// kernel's costs and covers twice the k-values: the prologue / epilogue share of a tile's time doubles (K = 3072: 24 K-tiles).
+template <int MI, int NJ>
+__global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatch batch) {
+  constexpr int TM = 32 * MI, TN = 32 * NJ, KB = 128;          // K-tile: 128 fp8 values = 128 bytes per row
+  constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;
+  constexpr int NH = NJ / 2, NM = MI * NH;                     // column tiles / MFMAs per phase
+  constexpr int R0 = NJ, R1 = 2 * MI + NJ;                     // 16-byte fragment reads of phase 0 / phase 1
+  static_assert(NJ % 2 == 0 && 4 * MI * NJ <= 256 && 2 * NJ + R0 <= 2 * NM && MI + R1 <= NM, "v3f8 tile shape");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const smem_w = smem + 2 * A_SLOT;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  int wg = xcd_remap(blockIdx.x, (int)gridDim.x);
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < GEMM_MAX_PROBLEMS; ++i)
+    if (i < batch.nprob && wg >= batch.p[i].tile_start) pi = i;
+  const GemmProblem& Q = batch.p[pi];
+  wg -= Q.tile_start;
+  const int GM_ = batch.group_m;
+  const int per_group = GM_ * Q.tiles_n;
+  const int grp = wg / per_group;
+  const int first_m = grp * GM_;
+  const int gsz = min(Q.tiles_m - first_m, GM_);
+  const int in_grp = wg - grp * per_group;
+  const int m0 = (first_m + in_grp % gsz) * TM, n0 = (in_grp / gsz) * TN;
+  const int nk = Q.K / KB;
+  uint32_t aoff[MI], woff[NJ];
+  {
+    const int prow = tid >> 3;                                        // + 32 i
+    const int pc = ((tid & 7) ^ ((prow >> 1) & 7)) * 16;              // logical 16-byte chunk stored at physical chunk tid & 7
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      int ar = m0 + prow + 32 * i;
+      ar = ar < Q.M ? ar : Q.M - 1;
+      aoff[i] = (uint32_t)((int64_t)ar * Q.lda + pc);
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; ++i) {
+      int br = n0 + prow + 32 * i;
+      br = br < Q.N ? br : Q.N - 1;
+      woff[i] = (uint32_t)((int64_t)br * Q.ldw + pc);
+    }
+  }
+  const char* const abase = reinterpret_cast<const char*>(Q.A);
+  const char* const wbase = reinterpret_cast<const char*>(Q.W);
+  auto stage_a = [&](int t) {
+    t = t < nk ? t : nk - 1;
+    const char* src = abase + (int64_t)t * KB;
+    char* dst = smem + (t & 1) * A_SLOT;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + aoff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
+  };
+  auto stage_w = [&](int t) {
+    t = t < nk ? t : nk - 1;
+    const char* src = wbase + (int64_t)t * KB;
+    char* dst = smem_w + (t % 3) * W_SLOT;
+#pragma unroll
+    for (int i = 0; i < NJ; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + woff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
+  };
+
+  f32x4_t acc[MI][NJ];
+  const int frow = lane & 15, fq = lane >> 4;
+  const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
+  stage_a(0); stage_w(0); stage_w(1); stage_a(1);
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
+  __builtin_amdgcn_s_barrier();
+  // 32-byte operands: words 0..3 = chunk fq, words 4..7 = chunk 4 + fq of the lane's row
+  i32x8_t af[2][MI], bl[NH], bh[NH];
+  auto ld_half = [&](i32x8_t& f, int h, const char* tile, int row) {
+    const u32x4_t w = __builtin_bit_cast(u32x4_t, lds_frag(tile, row, 4 * h + fq));
+    f[4 * h + 0] = (int)w[0]; f[4 * h + 1] = (int)w[1]; f[4 * h + 2] = (int)w[2]; f[4 * h + 3] = (int)w[3];
+  };
+  // fragment read r of phase 1 (tile t+1's operands, in the order the next phase 0 needs them): W_lo first, then the A row tiles
+  auto read1 = [&](int r, i32x8_t (&an)[MI], const char* na, const char* nw) {
+    if (r < NJ) ld_half(bl[r >> 1], r & 1, nw, brow + (r >> 1) * 16);
+    else ld_half(an[(r - NJ) >> 1], (r - NJ) & 1, na, arow + ((r - NJ) >> 1) * 16);
+  };
+  // (the host pass parses this body too, and x86's "v" constraint does not take a 256-bit operand without AVX: the function would be dropped
+  // from the host object -- silently, as a deferred diagnostic -- and its launch stub with it)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define V3F8_ONE(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+#else
+#define V3F8_ONE(ACC, A_, B_) (void)(ACC)
+#endif
+  // One K-tile.  PAR: which A register set holds A(t) (the other one receives A(t+1)); MORE: tile t+2 exists -> issue its DMA.  Both are
+  // compile-time (a scalar branch around each DMA issue costs the lone wave ~30 cycles of instruction refetch).
+  auto tile = [&](auto PAR_, auto MORE_, int t) {
+    constexpr int par = decltype(PAR_)::value;
+    constexpr bool more = decltype(MORE_)::value;
+    const char* sw = smem_w + (t % 3) * W_SLOT;
+    // ---- phase 0: column tiles [0, NH); W_hi(t) streams in; W(t+2) -> slot (t+2) % 3 -----------------------------------------------
+    {
+      const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(t + 2) * KB));
+      char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        V3F8_ONE(acc[m / NH][m % NH], bl[m % NH], af[par][m / NH]);
+        V3_FENCE();
+        if ((m & 1) && (m >> 1) < R0) { const int r = m >> 1; ld_half(bh[r >> 1], r & 1, sw, brow + (NH + (r >> 1)) * 16); }
+        if (!(m & 1) && (m >> 1) < NJ && more) {
+          const int q = m >> 1;
+          V3_DMA(wsrc_u, woff[q], wdst + (q * V3_THREADS + wave * 64) * 16);
+        }
+        V3_FENCE();
+      }
+    }
+    if constexpr (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: column tiles [NH, NJ); A(t+1) and W_lo(t+1) stream in; A(t+2) -> slot t & 1 ------------------------------------
+    {
+      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + (int64_t)(t + 2) * KB));
+      char* adst = smem + (t & 1) * A_SLOT;
+      const char* na = smem + ((t + 1) & 1) * A_SLOT;
+      const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        V3F8_ONE(acc[m / NH][NH + m % NH], bh[m % NH], af[par][m / NH]);
+        V3_FENCE();
+        // one memory instruction per gap: DMA piece q behind MFMA 2 q, fragment reads behind the odd MFMAs and the even ones past the DMA
+        if (!(m & 1) && (m >> 1) < MI) {
+          const int q = m >> 1;
+          if constexpr (more) V3_DMA(asrc_u, aoff[q], adst + (q * V3_THREADS + wave * 64) * 16);
+        } else {
+          const int r = (m & 1) ? (m >> 1) : NM / 2 + ((m >> 1) - MI);
+          if (r < R1) read1(r, af[par ^ 1], na, nw);
+        }
+        V3_FENCE();
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  // A(t) lives in register set (t + nk) & 1, so the last two tiles are always (set 0, set 1); an odd tile count peels tile 0 (set 1)
+  int t = 0;
+  if (nk & 1) {
+#pragma unroll
+    for (int r = 0; r < R1; ++r) read1(r, af[1], smem, smem_w);
+    tile(I1{}, std::true_type{}, 0);
+    t = 1;
+  } else {
+#pragma unroll
+    for (int r = 0; r < R1; ++r) read1(r, af[0], smem, smem_w);
+  }
+#pragma unroll 1
+  for (; t < nk - 2; t += 2) {
+    tile(I0{}, std::true_type{}, t);
+    tile(I1{}, std::true_type{}, t + 1);
+  }
+  tile(I0{}, std::false_type{}, t);
+  tile(I1{}, std::false_type{}, t + 1);
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
+  {
+    int tid2 = threadIdx.x;
+    asm volatile("" : "+v"(tid2));
+    const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
+    const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
+    epi_store_fast_any<MI, NJ, true, true, false>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+  }
+}
+
 int& last_sk_cus() {           // CUs per XCD the last 8-phase launch split its tail over (0: plain launch) -- read by the stream-K tests
   static thread_local int v = 0;
   return v;
@@ -1707,6 +1890,42 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     return best == 0 ? launch_v3<8, 8>(batch, total, stream) : best == 1 ? launch_v3<9, 6>(batch, total, stream)
          : best == 2 ? launch_v3<10, 6>(batch, total, stream) : best == 3 ? launch_v3<4, 4>(batch, total, stream)
          : best == 4 ? launch_v3<8, 7>(batch, total, stream) : launch_v3<7, 8>(batch, total, stream);
+  }
+  // ---- fp8 launches with at least one full round of 256x256 tiles: the one-wave-per-SIMD fp8 kernel (AFX_FP8_V3=0: 8-phase kernel, A/B)
+  {
+    static int f8v3 = -1;
+    if (f8v3 < 0) {
+      const char* e = getenv("AFX_FP8_V3");
+      f8v3 = (e && e[0] == '0') ? 0 : 1;
+    }
+    bool ok = f8v3 != 0 && impl == 3 && sk_env == 0 && batch.sk_force == 0 && batch.nprob >= 1;
+    for (int i = 0; i < batch.nprob; ++i) {
+      const GemmProblem& p = batch.p[i];
+      ok = ok && p.fp8 != 0 && p.out_f32 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K % 128 == 0 && p.K >= 256 &&
+           p.qk_D == 0 && !p.w_perm16 && !p.bias_rows && p.split_k <= 1;
+    }
+    static int min_tiles = -1;
+    if (min_tiles < 0) {
+      const char* e = getenv("AFX_FP8_V3_MIN");      // fewest 256x256 tiles of a launch that takes this kernel
+      min_tiles = e ? atoi(e) : cus / 2;         // 216-tile launches (N = 3072): 2.1-2.2 -> 2.7 PF; below half a round the 8-phase kernel's 2 waves per SIMD win
+    }
+    if (ok && count_tiles(batch, 256, 256, false) >= min_tiles) {
+      const int total = count_tiles(batch, 256, 256, true);
+      batch.total_tiles = total;
+      batch.group_m = group_m_env ? group_m_env : GROUP_M;
+      batch.sk_cus = 0;
+      static bool attr = false;
+      if (!attr) {
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(8, 8));
+        if (r != hipSuccess) return r;
+        attr = true;
+      }
+      if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+        hipExtLaunchKernelGGL((gemm_kernel_v3f8<8, 8>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
+      else
+        hipLaunchKernelGGL((gemm_kernel_v3f8<8, 8>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, batch);
+      return hipGetLastError();
+    }
   }
   int total = count_tiles(batch, BM, BN, true);
   batch.total_tiles = total;

@@ -406,6 +406,35 @@ def test_fp8_quant_and_linear():
     assert rel(ops.linear_fp8(aq, asc, wq, wsc), a.float() @ w.float().t()) < 6e-2
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('K', [256, 1024, 1152, 3072])
+def test_fp8_linear_one_wave_kernel(K):
+    """Launches with a full round of 256x256 tiles run gemm_kernel_v3f8 (one wave per SIMD, column-split phases): ragged M / N, an even and an
+    odd number of K-tiles (the odd one peels a tile), every epilogue -- against the exact fp32 product of the dequantised operands."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N = 4645, 3640                                             # 19 x 15 tiles, both edges ragged
+    a = (torch.randn(M, K, generator=g) * 2.0).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    aq, asc = ops.quant_rows_fp8(a)
+    wq, wsc = ops.quant_rows_fp8(w)
+    ad = aq.view(torch.float8_e4m3fn).float() * asc[:, None]
+    wd = wq.view(torch.float8_e4m3fn).float() * wsc[:, None]
+    exact = ad @ wd.t()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    gate = torch.randn(N, generator=g).cuda()
+    rel = lambda x, y: ((x.float() - y).norm() / y.norm()).item()   # noqa: E731
+    y = ops.linear_fp8(aq, asc, wq, wsc, b)
+    assert rel(y, exact + b.float()) < 4e-3
+    assert (y.float() - (exact + b.float())).abs().max().item() < 0.02 * exact.abs().max().item() + 0.05     # no stray tile / row / column
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc, b, epilogue='gelu'), torch.nn.functional.gelu(exact + b.float(), approximate='tanh')) < 5e-3
+    assert rel(ops.linear_fp8(aq, asc, wq, wsc, b, epilogue='gate_res', gate=gate, residual=r), r.float() + gate * (exact + b.float())) < 4e-3
+    out = torch.full((M + 1, N + 8), 7.0, dtype=torch.bfloat16, device='cuda')        # strided output view: nothing written outside it
+    ops.linear_fp8(aq, asc, wq, wsc, b, out=out[:M, :N])
+    assert rel(out[:M, :N], exact + b.float()) < 4e-3 and (out[M] == 7).all() and (out[:, N:] == 7).all()
+
+
 # ------------------------------------------------------------------------------------------ stream-K tail of the GEMM
 @pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 3072, 15360), (4608, 9216, 3072), (4608, 12288, 3072),
                                    (2048, 1024, 512), (4608, 21504, 3072)])

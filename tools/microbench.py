@@ -44,7 +44,8 @@ def gemm():
 
 def gemm8():
     print('--- fp8 (e4m3, row-wise scales) linear vs the bf16 kernel')
-    for M, N, K in [(4608, 9216, 3072), (4608, 21504, 3072), (4608, 3072, 15360), (4608, 12288, 3072), (8192, 8192, 8192)]:
+    for M, N, K in [(4608, 9216, 3072), (4608, 21504, 3072), (4608, 3072, 15360), (4608, 12288, 3072), (4608, 3072, 3072), (4608, 3072, 12288),
+                    (9216, 3072, 3072), (9216, 9216, 3072), (8192, 8192, 8192)]:
         a = torch.randn(M, K, device='cuda').bfloat16()
         w = (torch.randn(N, K, device='cuda') * 0.02).bfloat16()
         out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
