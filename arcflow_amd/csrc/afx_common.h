@@ -55,6 +55,26 @@ AFX_DEV u32x4_t pack8(const float (&f)[8]) {
   return w;
 }
 
+// ---- block-scaled fp8 (MX layout, E8M0 scale bytes; afx_text.hip quant_rows_mx8_kernel and the fused producers) -------------------------
+// biased exponent b of the power-of-two scale of a block with absolute maximum amax: the smallest 2^(b - 127) with amax <= 448 * 2^(b - 127)
+AFX_DEV int mx_exp(float amax) {
+  const uint32_t u = __float_as_uint(amax * (1.0f / 448.0f));
+  const int b = (int)((u >> 23) & 0xffu) + ((u & 0x7fffffu) != 0u ? 1 : 0);
+  return min(max(b, 1), 254);
+}
+AFX_DEV float mx_inv(int b) { return __uint_as_float((uint32_t)(254 - b) << 23); }      // 2^(127 - b)
+AFX_DEV void mx_pack8(const float (&v)[8], float inv, uint32_t& w0, uint32_t& w1) {     // 8 values -> 8 e4m3 bytes (saturating)
+  float t[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) t[e] = __builtin_amdgcn_fmed3f(v[e] * inv, 448.0f, -448.0f);
+  int a = 0, b = 0;
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(t[0], t[1], a, false);
+  a = __builtin_amdgcn_cvt_pk_fp8_f32(t[2], t[3], a, true);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(t[4], t[5], b, false);
+  b = __builtin_amdgcn_cvt_pk_fp8_f32(t[6], t[7], b, true);
+  w0 = (uint32_t)a; w1 = (uint32_t)b;
+}
+
 AFX_DEV float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

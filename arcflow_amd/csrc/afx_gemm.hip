@@ -1474,6 +1474,73 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   }
 }
 
+// fp8 GEMM -> block-scaled fp8 output (GemmProblem::c8): a wave's 128 columns are ONE block of the next GEMM's A operand.  Per row tile: the
+// 32 values a lane owns (4 steps x 8 columns after the permlane exchange) are finished in fp32 (scales, bias, GELU), their absolute maximum
+// is combined over the 4 lanes of the row (two cross-lane exchanges), and the row's 128 values leave as e4m3 bytes (8 per lane and step)
+// with one E8M0 byte.  Half the store traffic of the bf16 epilogue and no quantisation pass behind it.
+template <bool GELU, int MI, int NJ>
+AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+  static_assert(NJ == 8, "one wave = 128 columns = one scale block");
+  constexpr int NS = NJ / 2;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int M = P.M, N = P.N;
+  if (col_base >= N) return;                         // (uniform) a wave past the last column owns no block: its scale byte would land in the next row
+  const int rows_ok = min(max(M - row_base, 0), MI * 16);
+  const int64_t ldc8 = P.ldc8;
+  __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.c8 + (int64_t)row_base * ldc8, (int)(rows_ok * ldc8));
+  __amdgpu_buffer_rsrc_t rm = uniform_rsrc(P.c_mx + (int64_t)row_base * P.ld_cmx, (int)(rows_ok * P.ld_cmx));
+  __amdgpu_buffer_rsrc_t ra = uniform_rsrc(const_cast<float*>(P.a_scale) + row_base, rows_ok * 4);
+  const int blk = (col_base - P.c8_col0) >> 7;
+  uint32_t coff[NS];
+  float bias[NS][8], wsc[NS][8];
+#pragma unroll
+  for (int st = 0; st < NS; ++st) {
+    const int gcol = col_base + (2 * st + (fq & 1)) * 16 + (fq >> 1) * 8;
+    const bool col_ok = gcol < N;
+    coff[st] = col_ok ? (uint32_t)(gcol - P.c8_col0) : OOB;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias[st][e] = 0.f; wsc[st][e] = col_ok ? P.w_scale[gcol + e] : 0.f; }
+    if (P.bias != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(P.bias + gcol), bias[st]);
+  }
+  float asc_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, frow * 4, 0, 0));
+#pragma unroll
+  for (int ii = 0; ii < MI; ++ii) {
+    const float asc = asc_n;
+    if (ii + 1 < MI) asc_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, ((ii + 1) * 16 + frow) * 4, 0, 0));
+    float v[NS][8];
+    float amax = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        v[st][e] = __uint_as_float(sw[0]);
+        v[st][4 + e] = __uint_as_float(sw[1]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = v[st][e] * (asc * wsc[st][e]) + bias[st][e];
+        if constexpr (GELU) x = gelu_tanh(x);
+        x = coff[st] != OOB ? x : 0.f;
+        v[st][e] = x;
+        amax = fmaxf(amax, fabsf(x));
+      }
+    }
+    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+    const int eb = mx_exp(amax);
+    const float inv = mx_inv(eb);
+    const uint32_t roff = (uint32_t)((ii * 16 + frow) * (int)ldc8);
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+      uint32_t w0, w1;
+      mx_pack8(v[st], inv, w0, w1);
+      __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){w0, w1}, rc, (int)(roff + coff[st]), 0, 0);
+    }
+    if (fq == 0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)eb, rm, (ii * 16 + frow) * (int)P.ld_cmx + blk, 0, 0);
+  }
+}
+
 // =================================================================================================
 // v3 / fp8: the one-wave-per-SIMD kernel for OCP e4m3 operands (v_mfma_f32_16x16x128_f8f6f4: 2x the bf16 rate).  LDS rings, DMA stream,
 // swizzle and the ONE mid-tile barrier are gemm_kernel_v3's -- a 128-byte LDS row is now 128 k-values, so a K-tile is a single MFMA per
@@ -1486,7 +1553,15 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 // 8 x 8 beside the 256 accumulators.  Per wave and K-tile: 64 MFMAs of 32 cycles, 48 fragment reads (16 bytes), 16 DMA issues -- exactly one
 // memory instruction behind every MFMA of phase 1, one behind every second MFMA of phase 0.  A K-tile costs the matrix pipe what the bf16
 // kernel's costs and covers twice the k-values: the prologue / epilogue share of a tile's time doubles (K = 3072: 24 K-tiles).
-template <int MI, int NJ>
+//
+// MX: the activation operand carries BLOCK scales instead of one fp32 scale per row (GemmProblem::a_mx: one E8M0 byte per row and K-tile,
+// i.e. per 128 k-values -- the MX layout with the block = this kernel's K-tile).  The matrix pipe applies them for free
+// (v_mfma_scale_f32_16x16x128_f8f6f4: the four k-groups of a lane row take the same byte), so a PRODUCER can quantise the 128 columns it
+// holds without ever seeing the whole row (GELU / attention epilogues, LayerNorm-modulate), and no separate quantisation pass is left.
+// A lane fetches the bytes of 4 K-tiles of its MI row tiles as one dword each (8 buffer loads per 4 tiles, issued behind the A DMA of
+// the group's second tile: in-order retirement makes the next mid-tile wait cover them); the byte is picked by op_sel, so the loop is
+// unrolled over the 4 tiles of a group.  K % 512 == 0.
+template <int MI, int NJ, bool MX = false>
 __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ, KB = 128;          // K-tile: 128 fp8 values = 128 bytes per row
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;
@@ -1553,6 +1628,30 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   f32x4_t acc[MI][NJ];
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
+  // ---- MX: scale bytes of this lane's MI row tiles, 4 K-tiles per dword --------------------------------------------------------
+  const int mx_one = 0x7f7f7f7f;
+  uint32_t sc_cur[MX ? MI : 1], sc_nxt[MX ? MI : 1];
+  u32x4_t mx_rsrc = (u32x4_t){0u, 0u, 0u, 0u};
+  uint32_t mx_voff = 0;
+  int mx_step = 0;                                   // bytes between two row tiles of a lane
+  if constexpr (MX) {
+    const uint64_t base = (uint64_t)(uintptr_t)Q.a_mx;
+    mx_rsrc[0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)base);
+    mx_rsrc[1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(base >> 32));
+    mx_rsrc[2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)((int64_t)Q.M * Q.ld_mx));      // rows past M read as zero (their products are never stored)
+    mx_rsrc[3] = 0x00020000u;
+    mx_voff = (uint32_t)((m0 + wr * (16 * MI) + frow) * (int)Q.ld_mx);
+    mx_step = __builtin_amdgcn_readfirstlane(16 * (int)Q.ld_mx);
+  }
+  // group g = K-tiles 4 g .. 4 g + 3; hand-waited (the compiler does not count the LDS-DMA issues of the asm statements around them)
+  auto mx_fetch = [&](uint32_t (&dst)[MX ? MI : 1], int g) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(dst[i]) : "v"(mx_voff), "s"(mx_rsrc), "s"(i * mx_step + 4 * g) : "memory");
+    }
+  };
+  if constexpr (MX) mx_fetch(sc_nxt, 0);          // in front of the prologue's DMA: the wait for A(0) / W(0) below covers them
   stage_a(0); stage_w(0); stage_w(1); stage_a(1);
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -1575,14 +1674,26 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   // from the host object -- silently, as a deferred diagnostic -- and its launch stub with it)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define V3F8_ONE(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+  // scaled form: src A = the weight fragment (scale 2^0: byte 0 of `one`), src B = the activation fragment, its scale = byte BT of SC
+#define V3F8_SC(ACC, A_, B_, SC, OPS) \
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS : "+a"(ACC) : "v"(A_), "v"(B_), "v"(mx_one), "v"(SC))
 #else
 #define V3F8_ONE(ACC, A_, B_) (void)(ACC)
+#define V3F8_SC(ACC, A_, B_, SC, OPS) (void)(ACC)
 #endif
+#define V3F8_MFMA(BT, ACC, A_, B_, SC)                                                        \
+  if constexpr (!MX) V3F8_ONE(ACC, A_, B_);                                                   \
+  else if constexpr ((BT) == 0) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,0,0]"); \
+  else if constexpr ((BT) == 1) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,0,0]"); \
+  else if constexpr ((BT) == 2) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,1,0]"); \
+  else V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,1,0]")
   // One K-tile.  PAR: which A register set holds A(t) (the other one receives A(t+1)); MORE: tile t+2 exists -> issue its DMA.  Both are
   // compile-time (a scalar branch around each DMA issue costs the lone wave ~30 cycles of instruction refetch).
-  auto tile = [&](auto PAR_, auto MORE_, int t) {
+  auto tile = [&](auto PAR_, auto MORE_, int t, auto BT_, auto FETCH_) {
     constexpr int par = decltype(PAR_)::value;
     constexpr bool more = decltype(MORE_)::value;
+    constexpr int bt = decltype(BT_)::value;            // MX: byte of the scale dwords = tile index inside its group of 4
+    constexpr bool fetch = decltype(FETCH_)::value;     // MX: request the next group's scale dwords behind this tile's A DMA
     const char* sw = smem_w + (t % 3) * W_SLOT;
     // ---- phase 0: column tiles [0, NH); W_hi(t) streams in; W(t+2) -> slot (t+2) % 3 -----------------------------------------------
     {
@@ -1590,7 +1701,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
       char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        V3F8_ONE(acc[m / NH][m % NH], bl[m % NH], af[par][m / NH]);
+        V3F8_MFMA(bt, acc[m / NH][m % NH], bl[m % NH], af[par][m / NH], sc_cur[MX ? m / NH : 0]);
         V3_FENCE();
         if ((m & 1) && (m >> 1) < R0) { const int r = m >> 1; ld_half(bh[r >> 1], r & 1, sw, brow + (NH + (r >> 1)) * 16); }
         if (!(m & 1) && (m >> 1) < NJ && more) {
@@ -1611,7 +1722,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
       const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        V3F8_ONE(acc[m / NH][NH + m % NH], bh[m % NH], af[par][m / NH]);
+        V3F8_MFMA(bt, acc[m / NH][NH + m % NH], bh[m % NH], af[par][m / NH], sc_cur[MX ? m / NH : 0]);
         V3_FENCE();
         // one memory instruction per gap: DMA piece q behind MFMA 2 q, fragment reads behind the odd MFMAs and the even ones past the DMA
         if (!(m & 1) && (m >> 1) < MI) {
@@ -1623,16 +1734,43 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
         }
         V3_FENCE();
       }
+      if constexpr (fetch) mx_fetch(sc_nxt, (t >> 2) + 1);
     }
   };
   using I0 = std::integral_constant<int, 0>;
   using I1 = std::integral_constant<int, 1>;
-  // A(t) lives in register set (t + nk) & 1, so the last two tiles are always (set 0, set 1); an odd tile count peels tile 0 (set 1)
+  using I2 = std::integral_constant<int, 2>;
+  using I3 = std::integral_constant<int, 3>;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
   int t = 0;
+  if constexpr (MX) {
+    // nk = 4 G tiles, A(t) in register set t & 1; the first group's scales were requested in front of the prologue's DMA
+#pragma unroll
+    for (int r = 0; r < R1; ++r) read1(r, af[0], smem, smem_w);
+    auto take = [&]() {      // sc_cur <- sc_nxt (asm: the copies must not float above the wait that makes the loads' data valid)
+#pragma unroll
+      for (int i = 0; i < MI; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(sc_cur[i]) : "v"(sc_nxt[i]));
+    };
+    take();
+#pragma unroll 1
+    for (; t < nk - 4; t += 4) {
+      tile(I0{}, T_{}, t, I0{}, F_{});
+      tile(I1{}, T_{}, t + 1, I1{}, T_{});
+      tile(I0{}, T_{}, t + 2, I2{}, F_{});            // its mid-tile wait leaves only W(t+4) in flight: the scale dwords have landed
+      tile(I1{}, T_{}, t + 3, I3{}, F_{});
+      take();
+    }
+    tile(I0{}, T_{}, t, I0{}, F_{});
+    tile(I1{}, T_{}, t + 1, I1{}, F_{});
+    tile(I0{}, F_{}, t + 2, I2{}, F_{});
+    tile(I1{}, F_{}, t + 3, I3{}, F_{});
+  } else {
+  // A(t) lives in register set (t + nk) & 1, so the last two tiles are always (set 0, set 1); an odd tile count peels tile 0 (set 1)
   if (nk & 1) {
 #pragma unroll
     for (int r = 0; r < R1; ++r) read1(r, af[1], smem, smem_w);
-    tile(I1{}, std::true_type{}, 0);
+    tile(I1{}, T_{}, 0, I0{}, F_{});
     t = 1;
   } else {
 #pragma unroll
@@ -1640,17 +1778,22 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   }
 #pragma unroll 1
   for (; t < nk - 2; t += 2) {
-    tile(I0{}, std::true_type{}, t);
-    tile(I1{}, std::true_type{}, t + 1);
+    tile(I0{}, T_{}, t, I0{}, F_{});
+    tile(I1{}, T_{}, t + 1, I0{}, F_{});
   }
-  tile(I0{}, std::false_type{}, t);
-  tile(I1{}, std::false_type{}, t + 1);
+  tile(I0{}, F_{}, t, I0{}, F_{});
+  tile(I1{}, F_{}, t + 1, I0{}, F_{});
+  }
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
   {
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
+    if (Q.c8 != nullptr && n0 + wc2 * (16 * NJ) >= Q.c8_col0) {       // (uniform) this wave's 128 columns go out as the next GEMM's block-scaled operand
+      if (Q.epi == EPI_GELU) epi_store_mx8<true, MI, NJ>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      else epi_store_mx8<false, MI, NJ>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+    } else
     epi_store_fast_any<MI, NJ, true, true, false>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
   }
 }
@@ -1757,6 +1900,14 @@ static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
     if (gemm_persist() == 2 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
   }
   return launch_v3_impl<MI, NJ, CONV, 0>(batch, total, stream);
+}
+
+bool gemm_fp8_mx_ok(int64_t rows_total, int N, int K) {
+  (void)rows_total; (void)N;                       // a block-scaled launch always takes the one-wave-per-SIMD kernel, whatever its tile count
+  const char* e = getenv("AFX_FP8_V3");
+  const char* k = getenv("AFX_GEMM_SK");
+  const char* m = getenv("AFX_GEMM_IMPL");
+  return !(e && e[0] == '0') && !(k && atoi(k) != 0) && !(m && (m[0] == '1' || m[0] == '2')) && K % 512 == 0 && K >= 512;
 }
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
@@ -1899,31 +2050,45 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
       f8v3 = (e && e[0] == '0') ? 0 : 1;
     }
     bool ok = f8v3 != 0 && impl == 3 && sk_env == 0 && batch.sk_force == 0 && batch.nprob >= 1;
+    bool mx_any = false, mx_all = true, c8_any = false;
     for (int i = 0; i < batch.nprob; ++i) {
       const GemmProblem& p = batch.p[i];
       ok = ok && p.fp8 != 0 && p.out_f32 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K % 128 == 0 && p.K >= 256 &&
            p.qk_D == 0 && !p.w_perm16 && !p.bias_rows && p.split_k <= 1;
+      mx_any = mx_any || p.a_mx != nullptr;
+      if (p.c8 != nullptr && (p.epi == EPI_GATE_RES || p.c8_col0 % 128 || !p.c_mx || p.ldc8 % 8 || (p.gelu_col0 != 0 && p.gelu_col0 != p.c8_col0))) return hipErrorInvalidValue;
+      c8_any = c8_any || p.c8 != nullptr;
+      mx_all = mx_all && p.a_mx != nullptr && p.K % 512 == 0 && p.ld_mx % 4 == 0;
     }
     static int min_tiles = -1;
     if (min_tiles < 0) {
       const char* e = getenv("AFX_FP8_V3_MIN");      // fewest 256x256 tiles of a launch that takes this kernel
       min_tiles = e ? atoi(e) : cus / 2;         // 216-tile launches (N = 3072): 2.1-2.2 -> 2.7 PF; below half a round the 8-phase kernel's 2 waves per SIMD win
     }
-    if (ok && count_tiles(batch, 256, 256, false) >= min_tiles) {
+    if (mx_any && !(ok && mx_all)) return hipErrorInvalidValue;      // block scales are this kernel's format only (callers ask gemm_fp8_mx_ok() first)
+    if (c8_any && !ok) return hipErrorInvalidValue;
+    if (ok && (mx_any || c8_any || count_tiles(batch, 256, 256, false) >= min_tiles)) {
       const int total = count_tiles(batch, 256, 256, true);
       batch.total_tiles = total;
+      if (total == 0) return hipSuccess;
       batch.group_m = group_m_env ? group_m_env : GROUP_M;
       batch.sk_cus = 0;
       static bool attr = false;
       if (!attr) {
-        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<8, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(8, 8));
+        hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<8, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(8, 8));
+        if (r != hipSuccess) return r;
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(8, 8));
         if (r != hipSuccess) return r;
         attr = true;
       }
-      if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
-        hipExtLaunchKernelGGL((gemm_kernel_v3f8<8, 8>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
-      else
-        hipLaunchKernelGGL((gemm_kernel_v3f8<8, 8>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, batch);
+      const bool timed = launch_timer().start != nullptr && launch_timer().stop != nullptr;
+      if (mx_any) {
+        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v3f8<8, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
+        else hipLaunchKernelGGL((gemm_kernel_v3f8<8, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, batch);
+      } else {
+        if (timed) hipExtLaunchKernelGGL((gemm_kernel_v3f8<8, 8, false>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
+        else hipLaunchKernelGGL((gemm_kernel_v3f8<8, 8, false>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, batch);
+      }
       return hipGetLastError();
     }
   }

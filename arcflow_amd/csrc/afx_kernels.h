@@ -27,6 +27,18 @@ struct GemmProblem {
   int32_t fp8;          // 1: A and W hold OCP e4m3 bytes (lda/ldw/K in elements = bytes, K % 128 == 0); the product is scaled by
   const float* a_scale; //    a_scale[m] * w_scale[n] (per-row activation scale, per-output-channel weight scale) before the epilogue
   const float* w_scale;
+  // fp8 with BLOCK-scaled activations (the one-wave-per-SIMD fp8 kernel only; gemm_fp8_mx_ok()): a_mx[m][t] = the E8M0 byte (2^(b - 127)) of
+  // row m's K-tile t = its k-values 128 t .. 128 t + 127 (row stride ld_mx bytes, a multiple of 4; K % 512 == 0).  a_scale still multiplies
+  // the row (pass ones); afx_quant_rows_mx8 / the fused producers write this layout.
+  const uint8_t* a_mx;
+  int64_t ld_mx;
+  // ... and the PRODUCER side of that layout (same kernel; epi EPI_NONE / EPI_GELU only): the columns from c8_col0 on (a multiple of 128) are
+  // not stored to C as bf16 but to c8[m][n - c8_col0] as e4m3 bytes with one scale byte per row and 128 columns in c_mx[m][(n - c8_col0) / 128]
+  // -- the next GEMM's A operand straight out of this one's epilogue (mlp hidden, the mlp part of the single blocks' [O | mlp] operand).
+  uint8_t* c8;
+  uint8_t* c_mx;
+  int64_t ldc8, ld_cmx;
+  int32_t c8_col0;
   // Fused q / k preparation of a k|v|q(|mlp) projection (one-wave-per-SIMD kernel, 256x256 tile only; gemm_qk_fusion_available()):
   // columns [0, qk_D) are keys, [2 qk_D, 3 qk_D) queries -- every 128-column head of those two ranges leaves the epilogue as
   // RoPE(RMSNorm_128(x + bias) * w) (diffusers FluxAttnProcessor order: norm_q / norm_k, then apply_rotary_emb on interleaved
@@ -115,6 +127,8 @@ inline int64_t attn_spad(int S) { return ((int64_t)S + 63) / 64 * 64; }
 
 // row-wise OCP e4m3 quantisation (afx_text.hip): q = round(x / scale[r]), scale[r] = absmax(row) / 448
 hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int K, hipStream_t stream);
+hipError_t launch_quant_rows_mx8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* mx, int64_t ld_mx, int rows, int K, hipStream_t stream);
+bool gemm_fp8_mx_ok(int64_t rows_total, int N, int K);      // would an fp8 launch of this size take the block-scaled kernel?
 
 // ---- element-wise / reductions -----------------------------------------------------------------
 hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows,

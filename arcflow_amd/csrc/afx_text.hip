@@ -182,6 +182,39 @@ __global__ __launch_bounds__(256) void finish_f32_kernel(const float* __restrict
   *reinterpret_cast<u32x4_t*>(out + m * ldo + c * 8) = pack8(v);
 }
 
+// Block-scaled fp8 (OCP e4m3 values, one E8M0 scale byte per row and 128 columns -- the MX layout with the block = one K-tile of the fp8
+// GEMM): byte b = 127 + ceil(log2(absmax(block) / 448)), q = round(x * 2^(127 - b)).  A block never sees another block's outlier, and a
+// producer can emit the format from the 128 columns it holds (afx_common.h mx_exp / mx_inv: the same arithmetic in the fused epilogues).
+// Thread = 8 columns, 16 consecutive lanes = one block.
+__global__ __launch_bounds__(256) void quant_rows_mx8_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
+                                                             uint8_t* __restrict__ mx, int64_t ld_mx, int64_t rows, int K) {
+  const int cpr = K >> 3;
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = g < rows * cpr;                 // (whole 16-lane groups: cpr % 16 == 0)
+  const int64_t row = live ? g / cpr : 0;
+  const int c = live ? (int)(g - row * cpr) : 0;
+  float v[8];
+  unpack8(*reinterpret_cast<const u32x4_t*>(x + row * ldx + c * 8), v);
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const int eb = mx_exp(amax);
+  const float inv = mx_inv(eb);
+  if (!live) return;
+  uint32_t w0, w1;
+  mx_pack8(v, inv, w0, w1);
+  *reinterpret_cast<u32x2_t*>(q + row * ldq + c * 8) = (u32x2_t){w0, w1};
+  if ((c & 15) == 0) mx[row * ld_mx + (c >> 4)] = (uint8_t)eb;
+}
+
+hipError_t launch_quant_rows_mx8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, uint8_t* mx, int64_t ld_mx, int rows, int K, hipStream_t stream) {
+  const int64_t n = (int64_t)rows * (K >> 3);
+  hipLaunchKernelGGL(quant_rows_mx8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, ldx, q, ldq, mx, ld_mx, (int64_t)rows, K);
+  return hipGetLastError();
+}
+
 hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int K, hipStream_t stream) {
   hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
   return hipGetLastError();
@@ -253,6 +286,54 @@ int afx_linear_fp8(const void* Aq, int64_t lda, const float* a_scale, const void
   p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
   p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
   p.fp8 = 1; p.a_scale = a_scale; p.w_scale = w_scale;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_quant_rows_mx8(const void* x, int64_t ldx, void* q, int64_t ldq, void* mx, int64_t ld_mx, int32_t rows, int32_t K, void* stream) {
+  if (!x || !q || !mx || rows < 1 || K < 128 || K % 128 || ldx % 8 || ldq % 8 || ld_mx < K / 128)
+    return fail(AFX_E_INVALID, "afx_quant_rows_mx8: need K %% 128 == 0, ldx / ldq %% 8 == 0, ld_mx >= K / 128");
+  HIP_TRY(launch_quant_rows_mx8((const uint16_t*)x, ldx, (uint8_t*)q, ldq, (uint8_t*)mx, ld_mx, rows, K, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_linear_fp8_mx(const void* Aq, int64_t lda, const void* a_mx, int64_t ld_mx, const float* a_scale, const void* Wq, int64_t ldw,
+                      const float* w_scale, const void* bias, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
+                      int32_t gelu_col0, const float* gate, int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, void* stream) {
+  if (!Aq || !a_mx || !Wq || !C || !a_scale || !w_scale) return fail(AFX_E_INVALID, "null argument to afx_linear_fp8_mx");
+  if (M < 0 || N < 0 || K < 512 || K % 512 || N % 8 || lda % 16 || ldw % 16 || ldc % 8 || ld_mx % 4 || ld_mx < K / 128 || epi < 0 || epi > 2)
+    return fail(AFX_E_INVALID, "afx_linear_fp8_mx: need K%%512==0, N%%8==0, lda/ldw%%16==0, ldc%%8==0, ld_mx%%4==0");
+  if (epi == EPI_GATE_RES && (!res || ldr % 8 || (gate && rows_per_batch < 1))) return fail(AFX_E_INVALID, "gated residual epilogue needs res");
+  if (!gemm_fp8_mx_ok(M, N, K)) return fail(AFX_E_INVALID, "afx_linear_fp8_mx: the block-scaled kernel is switched off (AFX_FP8_V3 / AFX_GEMM_IMPL / AFX_GEMM_SK)");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)Aq; p.lda = lda; p.W = (const uint16_t*)Wq; p.ldw = ldw; p.bias = (const uint16_t*)bias;
+  p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = epi; p.gelu_col0 = gelu_col0;
+  p.gate = gate; p.ldg = ldg; p.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; p.res = (const uint16_t*)res; p.ldr = ldr;
+  p.fp8 = 1; p.a_scale = a_scale; p.w_scale = w_scale; p.a_mx = (const uint8_t*)a_mx; p.ld_mx = ld_mx;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
+int afx_linear_fp8_to_mx8(const void* Aq, int64_t lda, const void* a_mx, int64_t ld_mx, const float* a_scale, const void* Wq, int64_t ldw,
+                          const float* w_scale, const void* bias, void* C, int64_t ldc, void* c8, int64_t ldc8, void* c_mx, int64_t ld_cmx,
+                          int32_t c8_col0, int32_t M, int32_t N, int32_t K, int32_t gelu, void* stream) {
+  if (!Aq || !Wq || !c8 || !c_mx || !a_scale || !w_scale || (c8_col0 > 0 && !C)) return fail(AFX_E_INVALID, "null argument to afx_linear_fp8_to_mx8");
+  if (M < 0 || N < 0 || K < 256 || K % 128 || N % 8 || lda % 16 || ldw % 16 || ldc % 8 || ldc8 % 8 || c8_col0 < 0 || c8_col0 % 128 || c8_col0 >= N ||
+      ld_cmx < (N - c8_col0 + 127) / 128 || (a_mx && (K % 512 || ld_mx % 4 || ld_mx < K / 128)))
+    return fail(AFX_E_INVALID, "afx_linear_fp8_to_mx8: need K%%128==0 (K%%512==0 with block-scaled A), c8_col0%%128==0, ldc8%%8==0");
+  if (!gemm_fp8_mx_ok(M, N, a_mx ? K : 512)) return fail(AFX_E_INVALID, "afx_linear_fp8_to_mx8: the one-wave-per-SIMD fp8 kernel is switched off");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& p = gb.p[0];
+  p = GemmProblem{};
+  p.A = (const uint16_t*)Aq; p.lda = lda; p.W = (const uint16_t*)Wq; p.ldw = ldw; p.bias = (const uint16_t*)bias;
+  p.C = (uint16_t*)C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.epi = gelu ? EPI_GELU : EPI_NONE; p.gelu_col0 = gelu ? c8_col0 : 0;
+  p.rows_per_batch = 1;
+  p.fp8 = 1; p.a_scale = a_scale; p.w_scale = w_scale; p.a_mx = (const uint8_t*)a_mx; p.ld_mx = ld_mx;
+  p.c8 = (uint8_t*)c8; p.ldc8 = ldc8; p.c_mx = (uint8_t*)c_mx; p.ld_cmx = ld_cmx; p.c8_col0 = c8_col0;
   HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
   return AFX_OK;
 }

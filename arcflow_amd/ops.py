@@ -320,6 +320,60 @@ def linear_fp8(aq, a_scale, wq, w_scale, bias=None, epilogue: str = 'none', gelu
     return out
 
 
+def quant_rows_mx8(x: torch.Tensor):
+    """bf16 [M,K] -> (q uint8 [M,K] OCP e4m3, mx uint8 [M, K/128] E8M0): block-scaled fp8, one power-of-two scale per row and 128 columns
+    (q = round(x * 2^(127 - mx)), the smallest scale that keeps the block inside +-448)."""
+    lib = _lib.load()
+    M, K = x.shape
+    q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    nb = K // 128
+    mx = torch.empty(M, (nb + 3) // 4 * 4, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.afx_quant_rows_mx8(_p(x), x.stride(0), _p(q), K, _p(mx), mx.stride(0), M, K, _s()))
+    return q, mx[:, :nb]
+
+
+def linear_fp8_mx(aq, a_mx, wq, w_scale, bias=None, epilogue: str = 'none', gelu_col0: int = 0, gate=None, residual=None,
+                  rows_per_batch: int = 0, out=None, a_scale=None):
+    """bf16 out = epi(w_scale[n] (sum over K-tiles t of 2^(a_mx[m, t] - 127) aq[m, t] . wq[n, t]) + bias): the fp8 GEMM on block-scaled
+    activations (``quant_rows_mx8`` / the fused producers).  K % 512 == 0."""
+    lib = _lib.load()
+    M, K = aq.shape
+    N = wq.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=aq.device)
+    if a_scale is None:
+        a_scale = torch.ones(M, dtype=torch.float32, device=aq.device)
+    epi = {'none': 0, 'gelu': 1, 'gate_res': 2}[epilogue]
+    if gate is not None:
+        gate = _cuda(gate, torch.float32)
+        if gate.dim() == 1:
+            gate = gate[None]
+    rpb = rows_per_batch if rows_per_batch > 0 else max(M, 1)
+    _lib.check(lib.afx_linear_fp8_mx(_p(aq), aq.stride(0), _p(a_mx), a_mx.stride(0), _p(a_scale), _p(wq), wq.stride(0), _p(w_scale), _p(bias),
+                                     _p(out), out.stride(0), M, N, K, epi, gelu_col0, _p(gate), 0 if gate is None else gate.stride(0), rpb,
+                                     _p(residual), 0 if residual is None else residual.stride(0), _s()))
+    return out
+
+
+def linear_fp8_to_mx8(aq, a_mx, wq, w_scale, bias=None, gelu: bool = False, c8_col0: int = 0, a_scale=None):
+    """The fp8 GEMM whose epilogue writes the next GEMM's block-scaled operand: returns (bf16 [M, c8_col0] or None, q uint8 [M, N - c8_col0],
+    mx uint8 [M, (N - c8_col0) / 128]).  a_mx None: per-row ``a_scale`` only."""
+    lib = _lib.load()
+    M, K = aq.shape
+    N = wq.shape[0]
+    n8 = N - c8_col0
+    nb = (n8 + 127) // 128
+    head = torch.empty(M, c8_col0, dtype=torch.bfloat16, device=aq.device) if c8_col0 > 0 else None
+    q = torch.empty(M, n8, dtype=torch.uint8, device=aq.device)
+    mx = torch.empty(M, (nb + 3) // 4 * 4, dtype=torch.uint8, device=aq.device)
+    if a_scale is None:
+        a_scale = torch.ones(M, dtype=torch.float32, device=aq.device)
+    _lib.check(lib.afx_linear_fp8_to_mx8(_p(aq), aq.stride(0), _p(a_mx), 0 if a_mx is None else a_mx.stride(0), _p(a_scale), _p(wq), wq.stride(0),
+                                         _p(w_scale), _p(bias), _p(head), c8_col0 if head is not None else 8, _p(q), n8, _p(mx), mx.stride(0),
+                                         c8_col0, M, N, K, int(gelu), _s()))
+    return head, q, mx[:, :nb]
+
+
 def linear_splitk(a, w, bias=None, residual=None, out=None, split_k: int = 0):
     """bf16 out = a @ w.T (+ bias) (+ residual) for few-row operands: split-K GEMM into per-chunk fp32 partial slabs, then one
     summing / converting pass.  Fills the chip when M x N alone gives only a handful of 256x256 tiles."""

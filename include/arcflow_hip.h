@@ -347,6 +347,22 @@ int afx_quant_rows_fp8(const void* x, int64_t ldx, void* q, int64_t ldq, float* 
 int afx_linear_fp8(const void* Aq, int64_t lda, const float* a_scale, const void* Wq, int64_t ldw, const float* w_scale, const void* bias,
                    void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate, int64_t ldg,
                    int32_t rows_per_batch, const void* res, int64_t ldr, void* stream);
+/* Block-scaled activations (the MX layout with 128-value blocks = one K-tile of the one-wave-per-SIMD fp8 kernel): mx[r][j] = E8M0 byte b,
+ * scale 2^(b - 127) = the smallest power of two with absmax(x[r, 128 j .. 128 j + 127]) <= 448 * scale; q = round(x / scale), e4m3.
+ * afx_linear_fp8_mx consumes it (the matrix instruction applies the block scales); a_scale[m] still multiplies row m (pass ones),
+ * weights keep their per-output-channel fp32 scales.  K % 512 == 0, ld_mx % 4 == 0.  No reference counterpart (the reference has no
+ * fp8 path): the format exists so that GEMM / attention / LayerNorm epilogues can quantise the 128 columns they hold. */
+int afx_quant_rows_mx8(const void* x, int64_t ldx, void* q, int64_t ldq, void* mx, int64_t ld_mx, int32_t rows, int32_t K, void* stream);
+int afx_linear_fp8_mx(const void* Aq, int64_t lda, const void* a_mx, int64_t ld_mx, const float* a_scale, const void* Wq, int64_t ldw,
+                      const float* w_scale, const void* bias, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t epi,
+                      int32_t gelu_col0, const float* gate, int64_t ldg, int32_t rows_per_batch, const void* res, int64_t ldr, void* stream);
+/* ... and the producer side: the fp8 GEMM whose epilogue writes the NEXT GEMM's block-scaled operand.  Columns [0, c8_col0) leave as bf16 in C
+ * (bias only), columns [c8_col0, N) as e4m3 bytes in c8[m][n - c8_col0] with scale bytes c_mx[m][(n - c8_col0) / 128], after bias and
+ * (gelu != 0) tanh-GELU -- the mlp hidden of a double block (c8_col0 = 0), the mlp part of a single block's k|v|q|mlp projection
+ * (c8_col0 = 3 D).  a_mx may be NULL (per-row a_scale only). */
+int afx_linear_fp8_to_mx8(const void* Aq, int64_t lda, const void* a_mx, int64_t ld_mx, const float* a_scale, const void* Wq, int64_t ldw,
+                          const float* w_scale, const void* bias, void* C, int64_t ldc, void* c8, int64_t ldc8, void* c_mx, int64_t ld_cmx,
+                          int32_t c8_col0, int32_t M, int32_t N, int32_t K, int32_t gelu, void* stream);
 /* Split-K GEMM for few-row operands (M <= 1-2 tiles: the prompt encoders): the K range is cut into chunks, chunk c stores
  * its partial A . W^T (+ bias on chunk 0) into the f32 slab partials[c][M][N]; afx_finish_f32_bf16 sums the slabs into bf16
  * (+ residual).  afx_linear_splitk_chunks = number of slabs for (M, N, K, split_k); split_k 0: chosen to fill the chip. */

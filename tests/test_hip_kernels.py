@@ -435,6 +435,91 @@ def test_fp8_linear_one_wave_kernel(K):
     assert rel(out[:M, :N], exact + b.float()) < 4e-3 and (out[M] == 7).all() and (out[:, N:] == 7).all()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K', [(4645, 3640, 1024), (300, 520, 512), (4608, 3072, 3072), (77, 3072, 15360)])
+def test_fp8_block_scaled_quant_and_linear(M, N, K):
+    """MX-style activations: one E8M0 byte per row and 128 columns (the fp8 kernel's K-tile), applied by the matrix instruction.  The
+    quantiser against its definition (torch), the GEMM against the exact fp32 product of the dequantised operands -- every epilogue,
+    ragged edges, a launch of a few tiles -- and the block scales must beat one scale per row on rows with an outlier."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(7)
+    a = (torch.randn(M, K, generator=g) * 2.0)
+    a[::7, 5] = 2000.0                                             # outliers: one per affected row, in block 0 (their weight column is zero)
+    a[:, 128:256] *= 1e-2                                          # a block of small values ...
+    a = a.bfloat16().cuda()
+    w = torch.randn(N, K, generator=g) * 0.05
+    w[:, 128:256] *= 1e2                                           # ... that matter as much as the others
+    w[:, 5] = 0
+    w = w.bfloat16().cuda()
+    aq, amx = ops.quant_rows_mx8(a)
+    wq, wsc = ops.quant_rows_fp8(w)
+    blocks = a.float().view(M, K // 128, 128)
+    amax = blocks.abs().amax(-1)
+    e = torch.ceil(torch.log2(amax.clamp_min(1e-30) / 448.0)).clamp(-126, 127)
+    assert torch.equal(amx.cpu().to(torch.int32) - 127, e.cpu().to(torch.int32))
+    scale = torch.exp2(e)[..., None]
+    ref_codes = (blocks / scale).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8).view(M, K)
+    assert torch.equal(aq, ref_codes)                              # power-of-two scaling is exact: the codes are the RNE casts, bit for bit
+    ad = (aq.view(torch.float8_e4m3fn).float().view(M, K // 128, 128) * scale).view(M, K)
+    wd = wq.view(torch.float8_e4m3fn).float() * wsc[:, None]
+    exact = ad @ wd.t()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    r = torch.randn(M, N, generator=g).bfloat16().cuda()
+    gate = torch.randn(N, generator=g).cuda()
+    rel = lambda x, y: ((x.float() - y).norm() / y.norm()).item()   # noqa: E731
+    y = ops.linear_fp8_mx(aq, amx, wq, wsc, b)
+    assert rel(y, exact + b.float()) < 4e-3
+    assert (y.float() - (exact + b.float())).abs().max().item() < 0.02 * exact.abs().max().item() + 0.05
+    assert rel(ops.linear_fp8_mx(aq, amx, wq, wsc, b, epilogue='gelu'), torch.nn.functional.gelu(exact + b.float(), approximate='tanh')) < 5e-3
+    assert rel(ops.linear_fp8_mx(aq, amx, wq, wsc, b, epilogue='gate_res', gate=gate, residual=r), r.float() + gate * (exact + b.float())) < 4e-3
+    # against the unquantised product: with one scale per row the outlier pushes the small block of its row into e4m3's subnormals;
+    # a block scale never sees another block's outlier
+    true = a.float() @ w.float().t()
+    q8, s8 = ops.quant_rows_fp8(a)
+    per_row = ops.linear_fp8(q8, s8, wq, wsc)
+    err_mx, err_row = rel(ops.linear_fp8_mx(aq, amx, wq, wsc)[::7], true[::7]), rel(per_row[::7], true[::7])
+    assert err_mx < 6e-2 and err_mx < err_row, (err_mx, err_row)       # (one small block of K / 128: 0.7x at K = 1024, a few % at K = 15360)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,K,col0,gelu', [(4645, 2048, 1024, 0, True), (1000, 1792, 512, 768, True), (300, 640, 1024, 128, False)])
+def test_fp8_gemm_writes_block_scaled_operand(M, N, K, col0, gelu):
+    """The producer epilogue: columns from col0 on leave the fp8 GEMM as e4m3 bytes + one scale byte per row and 128 columns, exactly what
+    ``quant_rows_mx8`` makes of the same fp32 values (scale bytes equal; codes equal except where the bf16 detour of the two-pass path rounds
+    differently), the columns before it as bf16.  Then chained: the written operand feeds the block-scaled GEMM."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(11)
+    a = (torch.randn(M, K, generator=g) * 2.0).bfloat16().cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    b = torch.randn(N, generator=g).bfloat16().cuda()
+    aq, amx = ops.quant_rows_mx8(a)
+    wq, wsc = ops.quant_rows_fp8(w)
+    scale_a = torch.exp2(amx.float() - 127)[..., None]
+    ad = (aq.view(torch.float8_e4m3fn).float().view(M, K // 128, 128) * scale_a).view(M, K)
+    wd = wq.view(torch.float8_e4m3fn).float() * wsc[:, None]
+    y = ad @ wd.t() + b.float()
+    if gelu:
+        y[:, col0:] = torch.nn.functional.gelu(y[:, col0:], approximate='tanh')
+    head, q, mx = ops.linear_fp8_to_mx8(aq, amx, wq, wsc, b, gelu=gelu, c8_col0=col0)
+    if col0:
+        assert ((head.float() - y[:, :col0]).norm() / y[:, :col0].norm()).item() < 4e-3
+    n8 = N - col0
+    blocks = y[:, col0:].reshape(M, n8 // 128, 128)
+    e = torch.ceil(torch.log2(blocks.abs().amax(-1).clamp_min(1e-30) / 448.0)).clamp(-126, 127)
+    got_e = mx.to(torch.int32) - 127
+    assert (got_e != e.to(torch.int32)).float().mean().item() < 2e-3            # (a block maximum within an fp32 rounding of a power of two)
+    deq = (q.view(torch.float8_e4m3fn).float().view(M, n8 // 128, 128) * torch.exp2(got_e.float())[..., None]).view(M, n8)
+    assert ((deq - y[:, col0:]).norm() / y[:, col0:].norm()).item() < 4.5e-2       # e4m3: 3 mantissa bits
+    assert (deq - y[:, col0:]).abs().max().item() <= 0.0625 * y[:, col0:].abs().max().item() + 1e-3
+    # chained: the next GEMM consumes what this epilogue wrote
+    if n8 % 512 == 0:
+        w2 = (torch.randn(384, n8, generator=g) * 0.05).bfloat16().cuda()
+        w2q, w2s = ops.quant_rows_fp8(w2)
+        z = ops.linear_fp8_mx(q, mx, w2q, w2s)
+        zref = deq @ (w2q.view(torch.float8_e4m3fn).float() * w2s[:, None]).t()
+        assert ((z.float() - zref).norm() / zref.norm()).item() < 4e-3
+
+
 # ------------------------------------------------------------------------------------------ stream-K tail of the GEMM
 @pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 3072, 15360), (4608, 9216, 3072), (4608, 12288, 3072),
                                    (2048, 1024, 512), (4608, 21504, 3072)])

@@ -56,7 +56,15 @@ def gemm8():
         d16 = timeit(lambda: ops.linear(a, w, out=out))
         ref = a.float() @ w.float().t()
         err = ((ops.linear_fp8(aq, asc, wq, wsc).float() - ref).norm() / ref.norm()).item()
-        print(f'M={M:5d} N={N:5d} K={K:5d}  fp8 {d8*1e6:8.1f} us {2*M*N*K/d8/1e12:7.1f} TF | quant(A) {dq*1e6:6.1f} us | bf16 {d16*1e6:8.1f} us {2*M*N*K/d16/1e12:7.1f} TF | rel err {err:.2e}')
+        mx = ''
+        if K % 512 == 0:
+            am, ax = ops.quant_rows_mx8(a)
+            ones = torch.ones(M, device='cuda')
+            dm = timeit(lambda: ops.linear_fp8_mx(am, ax, wq, wsc, out=out, a_scale=ones))
+            dqm = timeit(lambda: ops.quant_rows_mx8(a))
+            em = ((ops.linear_fp8_mx(am, ax, wq, wsc).float() - ref).norm() / ref.norm()).item()
+            mx = f' | block-scaled {dm*1e6:8.1f} us {2*M*N*K/dm/1e12:7.1f} TF quant {dqm*1e6:6.1f} us err {em:.2e}'
+        print(f'M={M:5d} N={N:5d} K={K:5d}  fp8 {d8*1e6:8.1f} us {2*M*N*K/d8/1e12:7.1f} TF | quant(A) {dq*1e6:6.1f} us | bf16 {d16*1e6:8.1f} us {2*M*N*K/d16/1e12:7.1f} TF | rel err {err:.2e}{mx}')
 
 
 def attn():
