@@ -90,11 +90,14 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
 // modulation vector (scale + shift, fp32) for every 2 bytes of x it normalises -- out of L1 / L2, but through the same 64 B/clk address path; here a
 // lane keeps (1 + scale, shift) of its NCH chunks in registers across the wave's rows and reloads them only when the (sample, stream) of a row
 // differs from the previous one's.  The next row's chunks are requested before the current one is reduced.  Same arithmetic, same order: bit-identical.
-template <int NCH, int R>
+// MX8: the row leaves as the next fp8 GEMM's block-scaled operand instead of bf16 (afx_common.h mx_exp / mx_pack8; a lane's chunk i and its 15
+// neighbours are one 128-column block): e4m3 bytes to q8[row][.] and one E8M0 byte per block to mx[row][.] -- no quantisation pass behind the LayerNorm.
+template <int NCH, int R, bool MX8 = false>
 __global__ __launch_bounds__(256) void norm_modulate_rows_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int rows,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ldmod, int rows_per_batch,
-    const float* __restrict__ scale_txt, const float* __restrict__ shift_txt, int n_txt) {
+    const float* __restrict__ scale_txt, const float* __restrict__ shift_txt, int n_txt, uint8_t* __restrict__ q8 = nullptr, int64_t ldq = 0,
+    uint8_t* __restrict__ mx = nullptr, int64_t ld_mx = 0) {
   constexpr int D = 512 * NCH;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -161,6 +164,18 @@ __global__ __launch_bounds__(256) void norm_modulate_rows_kernel(
       float r[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) r[e] = (v[i][e] - mean) * rstd * sc[i][e] + sh[i][e];
+      if constexpr (MX8) {
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(r[e]));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+        const int eb = mx_exp(amax);
+        uint32_t w0, w1;
+        mx_pack8(r, mx_inv(eb), w0, w1);
+        *reinterpret_cast<u32x2_t*>(q8 + (int64_t)row * ldq + (lane + i * 64) * 8) = (u32x2_t){w0, w1};
+        if ((lane & 15) == 0) mx[(int64_t)row * ld_mx + 4 * i + (lane >> 4)] = (uint8_t)eb;
+      } else
       *reinterpret_cast<u32x4_t*>(orow + (lane + i * 64) * 8) = pack8(r);
     }
 #pragma unroll
@@ -180,10 +195,16 @@ static int nm_rows_per_wave() {
 // true when the multi-row kernel took the launch
 static bool launch_norm_modulate_rows(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
                                       const float* shift, int64_t ldmod, int rows_per_batch, const float* scale_txt, const float* shift_txt,
-                                      int n_txt, hipStream_t stream) {
+                                      int n_txt, hipStream_t stream, uint8_t* q8 = nullptr, int64_t ldq = 0, uint8_t* mx = nullptr, int64_t ld_mx = 0) {
   const int R = nm_rows_per_wave();
   if (D != 3072 || rows < 1024 || (R != 2 && R != 4)) return false;
   const dim3 grid((rows + 4 * R - 1) / (4 * R));
+  if (q8 != nullptr) {
+    if (R != 2) return false;
+    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2, true>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+                       scale_txt, shift_txt, n_txt, q8, ldq, mx, ld_mx);
+    return true;
+  }
   if (R == 2)
     hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
                        scale_txt, shift_txt, n_txt);
@@ -204,6 +225,15 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
   hipLaunchKernelGGL(norm_modulate_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, out, ldo, rows,
                      D, scale, shift, ldmod, rows_per_batch > 0 ? rows_per_batch : rows, rms, (const float*)nullptr,
                      (const float*)nullptr, 0);
+  return hipGetLastError();
+}
+
+// LN + modulate straight into the next fp8 GEMM's block-scaled operand (q8 [rows, ldq] e4m3, mx [rows, ld_mx] E8M0 bytes; scale_txt may be null:
+// one stream).  *fused = false: this shape has no fused kernel, nothing was launched -- the caller runs the bf16 kernel and afx_quant_rows_mx8.
+hipError_t launch_norm_modulate_mx8(const uint16_t* x, int64_t ldx, uint8_t* q8, int64_t ldq, uint8_t* mx, int64_t ld_mx, int rows, int D,
+                                    const float* scale, const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
+                                    int n_txt, hipStream_t stream, bool* fused) {
+  *fused = rows > 0 && launch_norm_modulate_rows(x, ldx, nullptr, 0, rows, D, scale, shift, ldmod, S, scale_txt, shift_txt, n_txt, stream, q8, ldq, mx, ld_mx);
   return hipGetLastError();
 }
 

@@ -74,6 +74,7 @@ struct afx_ctx {
   int head_n = 0;          // padded head width
   uint16_t* ckpt = nullptr;   // optional [num_blocks][B*S, D] block-input checkpoints (gradient checkpointing)
   bool fp8 = false;            // block linears on the fp8 MFMA (afx_set_fp8_linear)
+  int fp8_mx = -1;             // fp8: block-scaled activations, quantisation in the producers' epilogues (AFX_FP8_MX=0: one scale per row + a pass per GEMM)
   bool sk_flags_dirty = false; // a new workspace was bound: its stream-K flag words are cleared on the next forward's stream
   const float* temb_override = nullptr;   // optional [B, D] f32 replacing timestep_embedder(t) (training student with its LoRA pair)
   // conditioning of several denoising steps prepared in one pass over the stacked modulation matrix (afx_mmdit_prepare_steps)
@@ -143,6 +144,12 @@ struct Workspace {
   float *sincos, *tmp, *temb, *semb, *mod, *pooled;
   float *prep_temb, *prep_semb, *prep_mod;   // [AFX_PREP_ROWS][D], [..][D], [..][n_mod]: prepared steps (step-major, then sample)
   uint8_t* q8;     // fp8 mode: the quantised A operand of the GEMM about to run [R, <= 5D]
+  uint8_t* q8n;    // fp8, block-scaled: the D-wide operands (LayerNorm outputs, the double blocks' attention output) [R, D] -- q8 then holds the
+                   // wide ones, written by the producing GEMM's epilogue while that GEMM still reads q8n
+  uint8_t* mxn;    // [R, ld_mxn] / [R, ld_mxw] E8M0 scale bytes of q8n / q8
+  uint8_t* mxw;
+  float* ones;     // [R] 1.0f: a_scale of the block-scaled launches
+  int64_t ld_mxn, ld_mxw;
   float* qs;       //           its per-row scales [R]
   int64_t total;
 };
@@ -174,9 +181,17 @@ Workspace carve(const afx_ctx* c, char* base, int B, int N, int T) {
   w.mod = (float*)take((int64_t)B * c->n_mod * 4);
   w.q8 = nullptr;
   w.qs = nullptr;
+  w.q8n = w.mxn = w.mxw = nullptr;
+  w.ones = nullptr;
+  w.ld_mxn = (D / 128 + 3) / 4 * 4;
+  w.ld_mxw = (5 * D / 128 + 3) / 4 * 4;
   if (c->fp8) {
     w.q8 = (uint8_t*)take(R * 5 * D);
     w.qs = (float*)take(R * 4);
+    w.q8n = (uint8_t*)take(R * D);
+    w.mxn = (uint8_t*)take(R * w.ld_mxn);
+    w.mxw = (uint8_t*)take(R * w.ld_mxw);
+    w.ones = (float*)take(R * 4);
   }
   w.total = off;
   return w;
@@ -535,10 +550,22 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       }
     }
   };
+  // fp8 with block-scaled activations: every block GEMM reads e4m3 rows + one E8M0 byte per row and 128 columns.  The D-wide
+  // operands are quantised into q8n / mxn (by the pass below until their producers write them), the wide ones (mlp hidden, [O | mlp]) leave
+  // the producing GEMM's epilogue in q8 / mxw.
+  if (c->fp8 && c->fp8_mx < 0) {
+    const char* e = getenv("AFX_FP8_MX");
+    c->fp8_mx = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool mx = c->fp8 && c->fp8_mx == 1 && D % 512 == 0 && gemm_fp8_mx_ok(R, (int)D, (int)D);
+  if (mx) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.ones, 0x3f800000, (size_t)R, st));
+  // mx_in: 0 = quantise A here; 1 = A is the wide operand a previous epilogue left in q8 / mxw; 2 = the LayerNorm kernel left it in q8n / mxn.
+  // mx_out: this GEMM's epilogue writes the wide operand.
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
-                         int blk, int gate_chunk, const float* qkn = nullptr) -> int {
+                         int blk, int gate_chunk, const float* qkn = nullptr, int mx_in = 0, bool mx_out = false) -> int {
     GemmBatch gb{};
-    if (c->fp8) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
+    if (mx && mx_in == 0) HIP_TRY(launch_quant_rows_mx8(A, lda, ws.q8n, K, ws.mxn, ws.ld_mxn, (int)R, K, st));      // (mx_in 2: the LayerNorm kernel wrote q8n / mxn itself)
+    else if (c->fp8 && !mx) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
     for (int b = 0; b < B; ++b)
       for (int s = 0; s < 2; ++s) {   // 0 image rows, 1 text rows
         GemmProblem& p = gb.p[gb.nprob++];
@@ -546,7 +573,12 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         const int64_t row0 = (int64_t)b * S + (s == 0 ? T : 0);
         p.A = A + row0 * lda; p.lda = lda;
         p.W = lw[s].w; p.ldw = K; p.bias = lw[s].b;
-        if (c->fp8) {
+        if (mx) {
+          p.W = (const uint16_t*)lw[s].wq; p.fp8 = 1; p.a_scale = ws.ones + row0; p.w_scale = lw[s].wscale; p.lda = K;
+          if (mx_in != 1) { p.A = (const uint16_t*)(ws.q8n + row0 * K); p.a_mx = ws.mxn + row0 * ws.ld_mxn; p.ld_mx = ws.ld_mxn; }
+          else { p.A = (const uint16_t*)(ws.q8 + row0 * K); p.a_mx = ws.mxw + row0 * ws.ld_mxw; p.ld_mx = ws.ld_mxw; }
+          if (mx_out) { p.c8 = ws.q8 + row0 * Nout; p.ldc8 = Nout; p.c_mx = ws.mxw + row0 * ws.ld_mxw; p.ld_cmx = ws.ld_mxw; p.c8_col0 = 0; }
+        } else if (c->fp8) {
           p.A = (const uint16_t*)(ws.q8 + row0 * K); p.lda = K;
           p.W = (const uint16_t*)lw[s].wq; p.fp8 = 1; p.a_scale = ws.qs + row0; p.w_scale = lw[s].wscale;
         }
@@ -567,7 +599,15 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     return AFX_OK;
   };
   // LN + modulate of both streams of every sample in one launch (text rows take the text stream's vectors)
+  bool norm_fused = false;      // mx: the last stream_norm wrote the GEMM operand itself
   auto stream_norm = [&](int blk, int shift_chunk, int scale_chunk) -> int {
+    norm_fused = false;
+    if (mx) {
+      HIP_TRY(launch_norm_modulate_mx8(ws.X, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
+                                       ws.mod + ml.dbl(blk, 0, shift_chunk), ws.mod + ml.dbl(blk, 1, scale_chunk),
+                                       ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, (int)S, T, st, &norm_fused));
+      if (norm_fused) return AFX_OK;
+    }
     HIP_TRY(launch_norm_modulate_joint(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
                                        ws.mod + ml.dbl(blk, 0, shift_chunk), ws.mod + ml.dbl(blk, 1, scale_chunk),
                                        ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, S, T, st));
@@ -593,7 +633,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
       }
     } else
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr, norm_fused ? 2 : 0))) return rc;
     // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
     if (vt_fuse) {
     } else if (qk_fuse)
@@ -605,8 +645,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
     if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
     if ((rc = stream_norm(i, 3, 4))) return rc;
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0))) return rc;
-    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0, nullptr, norm_fused ? 2 : 0, mx))) return rc;      // (mx: the hidden leaves as the next GEMM's operand, Hb stays unwritten)
+    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5, nullptr, mx ? 1 : 0))) return rc;
   }
 
   // ---- single-stream blocks on the joint sequence -------------------------------------------------
@@ -616,14 +656,22 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if ((rc = join_side(d.num_double + i))) return rc;
     if (c->ckpt)
       HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)(d.num_double + i) * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
+    bool sgl_fused = false;
+    if (mx) HIP_TRY(launch_norm_modulate_mx8(ws.X, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0),
+                                             nullptr, nullptr, ldm, (int)S, 0, st, &sgl_fused));
+    if (!sgl_fused) HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
     GemmBatch gb{};
     gb.nprob = 1;
     GemmProblem& f = gb.p[0];
     f = GemmProblem{};
     f.A = ws.Xn; f.lda = D; f.W = bw.fused.w; f.ldw = D; f.bias = bw.fused.b;
     f.C = ws.F; f.ldc = 7 * D; f.M = (int)R; f.N = (int)(7 * D); f.K = (int)D; f.epi = EPI_GELU; f.gelu_col0 = (int)(3 * D);
-    if (c->fp8) {
+    if (mx) {             // A: the LayerNorm rows, block-scaled; the mlp columns leave as columns [D, 5D) of the proj_out operand
+      if (!sgl_fused) HIP_TRY(launch_quant_rows_mx8(ws.Xn, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, st));
+      f.A = (const uint16_t*)ws.q8n; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.ones; f.w_scale = bw.fused.wscale;
+      f.a_mx = ws.mxn; f.ld_mx = ws.ld_mxn;
+      f.c8 = ws.q8 + D; f.ldc8 = 5 * D; f.c_mx = ws.mxw + D / 128; f.ld_cmx = ws.ld_mxw; f.c8_col0 = (int)(3 * D);
+    } else if (c->fp8) {
       HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));
       f.A = (const uint16_t*)ws.q8; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.qs; f.w_scale = bw.fused.wscale;
     }
@@ -663,7 +711,11 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     o.A = ws.F + 2 * D; o.lda = 7 * D; o.W = bw.out.w; o.ldw = 5 * D; o.bias = bw.out.b;
     o.C = ws.X; o.ldc = D; o.M = (int)R; o.N = (int)D; o.K = (int)(5 * D); o.epi = EPI_GATE_RES;
     o.gate = ws.mod + ml.sgl(i, 2); o.ldg = ldm; o.rows_per_batch = S; o.res = ws.X; o.ldr = D;
-    if (c->fp8) {
+    if (mx) {             // the attention output joins the mlp columns the projection's epilogue left in q8
+      HIP_TRY(launch_quant_rows_mx8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.mxw, ws.ld_mxw, (int)R, (int)D, st));
+      o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)bw.out.wq; o.fp8 = 1; o.a_scale = ws.ones; o.w_scale = bw.out.wscale;
+      o.a_mx = ws.mxw; o.ld_mx = ws.ld_mxw;
+    } else if (c->fp8) {
       HIP_TRY(launch_quant_rows_fp8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.qs, (int)R, (int)(5 * D), st));
       o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)bw.out.wq; o.fp8 = 1; o.a_scale = ws.qs;
       o.w_scale = bw.out.wscale;

@@ -176,6 +176,47 @@ def test_fp8_linear_mode_tracks_bf16(family):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('family', ['flux', 'qwen'])
+def test_fp8_block_scaled_mode_tracks_bf16(family, monkeypatch):
+    """Width 512 (4 heads) switches the fp8 engine to block-scaled activations (one E8M0 byte per row and 128 columns; the mlp hidden and the mlp part
+    of the single blocks' [O | mlp] operand leave the producing GEMM's epilogue quantised, no pass of their own).  Against the bf16 engine and
+    against the same engine with one scale per row and a quantisation pass per GEMM (AFX_FP8_MX=0): both within e4m3 error, and not identical."""
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    g = torch.Generator().manual_seed(23)
+    hp = wp = 16
+    T = 40
+    if family == 'flux':
+        cfg = D.FluxCfg(num_layers=2, num_single_layers=2, heads=4, joint_dim=128, pooled_dim=64)
+        w = D.make_flux_weights(cfg, seed=6)
+        kw = dict(num_double=2, num_single=2, joint_dim=128, pooled_dim=64)
+        pooled, gd = (torch.randn(2, 64, generator=g) * 0.5).bfloat16().cuda(), torch.full((2,), 3.5).cuda()
+    else:
+        cfg = D.QwenCfg(num_layers=3, heads=4, joint_dim=192)
+        w = D.make_qwen_weights(cfg, seed=6)
+        kw = dict(num_double=3, joint_dim=192)
+        pooled = gd = None
+    x = torch.randn(2, hp * wp, 64, generator=g).bfloat16().cuda()
+    ctx = (torch.randn(2, T, kw['joint_dim'], generator=g) * 0.5).bfloat16().cuda()
+    t = torch.tensor([0.6, 0.3]).cuda()
+    outs = {}
+    for mode in ('bf16', 'mx', 'row'):
+        monkeypatch.setenv('AFX_FP8_MX', '0' if mode == 'row' else '1')
+        eng = MMDiTEngine(family, kw['num_double'], kw.get('num_single', 0), heads=4, joint_dim=kw['joint_dim'], pooled_dim=kw.get('pooled_dim', 768))
+        eng.load_state_dict(w)
+        if mode != 'bf16':
+            eng.enable_fp8()
+        outs[mode] = {k: v.float().clone() for k, v in eng(x, t, ctx, pooled, gd, hp, wp).items()}
+    for k in ('means', 'logweights', 'loggammas'):
+        ref = outs['bf16'][k]
+        rel_mx = ((outs['mx'][k] - ref).norm() / ref.norm()).item()
+        rel_row = ((outs['row'][k] - ref).norm() / ref.norm()).item()
+        assert 0 < rel_mx < 8e-2 and 0 < rel_row < 8e-2, (k, rel_mx, rel_row)
+        assert rel_mx < 1.3 * rel_row + 1e-3, (k, rel_mx, rel_row)
+        assert not torch.equal(outs['mx'][k], outs['row'][k])          # the two formats really are different paths
+
+
+@pytest.mark.gpu
 def test_profile_events_every_launch_and_sampled():
     """afx_profile_enable(ctx, N): an event pair on every GEMM / attention launch (N = 1) or on one launch in N (bench.py's default 8: the pairs cost
     ~4 us each).  The sampled sums must cover 1 / N of the launches and give the same FLOP / time ratio within the launch-to-launch spread."""

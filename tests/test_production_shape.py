@@ -204,3 +204,45 @@ def test_full_flux12b_forward_properties_and_block_parity():
     # the increment itself (residual removed): a dead block would pass the check above
     inc = rel_l2(x_last.float().cpu()[None] - xin, ref - xin)
     assert inc < 8e-2, inc
+
+
+@pytest.mark.parametrize('family', ['flux', 'qwen'])
+def test_fp8_block_scaled_forward_at_full_width(family, monkeypatch):
+    """BASELINE.json configs[4]'s forward format at the production width: e4m3 operands with one E8M0 scale per row and 128 columns, written by
+    the LayerNorm-modulate kernel, by the mlp / k|v|q|mlp GEMMs' epilogues and (attention output) by the quantiser -- no bf16 copy of the mlp
+    hidden exists.  One double (+ one single) block at 1024 + 128 tokens, two samples: against the bf16 engine, and against the same engine with one
+    scale per row and a quantisation pass per GEMM (AFX_FP8_MX=0).  Stated tolerance of the fp8 mode: 8e-2, as for the row-scaled path (tests/test_hip_engine.py)."""
+    from arcflow_amd import MMDiTEngine
+    from oracle import dit_ref as D
+    hp = wp = 32
+    N, T, B = hp * wp, 128, 2
+    if family == 'flux':
+        cfg = D.FluxCfg(num_layers=1, num_single_layers=1)
+        w = D.make_flux_weights(cfg, seed=3)
+        nd, ns = 1, 1
+    else:
+        cfg = D.QwenCfg(num_layers=2)
+        w = D.make_qwen_weights(cfg, seed=3)
+        nd, ns = 2, 0
+    hid, ctx, pooled = _inputs(B, N, T, cfg.joint_dim, cfg.pooled_dim if family == 'flux' else 0, seed=4)
+    t = torch.tensor([1.0, 0.7619]).cuda()
+    gd = torch.full((B,), 3.5).cuda() if family == 'flux' else None
+    res = {}
+    for mode in ('bf16', 'mx', 'row'):
+        monkeypatch.setenv('AFX_FP8_MX', '0' if mode == 'row' else '1')
+        eng = MMDiTEngine(family, nd, ns, joint_dim=cfg.joint_dim)
+        eng.load_state_dict(w)
+        if mode != 'bf16':
+            eng.enable_fp8()
+        out = eng(hid.cuda(), t, ctx.cuda(), None if pooled is None else pooled.cuda(), gd, hp, wp)
+        xf = torch.empty(B * N, cfg.dim, dtype=torch.bfloat16, device='cuda')
+        eng.export('x_final', xf, B, N, T)
+        torch.cuda.synchronize()
+        res[mode] = (xf.float().clone(), out.means.float().clone())
+    for i, name in enumerate(('trunk', 'means')):
+        ref = res['bf16'][i]
+        e_mx, e_row = rel_l2(res['mx'][i], ref), rel_l2(res['row'][i], ref)
+        assert 0 < e_mx < 8e-2 and 0 < e_row < 8e-2, (name, e_mx, e_row)
+        assert e_mx < 1.25 * e_row, (name, e_mx, e_row)
+        assert not torch.equal(res['mx'][i], res['row'][i])
+        print(family, name, 'block-scaled', e_mx, 'row-scaled', e_row)
