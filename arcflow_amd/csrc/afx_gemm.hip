@@ -1215,7 +1215,7 @@ constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (3
 // the CU count, a multiple of 8: the walk stays on the work-group's XCD chunk) and issues the NEXT tile's first four DMA batches
 // (A(0) W(0) W(1) A(1)) between its last K-tile and its epilogue, so their latency -- and the launch of a fresh work-group -- hide
 // behind the epilogue's stores.  VMEM operations retire in order: the epilogue's own residual loads then queue behind those batches.
-template <int MI, int NJ, bool CONV = false, int PERSIST = 0>      // PERSIST 1: next tile's DMA in front of the epilogue, 2: behind it
+template <int MI, int NJ, bool CONV = false, int PERSIST = 0>      // PERSIST 1: next tile's DMA in front of the epilogue, 2: behind it; 3: no walk, ONE copy of the K-tile body (see the loop)
 __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_kernel_v3(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ;
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
@@ -1363,11 +1363,14 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   // Two copies of the K-tile body: tiles whose successor t+2 exists issue its DMA, the last two tiles issue nothing -- as a
   // compile-time flag, because a scalar branch around each DMA issue costs the lone wave ~30 cycles of instruction refetch
   // (16 per K-tile: +20 %).
+  // PERSIST == 3: ONE copy instead -- the last two tiles re-fetch tile nk - 1 into slots nobody reads any more (as the attention kernel does).
+  // The two copies meet in a block where hipcc moves all 4 MI NJ accumulators to the registers the second copy was allocated
+  // (255 v_accvgpr_mov_b32 per tile for 8 x 8: ~1-2 k cycles of a 125 k-cycle K = 3072 tile); one copy has no such seam.
   int t = 0;
 #pragma unroll
-  for (int part = 0; part < 2; ++part) {
+  for (int part = 0; part < (PERSIST == 3 ? 1 : 2); ++part) {
   const bool more = part == 0;                 // a constant once the two parts are unrolled
-  const int t_end = more ? nk - 2 : nk;
+  const int t_end = (more && PERSIST != 3) ? nk - 2 : nk;
 #pragma unroll 1
   for (; t < t_end; ++t) {
     const char* sa = smem + (t & 1) * A_SLOT;
@@ -1375,7 +1378,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     AFX_TR(0)
     // ---- k-half 0 multiplies; the k-half-1 fragments stream in; W(t+2) -> slot (t+2) % 3 ------------------------------------
     {
-      const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(t + 2) * (BK * 2)));
+      const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(PERSIST == 3 ? min(t + 2, nk - 1) : t + 2) * (BK * 2)));
       char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {          // one memory instruction at most between two MFMAs (12 free issue cycles)
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     AFX_TR(3)
     // ---- k-half 1 multiplies; DMA of A(t+2) -> slot t & 1 and the k-half-0 fragments of tile t+1 ---------------------------
     {
-      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + ka(t + 2)));
+      const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + ka(PERSIST == 3 ? min(t + 2, nk - 1) : t + 2)));
       char* adst = smem + (t & 1) * A_SLOT;
       const char* na = smem + ((t + 1) & 1) * A_SLOT;
       const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
@@ -1469,6 +1472,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
       for (int i = 0; i < 24; ++i) g_gemm_trace[blockIdx.x ? 1 : 0][wave2][i] = tr[i];
 #endif
     if constexpr (PERSIST == 2) next_tile();
+    if constexpr (PERSIST == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the re-fetched tiles must have landed before the LDS is handed on
     if (!has_next) break;
   }
   }
