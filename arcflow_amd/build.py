@@ -19,6 +19,28 @@ HEADERS = ['afx_common.h', 'afx_kernels.h', 'afx_api_util.h', os.path.join('..',
 HEADERS += [os.path.join('gen', f) for f in sorted(os.listdir(os.path.join(CSRC, 'gen'))) if f.endswith('.inc')]
 # sources whose kernels OWN registers by literal name (tools/gen_attn3.py): their ISA is audited after every build
 ASM_OWNED = {'afx_attn3.hip': 'attention_v3_kernel'}
+# kernels whose accumulators are written by inline-asm MFMAs the compiler cannot see into: a register spill there may store an accumulator straight
+# behind the MFMA that is still writing it (happened to gemm_kernel_v3f8 once its epilogue grew) -- they must not use scratch at all
+NO_SCRATCH = {'afx_gemm.hip': ['gemm_kernel_v3f8', 'gemm_kernel_v3ILi8ELi8ELb0ELi0E', 'gemm_kernel_v3ILi8ELi7ELb0ELi0E', 'gemm_kernel_v3ILi7ELi8ELb0ELi0E',
+                               'gemm_kernel_v3ILi9ELi6ELb0ELi0E', 'gemm_kernel_v3ILi4ELi4ELb0ELi0E']}
+
+
+def audit_no_scratch(asm_path: str, kernel_substrs) -> None:
+    """Every kernel of the file whose mangled name contains one of `kernel_substrs` must have private_segment_fixed_size 0."""
+    import re
+    text = open(asm_path).read()
+    seen = 0
+    for m in re.finditer(r'\.amdhsa_kernel (\S+)', text):
+        name = m.group(1)
+        if not any(k in name for k in kernel_substrs):
+            continue
+        seen += 1
+        size = re.search(r'private_segment_fixed_size\s+(\d+)', text[m.start():m.start() + 4000])
+        if size is None or int(size.group(1)) != 0:
+            raise RuntimeError(f'{asm_path}: kernel {name} uses {size.group(1) if size else "?"} bytes of scratch: a spill inside an inline-asm MFMA stream '
+                               f'is not hazard-checked by hipcc -- reduce its register pressure')
+    if seen == 0:
+        raise RuntimeError(f'{asm_path}: none of {kernel_substrs} found by the scratch audit')
 
 
 def lib_path() -> str:
@@ -97,7 +119,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         obj = os.path.join(objdir, src.replace('.hip', '.o'))
         objs.append(obj)
         cmd = [hipcc, *flags, '-c', os.path.join(CSRC, src), '-o', obj]
-        if src in ASM_OWNED:
+        if src in ASM_OWNED or src in NO_SCRATCH:
             cmd += ['-save-temps=obj', '-Wno-inline-asm']      # keeps the .s next to the object for the audit below
         if verbose:
             print('[arcflow_amd.build]', ' '.join(cmd), flush=True)
@@ -110,6 +132,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(log)
         if src in ASM_OWNED:
             audit_asm_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ASM_OWNED[src])
+        if src in NO_SCRATCH:
+            audit_no_scratch(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), NO_SCRATCH[src])
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out]
     if verbose:
         print('[arcflow_amd.build]', ' '.join(cmd), flush=True)

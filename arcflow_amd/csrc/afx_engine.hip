@@ -519,15 +519,29 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     }
     return AFX_OK;
   };
+  // fp8 with block-scaled activations (DESIGN 11): every block GEMM reads e4m3 rows + one E8M0 byte per row and 128 columns.  The D-wide
+  // operands are quantised into q8n / mxn (by the pass below until their producers write them), the wide ones (mlp hidden, [O | mlp]) leave
+  // the producing GEMM's epilogue in q8 / mxw.
+  if (c->fp8 && c->fp8_mx < 0) {
+    const char* e = getenv("AFX_FP8_MX");
+    c->fp8_mx = (e && e[0] == '0') ? 0 : 1;
+  }
+  const bool mx = c->fp8 && c->fp8_mx == 1 && D % 512 == 0 && gemm_fp8_mx_ok(R, (int)D, (int)D);
+  if (mx) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.ones, 0x3f800000, (size_t)R, st));
+  // The fused q / k epilogue also exists on the one-wave-per-SIMD fp8 kernel (epi_store_qk<MI, true>; V is then transposed by its own launch), opt-in:
+  // measured level with the separate preparation launch (11.30 vs 11.30 images/s) -- with 256 accumulators in the file the fp8 variant of that epilogue
+  // has to re-read the weight scales per row tile, which costs what the saved launch gave (AFX_FP8_QK_FUSE=1).
+  const char* qkf8 = getenv("AFX_FP8_QK_FUSE");
+  const bool qk_fuse_fp8 = mx && qkf8 != nullptr && qkf8[0] == '1';
   // helper: one grouped GEMM over the image and text row ranges of every sample
   // q / k RMSNorm + RoPE inside the epilogue of the k|v|q projections (GemmProblem::qk_D) when the GEMM kernel in use offers it:
   // the separate launch then only transposes V.  Not in fp8 mode (that kernel has no such epilogue).
-  const bool qk_fuse = gemm_qk_fusion_available() && !c->fp8;
+  const bool qk_fuse = gemm_qk_fusion_available() && (!c->fp8 || qk_fuse_fp8);
   // ... and V^T straight out of the projection (GemmProblem::w_perm16 / bias_rows: the V third computed transposed, A = the V rows
   // of the weight, W = the tokens) when the 16-key groups of the joint sequence do not straddle the text / image boundary and no
   // key padding is needed: then no preparation launch is left between the projection and the attention.
   const int S_pad_ = (int)attn_spad(S);
-  const bool vt_fuse = qk_fuse && T % 16 == 0 && S % 64 == 0 && getenv("AFX_VT_FUSE_OFF") == nullptr;
+  const bool vt_fuse = qk_fuse && !c->fp8 && T % 16 == 0 && S % 64 == 0 && getenv("AFX_VT_FUSE_OFF") == nullptr;
   const int64_t vt_sample = (int64_t)H * 128 * S_pad_;           // elements of one sample's V^T
   // the k, q and transposed-v problems of one k|v|q(|mlp) projection over `rows` joint rows starting at joint row `row0` of sample b
   auto kqv_problems = [&](GemmBatch& gb, const uint16_t* A, int64_t lda, const LinW& lw, uint16_t* C, int64_t ldc, int64_t row0g,
@@ -550,15 +564,6 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       }
     }
   };
-  // fp8 with block-scaled activations (DESIGN 11): every block GEMM reads e4m3 rows + one E8M0 byte per row and 128 columns.  The D-wide
-  // operands are quantised into q8n / mxn (by the pass below until their producers write them), the wide ones (mlp hidden, [O | mlp]) leave
-  // the producing GEMM's epilogue in q8 / mxw.
-  if (c->fp8 && c->fp8_mx < 0) {
-    const char* e = getenv("AFX_FP8_MX");
-    c->fp8_mx = (e && e[0] == '0') ? 0 : 1;
-  }
-  const bool mx = c->fp8 && c->fp8_mx == 1 && D % 512 == 0 && gemm_fp8_mx_ok(R, (int)D, (int)D);
-  if (mx) HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)ws.ones, 0x3f800000, (size_t)R, st));
   // mx_in: 0 = quantise A here; 1 = A is the wide operand a previous epilogue left in q8 / mxw; 2 = the LayerNorm kernel left it in q8n / mxn.
   // mx_out: this GEMM's epilogue writes the wide operand.
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,

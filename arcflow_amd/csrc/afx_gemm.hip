@@ -506,13 +506,17 @@ AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.conv
 // exchange lane (frow, fq) owns, for row ii*16 + frow, the 8-column chunks 4 st + 2 (fq & 1) + (fq >> 1), st = 0..3, of that head:
 // its 32 values + those of the three other fq lanes are the 128 of the RMSNorm (two cross-lane adds); a chunk holds 4 whole
 // rotation pairs.  cos / sin of the NEXT row tile are requested before this one is finished.
-template <int MI>
+// FP8: the accumulators are first scaled by a_scale[row] * w_scale[col] (the fp8 kernels' products).
+template <int MI, bool FP8 = false>
 AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_base, int col_base, int frow, int fq, const float* wn) {
   constexpr uint32_t OOB = 0x80000000u;
   const int M = P.M, N = P.N;
   const int rows_ok = min(max(M - row_base, 0), MI * 16);
   const int64_t ldc = P.ldc;
   __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.C + (int64_t)row_base * ldc, (int)(rows_ok * ldc * 2));
+  __amdgpu_buffer_rsrc_t ra = rc;
+  if constexpr (FP8) ra = uniform_rsrc(const_cast<float*>(P.a_scale) + row_base, rows_ok * 4);
+  const float* const wscp = P.w_scale;       // (FP8: re-read per row tile out of L1, requested with the cos / sin rows -- 32 more live floats make hipcc spill)
   __amdgpu_buffer_rsrc_t rcs = uniform_rsrc(const_cast<float*>(P.rope_cos), P.rope_rows * 256);
   __amdgpu_buffer_rsrc_t rsn = uniform_rsrc(const_cast<float*>(P.rope_sin), P.rope_rows * 256);
   const int ldc2 = (int)(ldc * 2);
@@ -531,6 +535,7 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[st][e] = 0.f;
     if (biasp != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(biasp + gcol), bias[st]);
+
     const f32x4_t w0 = *reinterpret_cast<const f32x4_t*>(wn + c8 * 8), w1 = *reinterpret_cast<const f32x4_t*>(wn + c8 * 8 + 4);
     w[st][0] = w0[0]; w[st][1] = w0[1]; w[st][2] = w0[2]; w[st][3] = w0[3];
     w[st][4] = w1[0]; w[st][5] = w1[1]; w[st][6] = w1[2]; w[st][7] = w1[3];
@@ -555,6 +560,17 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
     float v[4][8];
     float ss = 0.f;
+    float asc = 1.f;
+    f32x4_t ws[FP8 ? 4 : 1][2];
+    if constexpr (FP8) {
+      asc = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (ii * 16 + frow) * 4, 0, 0));
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        const int gc = min(col_base + (4 * st + 2 * (fq & 1) + (fq >> 1)) * 8, N - 8);
+        ws[st][0] = *reinterpret_cast<const f32x4_t*>(wscp + gc);
+        ws[st][1] = *reinterpret_cast<const f32x4_t*>(wscp + gc + 4);
+      }
+    }
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
 #pragma unroll
@@ -565,6 +581,7 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
+        if constexpr (FP8) v[st][e] *= asc * ws[st][e >> 2][e & 3];
         v[st][e] += bias[st][e];
         ss += v[st][e] * v[st][e];
       }
@@ -593,11 +610,11 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
 #endif
 template <int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
 AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
-  if constexpr (NJ == 8 && SWAP && !FP8 && !PRE) {
+  if constexpr (NJ == 8 && SWAP && !PRE) {
     if (P.qk_D > 0) {                                            // (uniform) which 128-column head of k | v | q (| mlp) is this wave's?
       const int region = col_base / P.qk_D;
-      if (region == 0) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
-      if (region == 2) { epi_store_qk<MI>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
+      if (region == 0) { epi_store_qk<MI, FP8>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
+      if (region == 2) { epi_store_qk<MI, FP8>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
     }
   }
   if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4) && NJ % 2 == 0) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
@@ -1633,7 +1650,11 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
   // ---- MX: scale bytes of this lane's MI row tiles, 4 K-tiles per dword --------------------------------------------------------
-  const int mx_one = 0x7f7f7f7f;
+  // scale of the weight operand: 2^0 in every byte.  OPAQUE (asm-defined): as a plain constant hipcc re-materialises it with a v_mov right in front of
+  // the first MFMA of a tile, and a VALU write -> v_mfma_scale scale-operand read needs wait states its hazard recogniser does not add (seen as ONE
+  // wrong 16x16 tile per wave: row tile 0 x column tile 0).
+  int mx_one;
+  asm volatile("v_mov_b32 %0, 0x7f7f7f7f\n\ts_nop 7" : "=v"(mx_one));
   uint32_t sc_cur[MX ? MI : 1], sc_nxt[MX ? MI : 1];
   u32x4_t mx_rsrc = (u32x4_t){0u, 0u, 0u, 0u};
   uint32_t mx_voff = 0;
@@ -1663,17 +1684,37 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
     for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
   __builtin_amdgcn_s_barrier();
-  // 32-byte operands: words 0..3 = chunk fq, words 4..7 = chunk 4 + fq of the lane's row
-  i32x8_t af[2][MI], bl[NH], bh[NH];
-  auto ld_half = [&](i32x8_t& f, int h, const char* tile, int row) {
-    const u32x4_t w = __builtin_bit_cast(u32x4_t, lds_frag(tile, row, 4 * h + fq));
+  // 32-byte operands: words 0..3 = chunk fq, words 4..7 = chunk 4 + fq of the lane's row.  ONE register set for A: row tile i's fragment of tile
+  // t+1 is read right behind the last MFMA of tile t that uses row tile i (phase 1 runs row tile by row tile), the last one at the start of the next
+  // phase 0 -- 64 + 64 fragment registers instead of 128 + 64 (with two A sets the kernel sat at 250+ of 256 arch VGPRs and hipcc spilled: an LDS
+  // address at best, and once an ACCUMULATOR, stored straight behind the inline-asm MFMA that was still writing it).
+  static_assert(MI == 8 && NJ == 8, "the slot tables below are written for the 8 x 8 shape");
+  i32x8_t af[MI], bl[NH], bh[NH];
+  // LDS address of half h of row tile i of a slot = slot + lane part(h) + 2048 i: the swizzle term ((row >> 1) & 7) does not depend on i, so a tile
+  // needs FOUR address registers (A / W x two halves: slot + lane part, made opaque per tile) and every read is `base offset:2048 i`.  Left to
+  // itself hipcc hoists one register per (i, h) and slot out of the loop (`lane | 0x800 i`: 32+ of them) until the register file is full.
+  typedef __attribute__((address_space(3))) const bf16x8_t* lds_frag_ptr;
+  const uint32_t la0 = (uint32_t)(arow * 128 + (((0 + fq) ^ ((arow >> 1) & 7)) << 4)), la1 = (uint32_t)(arow * 128 + (((4 + fq) ^ ((arow >> 1) & 7)) << 4));
+  const uint32_t lb0 = (uint32_t)(brow * 128 + (((0 + fq) ^ ((brow >> 1) & 7)) << 4)), lb1 = (uint32_t)(brow * 128 + (((4 + fq) ^ ((brow >> 1) & 7)) << 4));
+  auto ld_at = [&](i32x8_t& f, int h, uint32_t base, int i) {      // base = slot + lane part of half h (a VGPR), i = row tile
+    const u32x4_t w = __builtin_bit_cast(u32x4_t, *reinterpret_cast<lds_frag_ptr>(base + (uint32_t)(i * 2048)));
     f[4 * h + 0] = (int)w[0]; f[4 * h + 1] = (int)w[1]; f[4 * h + 2] = (int)w[2]; f[4 * h + 3] = (int)w[3];
   };
-  // fragment read r of phase 1 (tile t+1's operands, in the order the next phase 0 needs them): W_lo first, then the A row tiles
-  auto read1 = [&](int r, i32x8_t (&an)[MI], const char* na, const char* nw) {
-    if (r < NJ) ld_half(bl[r >> 1], r & 1, nw, brow + (r >> 1) * 16);
-    else ld_half(an[(r - NJ) >> 1], (r - NJ) & 1, na, arow + ((r - NJ) >> 1) * 16);
+  auto slot_bases = [&](const char* slot, uint32_t l0, uint32_t l1, uint32_t (&out)[2]) {
+    const uint32_t sb = (uint32_t)(uintptr_t)slot;
+    out[0] = sb + l0; out[1] = sb + l1;
+    asm volatile("" : "+v"(out[0]), "+v"(out[1]));              // opaque: computed here, once per tile and slot, not hoisted in 32 variants
   };
+  // prologue: A row tiles 0..6 and W_lo of tile 0 (row tile 7 is read by tile 0's phase 0 like every tile's)
+  {
+    uint32_t pa[2], pw[2];
+    slot_bases(smem, la0, la1, pa);
+    slot_bases(smem_w, lb0, lb1, pw);
+#pragma unroll
+    for (int r = 0; r < NJ; ++r) ld_at(bl[r >> 1], r & 1, pw[r & 1], r >> 1);
+#pragma unroll
+    for (int r = 0; r < 2 * (MI - 1); ++r) ld_at(af[r >> 1], r & 1, pa[r & 1], r >> 1);
+  }
   // (the host pass parses this body too, and x86's "v" constraint does not take a 256-bit operand without AVX: the function would be dropped
   // from the host object -- silently, as a deferred diagnostic -- and its launch stub with it)
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1691,50 +1732,53 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   else if constexpr ((BT) == 1) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,0,0]"); \
   else if constexpr ((BT) == 2) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,1,0]"); \
   else V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,1,0]")
-  // One K-tile.  PAR: which A register set holds A(t) (the other one receives A(t+1)); MORE: tile t+2 exists -> issue its DMA.  Both are
-  // compile-time (a scalar branch around each DMA issue costs the lone wave ~30 cycles of instruction refetch).
-  auto tile = [&](auto PAR_, auto MORE_, int t, auto BT_, auto FETCH_) {
-    constexpr int par = decltype(PAR_)::value;
+  // One K-tile.  MORE: tile t+2 exists -> issue its DMA (compile-time: a scalar branch around each DMA issue costs the lone wave ~30 cycles of
+  // instruction refetch).  Memory instruction behind MFMA m (at most one per gap):
+  //   phase 0   even m < 16: W(t+2) piece m / 2 | odd m < 16: W_hi(t) half (m - 1) / 2 | m = 16, 17: A(t) row tile 7 (first used by MFMA 28)
+  //   phase 1   m = 0..3, 6, 7, 10, 11: W_lo(t+1) halves | m = 4 i + 4, 4 i + 5 (i < 7): A(t+1) row tile i (free since MFMA 4 i + 3)
+  //             m = 14, 15, 18, 19, 22, 23, 26, 27: A(t+2) pieces 0..7
+  auto tile = [&](auto MORE_, int t, auto BT_, auto FETCH_) {
     constexpr bool more = decltype(MORE_)::value;
     constexpr int bt = decltype(BT_)::value;            // MX: byte of the scale dwords = tile index inside its group of 4
     constexpr bool fetch = decltype(FETCH_)::value;     // MX: request the next group's scale dwords behind this tile's A DMA
-    const char* sw = smem_w + (t % 3) * W_SLOT;
-    // ---- phase 0: column tiles [0, NH); W_hi(t) streams in; W(t+2) -> slot (t+2) % 3 -----------------------------------------------
+    uint32_t pa[2], pw[2];
+    slot_bases(smem + (t & 1) * A_SLOT, la0, la1, pa);
+    slot_bases(smem_w + (t % 3) * W_SLOT, lb0, lb1, pw);
     {
       const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(t + 2) * KB));
       char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        V3F8_MFMA(bt, acc[m / NH][m % NH], bl[m % NH], af[par][m / NH], sc_cur[MX ? m / NH : 0]);
+        V3F8_MFMA(bt, acc[m / NH][m % NH], bl[m % NH], af[m / NH], sc_cur[MX ? m / NH : 0]);
         V3_FENCE();
-        if ((m & 1) && (m >> 1) < R0) { const int r = m >> 1; ld_half(bh[r >> 1], r & 1, sw, brow + (NH + (r >> 1)) * 16); }
-        if (!(m & 1) && (m >> 1) < NJ && more) {
+        if (m < 16 && (m & 1)) { const int r = m >> 1; ld_at(bh[r >> 1], r & 1, pw[r & 1], NH + (r >> 1)); }
+        if (m < 16 && !(m & 1) && more) {
           const int q = m >> 1;
           V3_DMA(wsrc_u, woff[q], wdst + (q * V3_THREADS + wave * 64) * 16);
         }
+        if (m == 16 || m == 17) ld_at(af[MI - 1], m - 16, pa[m - 16], MI - 1);
         V3_FENCE();
       }
     }
     if constexpr (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // ---- phase 1: column tiles [NH, NJ); A(t+1) and W_lo(t+1) stream in; A(t+2) -> slot t & 1 ------------------------------------
     {
       const uint64_t asrc_u = v3_uniform_u64((uintptr_t)(abase + (int64_t)(t + 2) * KB));
       char* adst = smem + (t & 1) * A_SLOT;
-      const char* na = smem + ((t + 1) & 1) * A_SLOT;
-      const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
+      uint32_t na[2], nw[2];
+      slot_bases(smem + ((t + 1) & 1) * A_SLOT, la0, la1, na);
+      slot_bases(smem_w + ((t + 1) % 3) * W_SLOT, lb0, lb1, nw);
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
-        V3F8_MFMA(bt, acc[m / NH][NH + m % NH], bh[m % NH], af[par][m / NH], sc_cur[MX ? m / NH : 0]);
+        V3F8_MFMA(bt, acc[m / NH][NH + m % NH], bh[m % NH], af[m / NH], sc_cur[MX ? m / NH : 0]);
         V3_FENCE();
-        // one memory instruction per gap: DMA piece q behind MFMA 2 q, fragment reads behind the odd MFMAs and the even ones past the DMA
-        if (!(m & 1) && (m >> 1) < MI) {
-          const int q = m >> 1;
-          if constexpr (more) V3_DMA(asrc_u, aoff[q], adst + (q * V3_THREADS + wave * 64) * 16);
-        } else {
-          const int r = (m & 1) ? (m >> 1) : NM / 2 + ((m >> 1) - MI);
-          if (r < R1) read1(r, af[par ^ 1], na, nw);
+        constexpr int kind[32] = {1, 1, 1, 1, 2, 2, 1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 0, 0};   // 1 W_lo, 2 A, 3 DMA
+        constexpr int arg[32] = {0, 1, 2, 3, 0, 1, 4, 5, 2, 3, 6, 7, 4, 5, 0, 1, 6, 7, 2, 3, 8, 9, 4, 5, 10, 11, 6, 7, 12, 13, 0, 0};
+        if (kind[m] == 1) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
+        else if (kind[m] == 2) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
+        else if (kind[m] == 3) {
+          if constexpr (more) V3_DMA(asrc_u, aoff[arg[m]], adst + (arg[m] * V3_THREADS + wave * 64) * 16);
         }
         V3_FENCE();
       }
@@ -1749,44 +1793,30 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   using F_ = std::false_type;
   int t = 0;
   if constexpr (MX) {
-    // nk = 4 G tiles, A(t) in register set t & 1; the first group's scales were requested in front of the prologue's DMA
-#pragma unroll
-    for (int r = 0; r < R1; ++r) read1(r, af[0], smem, smem_w);
+    // nk = 4 G tiles; the first group's scales were requested in front of the prologue's DMA
     auto take = [&]() {      // sc_cur <- sc_nxt (asm: the copies must not float above the wait that makes the loads' data valid)
 #pragma unroll
       for (int i = 0; i < MI; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(sc_cur[i]) : "v"(sc_nxt[i]));
+      asm volatile("s_nop 7" ::: "memory");      // VALU write -> scale operand of the next v_mfma_scale (hipcc does not pad inline asm pairs)
     };
     take();
 #pragma unroll 1
     for (; t < nk - 4; t += 4) {
-      tile(I0{}, T_{}, t, I0{}, F_{});
-      tile(I1{}, T_{}, t + 1, I1{}, T_{});
-      tile(I0{}, T_{}, t + 2, I2{}, F_{});            // its mid-tile wait leaves only W(t+4) in flight: the scale dwords have landed
-      tile(I1{}, T_{}, t + 3, I3{}, F_{});
+      tile(T_{}, t, I0{}, F_{});
+      tile(T_{}, t + 1, I1{}, T_{});
+      tile(T_{}, t + 2, I2{}, F_{});            // its mid-tile wait leaves only W(t+4) in flight: the scale dwords have landed
+      tile(T_{}, t + 3, I3{}, F_{});
       take();
     }
-    tile(I0{}, T_{}, t, I0{}, F_{});
-    tile(I1{}, T_{}, t + 1, I1{}, F_{});
-    tile(I0{}, F_{}, t + 2, I2{}, F_{});
-    tile(I1{}, F_{}, t + 3, I3{}, F_{});
+    tile(T_{}, t, I0{}, F_{});
+    tile(T_{}, t + 1, I1{}, F_{});
+    tile(F_{}, t + 2, I2{}, F_{});
+    tile(F_{}, t + 3, I3{}, F_{});
   } else {
-  // A(t) lives in register set (t + nk) & 1, so the last two tiles are always (set 0, set 1); an odd tile count peels tile 0 (set 1)
-  if (nk & 1) {
-#pragma unroll
-    for (int r = 0; r < R1; ++r) read1(r, af[1], smem, smem_w);
-    tile(I1{}, T_{}, 0, I0{}, F_{});
-    t = 1;
-  } else {
-#pragma unroll
-    for (int r = 0; r < R1; ++r) read1(r, af[0], smem, smem_w);
-  }
 #pragma unroll 1
-  for (; t < nk - 2; t += 2) {
-    tile(I0{}, T_{}, t, I0{}, F_{});
-    tile(I1{}, T_{}, t + 1, I0{}, F_{});
-  }
-  tile(I0{}, F_{}, t, I0{}, F_{});
-  tile(I1{}, F_{}, t + 1, I0{}, F_{});
+    for (; t < nk - 2; ++t) tile(T_{}, t, I0{}, F_{});
+    tile(F_{}, t, I0{}, F_{});
+    tile(F_{}, t + 1, I0{}, F_{});
   }
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
   {
@@ -1988,7 +2018,9 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
       qk = true;                                         // same kernel requirement (and the 256x256 shape: tested there)
       if (batch.p[i].out_f32 != 0 || batch.p[i].epi != EPI_NONE || (batch.p[i].w_perm16 && batch.p[i].N % 16)) return hipErrorInvalidValue;
     }
-  if (qk && !v3_ok) return hipErrorInvalidValue;        // callers ask gemm_qk_fusion_available() first
+  bool all_fp8 = batch.nprob >= 1;
+  for (int i = 0; i < batch.nprob; ++i) all_fp8 = all_fp8 && batch.p[i].fp8 != 0;
+  if (qk && !v3_ok && !all_fp8) return hipErrorInvalidValue;        // callers ask gemm_qk_fusion_available() first (fp8: checked below)
   if (v3_ok) {
     int best = 0;
     bool f32_any = false;                               // fp32-output launches: the shapes with an even number of column tiles per wave only
@@ -2054,11 +2086,12 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
       f8v3 = (e && e[0] == '0') ? 0 : 1;
     }
     bool ok = f8v3 != 0 && impl == 3 && sk_env == 0 && batch.sk_force == 0 && batch.nprob >= 1;
-    bool mx_any = false, mx_all = true, c8_any = false;
+    bool mx_any = false, mx_all = true, c8_any = false, qk_any = false;
     for (int i = 0; i < batch.nprob; ++i) {
       const GemmProblem& p = batch.p[i];
       ok = ok && p.fp8 != 0 && p.out_f32 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K % 128 == 0 && p.K >= 256 &&
-           p.qk_D == 0 && !p.w_perm16 && !p.bias_rows && p.split_k <= 1;
+           !p.w_perm16 && !p.bias_rows && p.split_k <= 1;
+      qk_any = qk_any || p.qk_D > 0;
       mx_any = mx_any || p.a_mx != nullptr;
       if (p.c8 != nullptr && (p.epi == EPI_GATE_RES || p.c8_col0 % 128 || !p.c_mx || p.ldc8 % 8 || (p.gelu_col0 != 0 && p.gelu_col0 != p.c8_col0))) return hipErrorInvalidValue;
       c8_any = c8_any || p.c8 != nullptr;
@@ -2070,8 +2103,8 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
       min_tiles = e ? atoi(e) : cus / 2;         // 216-tile launches (N = 3072): 2.1-2.2 -> 2.7 PF; below half a round the 8-phase kernel's 2 waves per SIMD win
     }
     if (mx_any && !(ok && mx_all)) return hipErrorInvalidValue;      // block scales are this kernel's format only (callers ask gemm_fp8_mx_ok() first)
-    if (c8_any && !ok) return hipErrorInvalidValue;
-    if (ok && (mx_any || c8_any || count_tiles(batch, 256, 256, false) >= min_tiles)) {
+    if ((c8_any || qk_any) && !ok) return hipErrorInvalidValue;     // (the fused q / k epilogue: this kernel only; the engine asks for it with block scales only)
+    if (ok && (mx_any || c8_any || qk_any || count_tiles(batch, 256, 256, false) >= min_tiles)) {
       const int total = count_tiles(batch, 256, 256, true);
       batch.total_tiles = total;
       if (total == 0) return hipSuccess;
