@@ -56,6 +56,14 @@ def gemm8():
         d16 = timeit(lambda: ops.linear(a, w, out=out))
         ref = a.float() @ w.float().t()
         err = ((ops.linear_fp8(aq, asc, wq, wsc).float() - ref).norm() / ref.norm()).item()
+        lt = ''
+        try:        # hipBLASLt's fp8 GEMM through torch._scaled_mm (test-side reference only; tensor-wise scales: the form every build supports)
+            one = torch.ones((), device='cuda')
+            a8, w8 = aq.view(torch.float8_e4m3fn), wq.view(torch.float8_e4m3fn)
+            dl = timeit(lambda: torch._scaled_mm(a8, w8.t(), scale_a=one, scale_b=one, out_dtype=torch.bfloat16))
+            lt = f' | torch._scaled_mm (hipBLASLt) {dl*1e6:8.1f} us {2*M*N*K/dl/1e12:7.1f} TF'
+        except Exception as e:      # noqa: BLE001
+            lt = f' | torch._scaled_mm unavailable ({type(e).__name__})'
         mx = ''
         if K % 512 == 0:
             am, ax = ops.quant_rows_mx8(a)
@@ -64,7 +72,7 @@ def gemm8():
             dqm = timeit(lambda: ops.quant_rows_mx8(a))
             em = ((ops.linear_fp8_mx(am, ax, wq, wsc).float() - ref).norm() / ref.norm()).item()
             mx = f' | block-scaled {dm*1e6:8.1f} us {2*M*N*K/dm/1e12:7.1f} TF quant {dqm*1e6:6.1f} us err {em:.2e}'
-        print(f'M={M:5d} N={N:5d} K={K:5d}  fp8 {d8*1e6:8.1f} us {2*M*N*K/d8/1e12:7.1f} TF | quant(A) {dq*1e6:6.1f} us | bf16 {d16*1e6:8.1f} us {2*M*N*K/d16/1e12:7.1f} TF | rel err {err:.2e}{mx}')
+        print(f'M={M:5d} N={N:5d} K={K:5d}  fp8 {d8*1e6:8.1f} us {2*M*N*K/d8/1e12:7.1f} TF | quant(A) {dq*1e6:6.1f} us | bf16 {d16*1e6:8.1f} us {2*M*N*K/d16/1e12:7.1f} TF | rel err {err:.2e}{mx}{lt}')
 
 
 def attn():
