@@ -1570,10 +1570,12 @@ AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
 //   phase 0   MFMAs (i, j <  NJ/2) from A(t) and W_lo(t)   | LDS: W_hi(t)               | DMA: W(t+2) -> the slot W(t-1) left
 //   mid-tile  every LDS read of tile t is done; A(t+1), W(t+1) have landed (W(t+2), just issued, may still fly)
 //   phase 1   MFMAs (i, j >= NJ/2) from A(t) and W_hi(t)   | LDS: A(t+1), W_lo(t+1)     | DMA: A(t+2) -> the slot A(t) left
-// A(t) is needed by both phases, so the A fragments are double-buffered in registers: 2 x MI x 8 (A) + NJ x 8 (W) = 192 arch VGPRs at
-// 8 x 8 beside the 256 accumulators.  Per wave and K-tile: 64 MFMAs of 32 cycles, 48 fragment reads (16 bytes), 16 DMA issues -- exactly one
-// memory instruction behind every MFMA of phase 1, one behind every second MFMA of phase 0.  A K-tile costs the matrix pipe what the bf16
-// kernel's costs and covers twice the k-values: the prologue / epilogue share of a tile's time doubles (K = 3072: 24 K-tiles).
+// A(t) is needed by both phases; phase 1 runs row tile by row tile, so row tile i's fragment of tile t+1 is read into the SAME registers right behind
+// the last MFMA of tile t that uses row tile i (the last row tile at the start of the next phase 0): MI x 8 (A) + NJ x 8 (W) = 128 arch VGPRs at
+// 8 x 8 beside the 256 accumulators.  Per wave and K-tile: 64 MFMAs of 32 cycles, 32 fragment reads (16 bytes), 16 DMA issues -- at most one
+// memory instruction behind an MFMA (the slot tables in the kernel).  A K-tile costs the matrix pipe what the bf16 kernel's costs and covers twice
+// the k-values: the prologue / epilogue share of a tile's time doubles (K = 3072: 24 K-tiles; measured 17.7 us per launch of two rounds against
+// 1.3 us per K-tile and round, tools/microbench.py).
 //
 // MX: the activation operand carries BLOCK scales instead of one fp32 scale per row (GemmProblem::a_mx: one E8M0 byte per row and K-tile,
 // i.e. per 128 k-values -- the MX layout with the block = this kernel's K-tile).  The matrix pipe applies them for free
