@@ -18,7 +18,7 @@ AFX_DT_FP8 = 3
 EXPORTS = [
     'afx_last_error', 'afx_version', 'afx_create', 'afx_destroy', 'afx_bind_weight', 'afx_finalize',
     'afx_workspace_bytes', 'afx_set_workspace', 'afx_mmdit_forward', 'afx_profile_enable', 'afx_profile_read', 'afx_set_checkpoint_buffer', 'afx_arcflow_step',
-    'afx_arcflow_velocity', 'afx_linear_bf16', 'afx_attention_ws_bytes', 'afx_attention_bf16',
+    'afx_arcflow_velocity', 'afx_linear_bf16', 'afx_attention_ws_bytes', 'afx_attention_bf16', 'afx_attention_to_mx8',
     'afx_norm_modulate_bf16', 'afx_qk_norm_rope_bf16', 'afx_gemv_bf16',
     'afx_attention_fwd_lse_bf16', 'afx_attention_bwd_ws_bytes', 'afx_attention_bwd_bf16',
     'afx_ln_modulate_backward', 'afx_qk_norm_rope_oop_bf16', 'afx_gelu_bf16', 'afx_add_scale_bf16',
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     lib.afx_attention_ws_bytes.argtypes = [i32, i32, i32]
     lib.afx_attention_ws_bytes.restype = i64
     lib.afx_attention_bf16.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.afx_attention_to_mx8.argtypes = [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp]
     lib.afx_norm_modulate_bf16.argtypes = [vp, i64, vp, i64, i32, i32, vp, vp, i64, i32, i32, vp]
     lib.afx_qk_norm_rope_bf16.argtypes = [vp, i64, vp, vp, vp, vp, i32, i32, i32, i32, vp]
     lib.afx_gemv_bf16.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]

@@ -784,7 +784,8 @@ void attn_set_impl(int impl) { attn_impl() = (impl >= 0 && impl <= 3) ? impl : 0
 
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream, float* lse) {
+                            hipStream_t stream, float* lse, const AttnMx8* mx8, bool* fused) {
+  if (fused) *fused = false;
   const int S_pad = (int)attn_spad(S);
   const int heads_per_xcd = (H + 7) / 8;
   int& impl = attn_impl();
@@ -800,7 +801,11 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
     if (r != hipSuccess) return r;
     attr = true;
   }
-  if ((impl == 0 || impl == 3) && attention_v3_eligible(S)) return launch_attention_v3(q, ldq, k, ldk, vt, o, ldo, B, H, S, stream, lse);
+  if ((impl == 0 || impl == 3) && attention_v3_eligible(S)) {
+    const bool f = mx8 != nullptr && fused != nullptr && mx8->o8 != nullptr && mx8->mx != nullptr;
+    if (f) *fused = true;
+    return launch_attention_v3(q, ldq, k, ldk, vt, o, ldo, B, H, S, stream, lse, f ? mx8 : nullptr);
+  }
   if (impl == 2 && S >= 2 * PP_QB) {
     const int nq8 = (S + PP_QB - 1) / PP_QB;
     dim3 grid8(8 * heads_per_xcd * nq8 * B);

@@ -79,7 +79,8 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 // v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
 __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                   int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
-                                                                  int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg) {
+                                                                  int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg,
+                                                                  uint8_t* __restrict__ o8, int64_t ldo8, uint8_t* __restrict__ omx, int64_t ld_omx) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,8 +253,56 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     A3_READ_##SL##_2 store_tile(SL, 2, inv, row, op);                                                              \
     A3_READ_##SL##_3 store_tile(SL, 3, inv, row, op);                                                              \
   }
-  A3_STORE_SLAB(0, lA0 + lA1, mA)
-  A3_STORE_SLAB(1, lB0 + lB1, mB)
+  // o8 != nullptr: O leaves as the next fp8 GEMM's block-scaled operand instead of bf16 (afx_common.h mx_exp / mx_inv: one E8M0 byte per row and
+  // head -- a head's 128 columns are one block; a row's values sit in the two half-waves' lanes).  Two passes over the accumulator file (the
+  // block maximum first), 8 instead of 16 bytes per lane and store, no quantisation pass behind the attention.
+  auto store_tile8 = [&](int d, float sc, int row, uint8_t* op) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int g0 = 2 * kk, g1 = 2 * kk + 1;
+      int a = 0, b_ = 0;
+      a = __builtin_amdgcn_cvt_pk_fp8_f32(ox[4 * g0 + 0] * sc, ox[4 * g0 + 1] * sc, a, false);
+      a = __builtin_amdgcn_cvt_pk_fp8_f32(ox[4 * g0 + 2] * sc, ox[4 * g0 + 3] * sc, a, true);
+      b_ = __builtin_amdgcn_cvt_pk_fp8_f32(ox[4 * g1 + 0] * sc, ox[4 * g1 + 1] * sc, b_, false);
+      b_ = __builtin_amdgcn_cvt_pk_fp8_f32(ox[4 * g1 + 2] * sc, ox[4 * g1 + 3] * sc, b_, true);
+      const auto r = __builtin_amdgcn_permlane32_swap((uint32_t)a, (uint32_t)b_, false, false);
+      if (row < S) *reinterpret_cast<u32x2_t*>(op + d * 32 + kk * 16) = (u32x2_t){r[0], r[1]};
+    }
+  };
+  auto amax16 = [&](float am) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) am = fmaxf(am, fabsf(ox[j]));
+    return am;
+  };
+#define A3_STORE_SLAB_MX8(SL, LSUM, MRUN)                                                                          \
+  {                                                                                                                \
+    const float lsum = (LSUM);                                                                                     \
+    const float l_tot = lsum + __shfl_xor(lsum, 32, 64);                                                           \
+    const float inv = 1.0f / l_tot;                                                                                \
+    const int row = q02 + (SL) * 32 + ql2;                                                                         \
+    if (lse != nullptr && hi2 == 0 && row < S) lse[((int64_t)b * H + h) * S_pad + row] = (MRUN) * c + __log2f(l_tot); \
+    float am = 0.f;                                                                                                \
+    A3_READ_##SL##_0 am = amax16(am);                                                                              \
+    A3_READ_##SL##_1 am = amax16(am);                                                                              \
+    A3_READ_##SL##_2 am = amax16(am);                                                                              \
+    A3_READ_##SL##_3 am = amax16(am);                                                                              \
+    am = fmaxf(am, __shfl_xor(am, 32, 64)) * inv;                                                                  \
+    const int eb = mx_exp(am);                                                                                     \
+    const float sc = inv * mx_inv(eb);                                                                             \
+    uint8_t* op = o8 + ((int64_t)b * S + row) * ldo8 + h * 128 + hi2 * 8;                                          \
+    A3_READ_##SL##_0 store_tile8(0, sc, row, op);                                                                  \
+    A3_READ_##SL##_1 store_tile8(1, sc, row, op);                                                                  \
+    A3_READ_##SL##_2 store_tile8(2, sc, row, op);                                                                  \
+    A3_READ_##SL##_3 store_tile8(3, sc, row, op);                                                                  \
+    if (hi2 == 0 && row < S) omx[((int64_t)b * S + row) * ld_omx + h] = (uint8_t)eb;                               \
+  }
+  if (o8 != nullptr) {        // (uniform)
+    A3_STORE_SLAB_MX8(0, lA0 + lA1, mA)
+    A3_STORE_SLAB_MX8(1, lB0 + lB1, mB)
+  } else {
+    A3_STORE_SLAB(0, lA0 + lA1, mA)
+    A3_STORE_SLAB(1, lB0 + lB1, mB)
+  }
 #ifdef AFX_ATTN_TRACE
   if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 300)) {
     unsigned* t4 = g_attn3_trace + ((blockIdx.x ? 1 : 0) * 4 + wave) * 16;
@@ -282,7 +331,10 @@ extern "C" int afx_debug_attn3_trace(unsigned* host_out) {      // [2 blocks][4 
 bool attention_v3_eligible(int S) { return S > a3::KVB; }        // >= 2 KV tiles (the pipeline's tile 0 is never the last one)
 
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
-                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse) {
+                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8) {
+  uint8_t* o8 = mx8 ? mx8->o8 : nullptr;
+  uint8_t* omx = mx8 ? mx8->mx : nullptr;
+  const int64_t ldo8 = mx8 ? mx8->ldo8 : 0, ld_omx = mx8 ? mx8->ld_mx : 0;
   static bool attr = false;
   if (!attr) {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(a3::attention_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -300,9 +352,9 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
-                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg);
+                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx);
   else
-    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg);
+    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx);
   return hipGetLastError();
 }
 

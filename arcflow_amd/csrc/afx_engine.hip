@@ -531,6 +531,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   // The fused q / k epilogue also exists on the one-wave-per-SIMD fp8 kernel (epi_store_qk<MI, true>; V is then transposed by its own launch), opt-in:
   // measured level with the separate preparation launch (11.30 vs 11.30 images/s) -- with 256 accumulators in the file the fp8 variant of that epilogue
   // has to re-read the weight scales per row tile, which costs what the saved launch gave (AFX_FP8_QK_FUSE=1).
+  const bool attn_mx = mx && H * 128 == D && getenv("AFX_FP8_ATTN_MX_OFF") == nullptr;      // the attention epilogue as the last producer of the format
   const char* qkf8 = getenv("AFX_FP8_QK_FUSE");
   const bool qk_fuse_fp8 = mx && qkf8 != nullptr && qkf8[0] == '1';
   // helper: one grouped GEMM over the image and text row ranges of every sample
@@ -646,9 +647,11 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     else
     HIP_TRY(launch_kv_prep(QKV, QKV + 2 * D, 3 * D, qkn + 3 * 128, qkn + 1 * 128, qkn + 2 * 128, qkn, rope_cos, rope_sin, T, QKV + D,
                            3 * D, ws.Vt, B, H, S, st));
+    bool o_fused = false;            // mx: the attention kernel wrote the out-projection's operand itself (q8n / mxn)
+    const AttnMx8 omx_d{ws.q8n, D, ws.mxn, ws.ld_mxn};
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
-      HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st)); }
-    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2))) return rc;
+      HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st, nullptr, attn_mx ? &omx_d : nullptr, &o_fused)); }
+    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2, nullptr, o_fused ? 2 : 0))) return rc;
     if ((rc = stream_norm(i, 3, 4))) return rc;
     if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0, nullptr, norm_fused ? 2 : 0, mx))) return rc;      // (mx: the hidden leaves as the next GEMM's operand, Hb stays unwritten)
     if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5, nullptr, mx ? 1 : 0))) return rc;
@@ -707,8 +710,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     else
     HIP_TRY(launch_kv_prep(ws.F, ws.F + 2 * D, 7 * D, qkn + 128, qkn + 128, qkn, qkn, rope_cos, rope_sin, T, ws.F + D, 7 * D, ws.Vt, B,
                            H, S, st));
+    bool o_fused = false;            // mx: ... columns [0, D) of the [O | mlp] operand (q8 / mxw)
+    const AttnMx8 omx_s{ws.q8, 5 * D, ws.mxw, ws.ld_mxw};
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
-      HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st)); }
+      HIP_TRY(launch_attention(ws.F + 2 * D, 7 * D, ws.F, 7 * D, ws.Vt, ws.F + 2 * D, 7 * D, B, H, S, st, nullptr, attn_mx ? &omx_s : nullptr, &o_fused)); }
     GemmBatch go{};
     go.nprob = 1;
     GemmProblem& o = go.p[0];
@@ -717,7 +722,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     o.C = ws.X; o.ldc = D; o.M = (int)R; o.N = (int)D; o.K = (int)(5 * D); o.epi = EPI_GATE_RES;
     o.gate = ws.mod + ml.sgl(i, 2); o.ldg = ldm; o.rows_per_batch = S; o.res = ws.X; o.ldr = D;
     if (mx) {             // the attention output joins the mlp columns the projection's epilogue left in q8
-      HIP_TRY(launch_quant_rows_mx8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.mxw, ws.ld_mxw, (int)R, (int)D, st));
+      if (!o_fused) HIP_TRY(launch_quant_rows_mx8(ws.F + 2 * D, 7 * D, ws.q8, 5 * D, ws.mxw, ws.ld_mxw, (int)R, (int)D, st));
       o.A = (const uint16_t*)ws.q8; o.lda = 5 * D; o.W = (const uint16_t*)bw.out.wq; o.fp8 = 1; o.a_scale = ws.ones; o.w_scale = bw.out.wscale;
       o.a_mx = ws.mxw; o.ld_mx = ws.ld_mxw;
     } else if (c->fp8) {
@@ -1092,6 +1097,20 @@ int afx_attention_fwd_lse_bf16(const void* q, int64_t ldq, const void* k, int64_
   HIP_TRY(launch_v_transpose((const uint16_t*)v, ldv, (uint16_t*)vt_ws, batch, heads, S, (hipStream_t)stream));
   HIP_TRY(launch_attention((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)vt_ws, (uint16_t*)o, ldo,
                            batch, heads, S, (hipStream_t)stream, lse));
+  return AFX_OK;
+}
+
+int afx_attention_to_mx8(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o8, int64_t ldo8,
+                         void* mx, int64_t ld_mx, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream) {
+  if (!q || !k || !v || !o8 || !mx || !vt_ws) return fail(AFX_E_INVALID, "null argument to afx_attention_to_mx8");
+  if (batch < 1 || heads < 1 || S < 1 || ldq % 8 || ldk % 8 || ldv % 8 || ldo8 % 8 || ld_mx < heads) return fail(AFX_E_INVALID, "bad attention shape / stride");
+  if (!attention_v3_eligible(S)) return fail(AFX_E_INVALID, "afx_attention_to_mx8: S > 64 (the one-wave-per-SIMD kernel's epilogue)");
+  HIP_TRY(launch_v_transpose((const uint16_t*)v, ldv, (uint16_t*)vt_ws, batch, heads, S, (hipStream_t)stream));
+  const AttnMx8 m{(uint8_t*)o8, ldo8, (uint8_t*)mx, ld_mx};
+  bool fused = false;
+  HIP_TRY(launch_attention((const uint16_t*)q, ldq, (const uint16_t*)k, ldk, (const uint16_t*)vt_ws, nullptr, 0, batch, heads, S, (hipStream_t)stream,
+                           nullptr, &m, &fused));
+  if (!fused) return fail(AFX_E_INVALID, "afx_attention_to_mx8: the one-wave-per-SIMD attention kernel is switched off (AFX_ATTN_IMPL)");
   return AFX_OK;
 }
 

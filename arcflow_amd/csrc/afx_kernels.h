@@ -101,13 +101,17 @@ int& last_sk_cus();
 // vt: [B, H, 128, S_pad] transposed + key-permuted V (see afx_attn.hip); S_pad = roundup(S, 64)
 hipError_t launch_v_transpose(const uint16_t* v, int64_t ldv, uint16_t* vt, int B, int H, int S,
                               hipStream_t stream);
+// mx8 (fp8 engine path): the output leaves as the next fp8 GEMM's block-scaled operand -- e4m3 bytes in o8[token][head * 128 + .] (row stride ldo8) and
+// one E8M0 byte per token and head in mx[token][head] -- INSTEAD of bf16 `o`, when the one-wave-per-SIMD kernel takes the launch (*fused = true);
+// otherwise bf16 `o` is written as always and *fused = false (the caller then quantises it).
+struct AttnMx8 { uint8_t* o8; int64_t ldo8; uint8_t* mx; int64_t ld_mx; };
 hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk,
                             const uint16_t* vt, uint16_t* o, int64_t ldo, int B, int H, int S,
-                            hipStream_t stream, float* lse = nullptr);
+                            hipStream_t stream, float* lse = nullptr, const AttnMx8* mx8 = nullptr, bool* fused = nullptr);
 // one-wave-per-SIMD kernel (afx_attn3.hip): any S > 64 (ragged tails handled); launch_attention dispatches to it (AFX_ATTN_IMPL=1 / attn_set_impl(1): 4-wave kernel)
 bool attention_v3_eligible(int S);
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
-                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse);
+                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8 = nullptr);
 void attn_set_impl(int impl);               // 0 = default (v3 where eligible), 1 = 4-wave kernel, 2 = 8-wave ping-pong (experimental), 3 = v3
 // K, Q <- RoPE(RMSNorm(.) w) in place (same row stride) and V -> V^T (key-permuted), one launch
 hipError_t launch_kv_prep(uint16_t* k, uint16_t* q, int64_t ldk, const float* wk_txt, const float* wk_img, const float* wq_txt,

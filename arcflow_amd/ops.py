@@ -102,6 +102,19 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor
     return o.reshape(B, S, H * Dh)
 
 
+def attention_to_mx8(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor):
+    """``attention`` with the output as a block-scaled fp8 operand: (uint8 [B*S, H*128] e4m3, uint8 [B*S, H] E8M0 -- one scale per token and head)."""
+    lib = _lib.load()
+    B, S, H, Dh = q.shape
+    assert Dh == 128 and q.dtype == torch.bfloat16
+    q2, k2, v2 = (t.reshape(B * S, H * Dh) for t in (q.contiguous(), k.contiguous(), v.contiguous()))
+    o8 = torch.empty(B * S, H * Dh, dtype=torch.uint8, device=q.device)
+    mx = torch.empty(B * S, (H + 3) // 4 * 4, dtype=torch.uint8, device=q.device)
+    ws = torch.empty(lib.afx_attention_ws_bytes(B, H, S), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.afx_attention_to_mx8(_p(q2), H * Dh, _p(k2), H * Dh, _p(v2), H * Dh, _p(o8), H * Dh, _p(mx), mx.stride(0), _p(ws), B, H, S, _s()))
+    return o8, mx[:, :H]
+
+
 def norm_modulate(x: torch.Tensor, scale: torch.Tensor, shift: Optional[torch.Tensor], rows_per_batch: int = 0,
                   rms: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x [R,D] bf16; AdaLN: scale/shift [B,D] f32 (row r uses batch r // rows_per_batch);

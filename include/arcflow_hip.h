@@ -425,6 +425,10 @@ int64_t afx_attention_ws_bytes(int32_t batch, int32_t heads, int32_t S);
 int afx_attention_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v,
                        int64_t ldv, void* o, int64_t ldo, void* vt_ws,
                        int32_t batch, int32_t heads, int32_t S, void* stream);
+/* The same attention with the output as the next fp8 GEMM's block-scaled operand (afx_quant_rows_mx8's layout; a head's 128 columns = one block):
+ * o8 [batch * S, ldo8] e4m3 bytes, mx [batch * S, ld_mx] one E8M0 byte per token and head.  S > 64.  vt_ws as afx_attention_bf16. */
+int afx_attention_to_mx8(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o8, int64_t ldo8,
+                         void* mx, int64_t ld_mx, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream);
 
 /* Training twins: forward that also returns lse [B, H, roundup(S,64)] f32 (log2-domain log-sum-exp of the scaled
  * scores; the caller pre-fills it with +inf so padded queries drop out), and the backward producing dq, dk, dv

@@ -520,6 +520,26 @@ def test_fp8_gemm_writes_block_scaled_operand(M, N, K, col0, gelu):
         assert ((z.float() - zref).norm() / zref.norm()).item() < 4e-3
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,S,H', [(1, 4608, 3), (2, 333, 2)])
+def test_attention_writes_block_scaled_operand(B, S, H):
+    """The attention epilogue as a producer of the fp8 format: e4m3 bytes + one E8M0 byte per token and head, against the quantiser applied to the
+    kernel's own bf16 output (scale bytes equal except where the bf16 rounding of the block maximum crosses a power of two; values equal to e4m3
+    resolution) -- ragged S included."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(13)
+    q, k, v = ((torch.randn(B, S, H, 128, generator=g) * s).bfloat16().cuda() for s in (1.0, 1.0, 2.0))
+    o = ops.attention(q, k, v).reshape(B * S, H * 128)
+    o8, mx = ops.attention_to_mx8(q, k, v)
+    rq, rmx = ops.quant_rows_mx8(o)
+    assert (mx != rmx).float().mean().item() < 0.02
+    deq = (o8.view(torch.float8_e4m3fn).float().view(B * S, H, 128) * torch.exp2(mx.float() - 127)[..., None]).view(B * S, H * 128)
+    assert ((deq - o.float()).norm() / o.float().norm()).item() < 4.5e-2
+    assert (deq - o.float()).abs().max().item() <= 0.0625 * o.float().abs().max().item() + 1e-3
+    same = mx == rmx
+    assert (o8.view(B * S, H, 128)[same] != rq.view(B * S, H, 128)[same]).float().mean().item() < 0.08     # the bf16 detour moves a value across an e4m3 rounding boundary now and then
+
+
 # ------------------------------------------------------------------------------------------ stream-K tail of the GEMM
 @pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 3072, 15360), (4608, 9216, 3072), (4608, 12288, 3072),
                                    (2048, 1024, 512), (4608, 21504, 3072)])
