@@ -1652,11 +1652,10 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
   // ---- MX: scale bytes of this lane's MI row tiles, 4 K-tiles per dword --------------------------------------------------------
-  // scale of the weight operand: 2^0 in every byte.  OPAQUE (asm-defined): as a plain constant hipcc re-materialises it with a v_mov right in front of
-  // the first MFMA of a tile, and a VALU write -> v_mfma_scale scale-operand read needs wait states its hazard recogniser does not add (seen as ONE
-  // wrong 16x16 tile per wave: row tile 0 x column tile 0).
+  // scale of the weight operand: 2^0 in every byte.  OPAQUE (asm-defined): a plain constant may be re-materialised by a v_mov right in front of an
+  // MFMA, and hipcc's hazard recogniser does not pad a VALU write -> scale-operand read when the reader is inline asm.
   int mx_one;
-  asm volatile("v_mov_b32 %0, 0x7f7f7f7f\n\ts_nop 7" : "=v"(mx_one));
+  asm volatile("v_mov_b32 %0, 0x7f7f7f7f\n\ts_nop 7\n\ts_nop 7" : "=v"(mx_one));
   uint32_t sc_cur[MX ? MI : 1], sc_nxt[MX ? MI : 1];
   u32x4_t mx_rsrc = (u32x4_t){0u, 0u, 0u, 0u};
   uint32_t mx_voff = 0;
@@ -1799,7 +1798,8 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
     auto take = [&]() {      // sc_cur <- sc_nxt (asm: the copies must not float above the wait that makes the loads' data valid)
 #pragma unroll
       for (int i = 0; i < MI; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(sc_cur[i]) : "v"(sc_nxt[i]));
-      asm volatile("s_nop 7" ::: "memory");      // VALU write -> scale operand of the next v_mfma_scale (hipcc does not pad inline asm pairs)
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // VALU write -> scale operand of the next v_mfma_scale: hipcc does not pad inline-asm pairs, and the
+                                                         // wait states this pair needs are not documented here -- 16, once per 4 K-tiles
     };
     take();
 #pragma unroll 1
