@@ -324,6 +324,7 @@ int afx_linear_fp8_to_mx8(const void* Aq, int64_t lda, const void* a_mx, int64_t
   if (M < 0 || N < 0 || K < 256 || K % 128 || N % 8 || lda % 16 || ldw % 16 || ldc % 8 || ldc8 % 8 || c8_col0 < 0 || c8_col0 % 128 || c8_col0 >= N ||
       ld_cmx < (N - c8_col0 + 127) / 128 || (a_mx && (K % 512 || ld_mx % 4 || ld_mx < K / 128)))
     return fail(AFX_E_INVALID, "afx_linear_fp8_to_mx8: need K%%128==0 (K%%512==0 with block-scaled A), c8_col0%%128==0, ldc8%%8==0");
+  // (the producer epilogue lives in the one-wave-per-SIMD fp8 kernel: the same switches as the block-scaled consumer; K % 512 only binds with a_mx)
   if (!gemm_fp8_mx_ok(M, N, a_mx ? K : 512)) return fail(AFX_E_INVALID, "afx_linear_fp8_to_mx8: the one-wave-per-SIMD fp8 kernel is switched off");
   GemmBatch gb{};
   gb.nprob = 1;
