@@ -92,12 +92,15 @@ __global__ __launch_bounds__(256) void norm_modulate_kernel(
 // differs from the previous one's.  The next row's chunks are requested before the current one is reduced.  Same arithmetic, same order: bit-identical.
 // MX8: the row leaves as the next fp8 GEMM's block-scaled operand instead of bf16 (afx_common.h mx_exp / mx_pack8; a lane's chunk i and its 15
 // neighbours are one 128-column block): e4m3 bytes to q8[row][.] and one E8M0 byte per block to mx[row][.] -- no quantisation pass behind the LayerNorm.
-template <int NCH, int R, bool MX8 = false>
+// QOUT 2: e4m3 bytes with ONE fp32 scale per row (absmax / 448, afx_quant_rows_fp8's format) to q8 / rowscale: a LayerNorm row sits in one wave, so the
+// row-wise format is as cheap here as the block-wise one -- and its consumer is the plain fp8 MFMA (the scaled one costs 3-7 % per GEMM).
+template <int NCH, int R, int QOUT = 0>
 __global__ __launch_bounds__(256) void norm_modulate_rows_kernel(
     const bf16_t* __restrict__ x, int64_t ldx, bf16_t* __restrict__ out, int64_t ldo, int rows,
     const float* __restrict__ scale, const float* __restrict__ shift, int64_t ldmod, int rows_per_batch,
     const float* __restrict__ scale_txt, const float* __restrict__ shift_txt, int n_txt, uint8_t* __restrict__ q8 = nullptr, int64_t ldq = 0,
-    uint8_t* __restrict__ mx = nullptr, int64_t ld_mx = 0) {
+    uint8_t* __restrict__ mx = nullptr, int64_t ld_mx = 0, float* __restrict__ rowscale = nullptr) {
+  constexpr bool MX8 = QOUT == 1;
   constexpr int D = 512 * NCH;
   const int lane = threadIdx.x & 63;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -159,6 +162,27 @@ __global__ __launch_bounds__(256) void norm_modulate_rows_kernel(
     q = wave_sum(q);
     const float rstd = rsqrtf(q / (float)D + 1e-6f);
     bf16_t* orow = out + (int64_t)row * ldo;
+    if constexpr (QOUT == 2) {
+      float amax = 0.f;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[i][e] = (v[i][e] - mean) * rstd * sc[i][e] + sh[i][e];
+          amax = fmaxf(amax, fabsf(v[i][e]));
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+      const float s_ = fmaxf(amax, 1e-12f) / 448.0f;
+      const float inv = 1.0f / s_;
+      if (lane == 0) rowscale[row] = s_;
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        uint32_t w0, w1;
+        mx_pack8(v[i], inv, w0, w1);
+        *reinterpret_cast<u32x2_t*>(q8 + (int64_t)row * ldq + (lane + i * 64) * 8) = (u32x2_t){w0, w1};
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
       float r[8];
@@ -195,21 +219,26 @@ static int nm_rows_per_wave() {
 // true when the multi-row kernel took the launch
 static bool launch_norm_modulate_rows(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
                                       const float* shift, int64_t ldmod, int rows_per_batch, const float* scale_txt, const float* shift_txt,
-                                      int n_txt, hipStream_t stream, uint8_t* q8 = nullptr, int64_t ldq = 0, uint8_t* mx = nullptr, int64_t ld_mx = 0) {
+                                      int n_txt, hipStream_t stream, uint8_t* q8 = nullptr, int64_t ldq = 0, uint8_t* mx = nullptr, int64_t ld_mx = 0,
+                                      float* rowscale = nullptr) {
   const int R = nm_rows_per_wave();
   if (D != 3072 || rows < 1024 || (R != 2 && R != 4)) return false;
   const dim3 grid((rows + 4 * R - 1) / (4 * R));
   if (q8 != nullptr) {
     if (R != 2) return false;
-    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2, true>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
-                       scale_txt, shift_txt, n_txt, q8, ldq, mx, ld_mx);
+    if (rowscale != nullptr)
+      hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2, 2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+                         scale_txt, shift_txt, n_txt, q8, ldq, (uint8_t*)nullptr, (int64_t)0, rowscale);
+    else
+      hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2, 1>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+                         scale_txt, shift_txt, n_txt, q8, ldq, mx, ld_mx, (float*)nullptr);
     return true;
   }
   if (R == 2)
-    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 2, 0>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
                        scale_txt, shift_txt, n_txt);
   else
-    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 4>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
+    hipLaunchKernelGGL((norm_modulate_rows_kernel<6, 4, 0>), grid, dim3(256), 0, stream, x, ldx, out, ldo, rows, scale, shift, ldmod, rows_per_batch,
                        scale_txt, shift_txt, n_txt);
   return true;
 }
@@ -228,12 +257,14 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
   return hipGetLastError();
 }
 
-// LN + modulate straight into the next fp8 GEMM's block-scaled operand (q8 [rows, ldq] e4m3, mx [rows, ld_mx] E8M0 bytes; scale_txt may be null:
-// one stream).  *fused = false: this shape has no fused kernel, nothing was launched -- the caller runs the bf16 kernel and afx_quant_rows_mx8.
+// LN + modulate straight into the next fp8 GEMM's operand (q8 [rows, ldq] e4m3; scale_txt may be null: one stream) -- block-scaled (mx [rows, ld_mx]
+// E8M0 bytes) or, with rowscale != nullptr, one fp32 scale per row (rowscale [rows]; mx unused).  *fused = false: this shape has no fused kernel,
+// nothing was launched -- the caller runs the bf16 kernel and a quantisation pass.
 hipError_t launch_norm_modulate_mx8(const uint16_t* x, int64_t ldx, uint8_t* q8, int64_t ldq, uint8_t* mx, int64_t ld_mx, int rows, int D,
                                     const float* scale, const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
-                                    int n_txt, hipStream_t stream, bool* fused) {
-  *fused = rows > 0 && launch_norm_modulate_rows(x, ldx, nullptr, 0, rows, D, scale, shift, ldmod, S, scale_txt, shift_txt, n_txt, stream, q8, ldq, mx, ld_mx);
+                                    int n_txt, hipStream_t stream, bool* fused, float* rowscale) {
+  *fused = rows > 0 && launch_norm_modulate_rows(x, ldx, nullptr, 0, rows, D, scale, shift, ldmod, S, scale_txt, shift_txt, n_txt, stream, q8, ldq, mx, ld_mx,
+                                                 rowscale);
   return hipGetLastError();
 }
 

@@ -531,6 +531,9 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   // The fused q / k epilogue also exists on the one-wave-per-SIMD fp8 kernel (epi_store_qk<MI, true>; V is then transposed by its own launch), opt-in:
   // measured level with the separate preparation launch (11.30 vs 11.30 images/s) -- with 256 accumulators in the file the fp8 variant of that epilogue
   // has to re-read the weight scales per row tile, which costs what the saved launch gave (AFX_FP8_QK_FUSE=1).
+  // LayerNorm-produced operands (a row sits in one wave there) carry ONE scale per row and run on the plain fp8 MFMA; only the operands written by
+  // GEMM / attention epilogues need block scales (AFX_FP8_NORM_MX=1: block scales everywhere, A/B)
+  const bool norm_rows = mx && getenv("AFX_FP8_NORM_MX") == nullptr;
   const bool attn_mx = mx && H * 128 == D && getenv("AFX_FP8_ATTN_MX_OFF") == nullptr;      // the attention epilogue as the last producer of the format
   const char* qkf8 = getenv("AFX_FP8_QK_FUSE");
   const bool qk_fuse_fp8 = mx && qkf8 != nullptr && qkf8[0] == '1';
@@ -565,7 +568,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       }
     }
   };
-  // mx_in: 0 = quantise A here; 1 = A is the wide operand a previous epilogue left in q8 / mxw; 2 = the LayerNorm kernel left it in q8n / mxn.
+  // mx_in: 0 = quantise A here; 1 = A is the wide operand a previous epilogue left in q8 / mxw; 2 = the LayerNorm kernel left it in q8n (+ qs: one scale
+  // per row, or + mxn with AFX_FP8_NORM_MX); 3 = the attention kernel left it in q8n / mxn.
   // mx_out: this GEMM's epilogue writes the wide operand.
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
                          int blk, int gate_chunk, const float* qkn = nullptr, int mx_in = 0, bool mx_out = false) -> int {
@@ -581,7 +585,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         p.W = lw[s].w; p.ldw = K; p.bias = lw[s].b;
         if (mx) {
           p.W = (const uint16_t*)lw[s].wq; p.fp8 = 1; p.a_scale = ws.ones + row0; p.w_scale = lw[s].wscale; p.lda = K;
-          if (mx_in != 1) { p.A = (const uint16_t*)(ws.q8n + row0 * K); p.a_mx = ws.mxn + row0 * ws.ld_mxn; p.ld_mx = ws.ld_mxn; }
+          if (mx_in == 2 && norm_rows) { p.A = (const uint16_t*)(ws.q8n + row0 * K); p.a_scale = ws.qs + row0; }      // LayerNorm rows: one scale per row, the plain fp8 MFMA
+          else if (mx_in != 1) { p.A = (const uint16_t*)(ws.q8n + row0 * K); p.a_mx = ws.mxn + row0 * ws.ld_mxn; p.ld_mx = ws.ld_mxn; }
           else { p.A = (const uint16_t*)(ws.q8 + row0 * K); p.a_mx = ws.mxw + row0 * ws.ld_mxw; p.ld_mx = ws.ld_mxw; }
           if (mx_out) { p.c8 = ws.q8 + row0 * Nout; p.ldc8 = Nout; p.c_mx = ws.mxw + row0 * ws.ld_mxw; p.ld_cmx = ws.ld_mxw; p.c8_col0 = 0; }
         } else if (c->fp8) {
@@ -611,7 +616,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if (mx) {
       HIP_TRY(launch_norm_modulate_mx8(ws.X, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
                                        ws.mod + ml.dbl(blk, 0, shift_chunk), ws.mod + ml.dbl(blk, 1, scale_chunk),
-                                       ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, (int)S, T, st, &norm_fused));
+                                       ws.mod + ml.dbl(blk, 1, shift_chunk), ldm, (int)S, T, st, &norm_fused, norm_rows ? ws.qs : nullptr));
       if (norm_fused) return AFX_OK;
     }
     HIP_TRY(launch_norm_modulate_joint(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.dbl(blk, 0, scale_chunk),
@@ -651,7 +656,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     const AttnMx8 omx_d{ws.q8n, D, ws.mxn, ws.ld_mxn};
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
       HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st, nullptr, attn_mx ? &omx_d : nullptr, &o_fused)); }
-    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2, nullptr, o_fused ? 2 : 0))) return rc;
+    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2, nullptr, o_fused ? 3 : 0))) return rc;
     if ((rc = stream_norm(i, 3, 4))) return rc;
     if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0, nullptr, norm_fused ? 2 : 0, mx))) return rc;      // (mx: the hidden leaves as the next GEMM's operand, Hb stays unwritten)
     if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5, nullptr, mx ? 1 : 0))) return rc;
@@ -666,7 +671,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
       HIP_TRY(hipMemcpyAsync(c->ckpt + (int64_t)(d.num_double + i) * R * D, ws.X, (size_t)R * D * 2, hipMemcpyDeviceToDevice, st));
     bool sgl_fused = false;
     if (mx) HIP_TRY(launch_norm_modulate_mx8(ws.X, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0),
-                                             nullptr, nullptr, ldm, (int)S, 0, st, &sgl_fused));
+                                             nullptr, nullptr, ldm, (int)S, 0, st, &sgl_fused, norm_rows ? ws.qs : nullptr));
     if (!sgl_fused) HIP_TRY(launch_norm_modulate(ws.X, D, ws.Xn, D, (int)R, (int)D, ws.mod + ml.sgl(i, 1), ws.mod + ml.sgl(i, 0), ldm, S, 0, st));
     GemmBatch gb{};
     gb.nprob = 1;
@@ -677,7 +682,8 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     if (mx) {             // A: the LayerNorm rows, block-scaled; the mlp columns leave as columns [D, 5D) of the proj_out operand
       if (!sgl_fused) HIP_TRY(launch_quant_rows_mx8(ws.Xn, D, ws.q8n, D, ws.mxn, ws.ld_mxn, (int)R, (int)D, st));
       f.A = (const uint16_t*)ws.q8n; f.W = (const uint16_t*)bw.fused.wq; f.fp8 = 1; f.a_scale = ws.ones; f.w_scale = bw.fused.wscale;
-      f.a_mx = ws.mxn; f.ld_mx = ws.ld_mxn;
+      if (sgl_fused && norm_rows) f.a_scale = ws.qs;      // the LayerNorm kernel wrote one scale per row: the plain fp8 MFMA
+      else { f.a_mx = ws.mxn; f.ld_mx = ws.ld_mxn; }
       f.c8 = ws.q8 + D; f.ldc8 = 5 * D; f.c_mx = ws.mxw + D / 128; f.ld_cmx = ws.ld_mxw; f.c8_col0 = (int)(3 * D);
     } else if (c->fp8) {
       HIP_TRY(launch_quant_rows_fp8(ws.Xn, D, ws.q8, D, ws.qs, (int)R, (int)D, st));

@@ -140,7 +140,7 @@ hipError_t launch_norm_modulate(const uint16_t* x, int64_t ldx, uint16_t* out, i
                                 int rows_per_batch, int rms, hipStream_t stream);
 hipError_t launch_norm_modulate_mx8(const uint16_t* x, int64_t ldx, uint8_t* q8, int64_t ldq, uint8_t* mx, int64_t ld_mx, int rows, int D,
                                     const float* scale, const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
-                                    int n_txt, hipStream_t stream, bool* fused);
+                                    int n_txt, hipStream_t stream, bool* fused, float* rowscale = nullptr);
 hipError_t launch_norm_modulate_joint(const uint16_t* x, int64_t ldx, uint16_t* out, int64_t ldo, int rows, int D, const float* scale,
                                       const float* shift, const float* scale_txt, const float* shift_txt, int64_t ldmod, int S,
                                       int n_txt, hipStream_t stream);
