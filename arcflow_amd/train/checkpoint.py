@@ -19,6 +19,7 @@ from __future__ import annotations
 
 import json
 import os
+import threading
 import time
 import warnings
 from dataclasses import dataclass
@@ -102,8 +103,8 @@ def build_checkpoint(distiller, fp16: bool = True, fp16_ema: bool = False, save_
     state = {}
     for prefix, flat, half in ((LIVE_PREFIX, distiller.params, fp16), (EMA_PREFIX, distiller.ema, fp16_ema)):
         for k, v in flat_to_state(flat, lay, peft_names=True).items():
-            v = v.detach().to('cpu', copy=True)
-            state[prefix + k] = v.half() if half else v
+            v = v.detach()
+            state[prefix + k] = (v.half() if half else v).to('cpu', copy=True)      # (rounded on the device: half the transfer, no host-side conversion loop)
     m = dict(meta or {})
     m.update(iter=distiller.iteration, epoch=1, time=time.asctime(), writer='arcflow_amd')
     ckpt = {'meta': m, 'state_dict': state}
@@ -129,6 +130,50 @@ def save_checkpoint(distiller, out_dir: str, filename_tmpl: str = 'iter_{}.pth',
         if os.path.lexists(link):
             os.remove(link)
         os.symlink(os.path.basename(path), link)
+    return path
+
+
+_pending_save: Optional[threading.Thread] = None
+_pending_error: List[BaseException] = []
+
+
+def wait_pending_save() -> None:
+    """Block until a background save started by ``save_checkpoint_async`` has reached the disk (re-raises its error)."""
+    global _pending_save
+    if _pending_save is not None:
+        _pending_save.join()
+        _pending_save = None
+    if _pending_error:
+        raise _pending_error.pop()
+
+
+def save_checkpoint_async(distiller, out_dir: str, filename_tmpl: str = 'iter_{}.pth', create_symlink: bool = True, **kw) -> str:
+    """``save_checkpoint`` with the file write off the training loop: the state is copied to host memory here (that part synchronises the device:
+    ~1 s for the Qwen-Image adapter set), pickling and the ~6 GB write run in a thread.  The file appears under its final name only when complete
+    (written as ``*.tmp``, then renamed), ``latest.pth`` moves after that; a second save waits for the first; call ``wait_pending_save()`` before exit."""
+    global _pending_save
+    wait_pending_save()
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, filename_tmpl.format(distiller.iteration))
+    ckpt = build_checkpoint(distiller, **kw)
+
+    def work():
+        try:
+            tmp = path + '.tmp'
+            with open(tmp, 'wb') as f:
+                torch.save(ckpt, f)
+                f.flush()
+            os.replace(tmp, path)
+            if create_symlink:
+                link = os.path.join(out_dir, 'latest.pth')
+                if os.path.lexists(link):
+                    os.remove(link)
+                os.symlink(os.path.basename(path), link)
+        except BaseException as e:      # noqa: BLE001  (handed to the training thread by wait_pending_save)
+            _pending_error.append(e)
+
+    _pending_save = threading.Thread(target=work, name='arcflow-checkpoint-writer')
+    _pending_save.start()
     return path
 
 

@@ -109,6 +109,27 @@ def test_checkpoint_resume_is_exact(tmp_path):
 
 
 @pytest.mark.gpu
+def test_background_save_snapshots_the_state_at_call_time(tmp_path):
+    """``save_checkpoint_async`` (tools/train.py): the file written by the thread holds the state of the moment of the call -- training goes on
+    while it is written -- appears under its final name only when complete, and equals what the synchronous writer stores."""
+    a, _ = _tiny_distiller()
+    rng = torch.Generator(device='cuda').manual_seed(5)
+    a.train_step(_cond(), 2, rng=rng)
+    ref = CK.build_checkpoint(a, fp16=False)
+    path = CK.save_checkpoint_async(a, str(tmp_path), fp16=False)
+    a.train_step(_cond(seed=3), 2, rng=rng)               # the live state moves on while the writer runs
+    CK.wait_pending_save()
+    assert os.path.basename(path) == 'iter_1.pth' and os.path.exists(path) and not os.path.exists(path + '.tmp')
+    assert os.readlink(tmp_path / 'latest.pth') == 'iter_1.pth'
+    got = torch.load(path, map_location='cpu', weights_only=False)
+    assert got['meta']['iter'] == 1 and set(got['state_dict']) == set(ref['state_dict'])
+    for k, v in ref['state_dict'].items():
+        assert torch.equal(got['state_dict'][k], v), k
+    live = CK.build_checkpoint(a, fp16=False)['state_dict']
+    assert any(not torch.equal(live[k], ref['state_dict'][k]) for k in live)          # ... and it really did move on
+
+
+@pytest.mark.gpu
 def test_adamw8bit_distiller_first_step_equals_fp32_and_resumes_exactly(tmp_path):
     """`optimizer='adamw8bit'` (the reference's bitsandbytes class, _ddp_train.py:18-26): block-wise 8-bit moments for the groups of
     >= 4096 values, fp32 for the small ones.  The parameter update uses the un-quantised new moments, so the FIRST step from

@@ -160,9 +160,10 @@ def main():
             t_last = now
         if dist_.iteration % run['save_interval'] == 0 or dist_.iteration == total:
             dist_.reducer.check_consistent(dist_.params)      # every rank took the same optimizer steps: raises before a diverged state is saved
-            if rank == 0:
-                path = checkpoint.save_checkpoint(dist_, ckpt_dir, fp16=run['ckpt_fp16'], fp16_ema=run['ckpt_fp16_ema'])
-                print(f'[train] saved {path}', flush=True)
+            if rank == 0:       # host copy here, pickling + the file write in a thread (the Qwen-Image adapter set is ~6 GB: 14 s of disk time per save)
+                path = checkpoint.save_checkpoint_async(dist_, ckpt_dir, fp16=run['ckpt_fp16'], fp16_ema=run['ckpt_fp16_ema'])
+                print(f'[train] saving {path}', flush=True)
+    checkpoint.wait_pending_save()
     if args.export and rank == 0:
         print('[train] exported', checkpoint.export_adapter(dist_, args.export, ema=True, policy_kwargs=run['policy_kwargs']))
     if pg is not None:
