@@ -792,7 +792,7 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
   static bool attr = false;
   if (impl < 0) {
     // AFX_ATTN_IMPL / attn_set_impl: 0 (default) = the one-wave-per-SIMD kernel (afx_attn3.hip) where eligible, else the 4-wave kernel;
-    // 1 = 4-wave kernel always; 2 = the 8-wave ping-pong kernel (experimental, see its header); 3 = as 0
+    // 1 = 4-wave kernel always; 2 = the 8-wave ping-pong kernel (experimental, see its header); 3 = as 0 on the plain grid (no KV-split of the last round)
     const char* e = getenv("AFX_ATTN_IMPL");
     impl = (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 0;
   }
@@ -804,7 +804,7 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
   if ((impl == 0 || impl == 3) && attention_v3_eligible(S)) {
     const bool f = mx8 != nullptr && fused != nullptr && mx8->o8 != nullptr && mx8->mx != nullptr;
     if (f) *fused = true;
-    return launch_attention_v3(q, ldq, k, ldk, vt, o, ldo, B, H, S, stream, lse, f ? mx8 : nullptr);
+    return launch_attention_v3(q, ldq, k, ldk, vt, o, ldo, B, H, S, stream, lse, f ? mx8 : nullptr, impl == 0);
   }
   if (impl == 2 && S >= 2 * PP_QB) {
     const int nq8 = (S + PP_QB - 1) / PP_QB;

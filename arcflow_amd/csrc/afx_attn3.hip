@@ -31,7 +31,12 @@
 //     slots are immediates of the ds_read / M0 offsets (no address arithmetic in the loop).
 //   * the O rescale is deferred (row max grown by more than 2^5, as in the 4-wave kernel) and lives on a cold path
 //     (accumulator-file reads / writes with explicit wait states).
+#include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 #include <hip/hip_ext.h>
 
@@ -74,26 +79,54 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 // One tile = iteration t with ring slot J = t & 3 (gen/a3_body{J}.inc):
 //   phase A   MFMA: S_A^T(t+1) (16), O_A^T += V^T(t) P_A^T(t) (16)   VALU: softmax of S_B(t)     LDS: V^T(t) fragments | DMA K(t+4)
 //   phase B   MFMA: S_B^T(t+1) (16), O_B^T += V^T(t) P_B^T(t) (16)   VALU: softmax of S_A(t+1)   DMA V^T(t+2) | LDS: K(t+2) fragments
+// KV-split of the under-filled last round (round 5; launch_attention_v3 builds the table): 432 work-groups on 256 CUs are 1.69 rounds and cost
+// two (tools/round_probe.py: time follows ceil(rounds), not the work).  With a work table a work-group runs one or two SEGMENTS = (head,
+// 256-query block, key tiles [t0, t0 + n)); the q-blocks of the last round are cut into equal runs of key tiles, one run per CU.  A segment that
+// does not cover its block's whole key range writes a PARTIAL: O normalised by its own row sum as bf16 [256][128] + the row's log2-sum-exp;
+// attention_combine_kernel merges the 2-3 partials of a block (softmax is associative under exp2(lse_p - max) weights).
 // Softmax of one slab and tile = 134 instructions (gen_attn3.softmax_ops): two interleaved v_max3 chains, the xor-32 exchange,
 // the rescale decision (cold branch), then per score fma / exp2 / row-sum add and per pair cvt_pk, software-pipelined so that a
 // v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
+struct Seg { int h, b, qb, t0, n, pidx; };            // pidx < 0: the whole key range -> final output; else partial slot pidx
+struct Item { int nseg, pad_; Seg seg[2]; int pad2_[2]; };   // 64 bytes: one work-group's run of key tiles (at most two blocks touched)
+struct Comb { int h, b, qb, p0, np, pad_[3]; };       // a split block: partial slots [p0, p0 + np)
+
 __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                   int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
                                                                   int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg,
-                                                                  uint8_t* __restrict__ o8, int64_t ldo8, uint8_t* __restrict__ omx, int64_t ld_omx) {
+                                                                  uint8_t* __restrict__ o8, int64_t ldo8, uint8_t* __restrict__ omx, int64_t ld_omx,
+                                                                  const Item* __restrict__ work, bf16_t* __restrict__ po, float* __restrict__ plse) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int nseg = work != nullptr ? __builtin_amdgcn_readfirstlane(work[blockIdx.x].nseg) : 1;
+#pragma unroll 1
+  for (int si = 0; si < nseg; ++si) {
+  // every lane constant is derived INSIDE the segment loop from an opaque copy of threadIdx: nothing a segment computes lives through the
+  // previous segment's epilogue (hipcc's 96 registers are full in the main loop; with the constants hoisted it parked values in the asm-owned accumulator file)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
-  // head -> XCD affinity as in the 4-wave kernel: XCD x owns heads x, x + 8, ...
-  const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
-  const int per_head = nqb * B;
-  const int h = xcd + 8 * (slot_id / per_head);
-  if (h >= H) return;
-  const int rem = slot_id % per_head;
-  const int b = rem / nqb;
-  const int q0 = (rem % nqb) * QBLK + wave * 64;
-  const int ntiles = S_pad / KVB;                                // >= 2 (launcher); S_pad = roundup(S, 64), V^T is zero-padded to it
+  int h, b, qblk, t0, ntiles, pidx;
+  if (work != nullptr) {                                         // (uniform)
+    const Seg& sg = work[blockIdx.x].seg[si];
+    h = __builtin_amdgcn_readfirstlane(sg.h); b = __builtin_amdgcn_readfirstlane(sg.b); qblk = __builtin_amdgcn_readfirstlane(sg.qb);
+    t0 = __builtin_amdgcn_readfirstlane(sg.t0); ntiles = __builtin_amdgcn_readfirstlane(sg.n); pidx = __builtin_amdgcn_readfirstlane(sg.pidx);
+  } else {
+    // head -> XCD affinity as in the 4-wave kernel: XCD x owns heads x, x + 8, ...
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int per_head = nqb * B;
+    h = xcd + 8 * (slot_id / per_head);
+    if (h >= H) return;
+    const int rem = slot_id % per_head;
+    b = rem / nqb;
+    qblk = rem % nqb;
+    t0 = 0;
+    ntiles = S_pad / KVB;                                        // >= 2 (launcher); S_pad = roundup(S, 64), V^T is zero-padded to it
+    pidx = -1;
+  }
+  const int q0 = qblk * QBLK + wave * 64;
+  const int KS = min(S - t0 * KVB, ntiles * KVB), KS_pad = ntiles * KVB;      // keys of this segment / its tiles x 64 (ragged only in the block's last segment)
   const float c = 0.08838834764831845f * 1.4426950408889634f;   // 1/sqrt(128) * log2(e)
   const float neg_c = -c;
   const float thr = RESCALE_LOG2 / c;
@@ -126,14 +159,14 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
   // Ragged S: the K rows of the LAST tile past the end are clamped to row S - 1 (finite data; their scores get -inf added in front of the last tile's softmax streams: gen/a3_mask.inc, cold),
   // so the last tile's DMA pieces use their own per-lane offsets; tiles past the end re-fetch the last one.
   const int last0 = (ntiles - 1) * KVB;
-#define A3_KOFFL(i) ((uint32_t)(((int64_t)(min(last0 + dk_r + 16 * (i), S - 1) - last0) * ldk + dk_c) * 2))
+#define A3_KOFFL(i) ((uint32_t)(((int64_t)(min(last0 + dk_r + 16 * (i), KS - 1) - last0) * ldk + dk_c) * 2))
   const uint32_t koffl0 = A3_KOFFL(0), koffl1 = A3_KOFFL(1), koffl2 = A3_KOFFL(2), koffl3 = A3_KOFFL(3);
 #define A3_KOFS(TILE)                                                                                                     \
   const bool klast_ = (TILE) >= ntiles - 1;                                                                               \
   const uint32_t kofs0 = klast_ ? koffl0 : koff0, kofs1 = klast_ ? koffl1 : koff1, kofs2 = klast_ ? koffl2 : koff2,       \
                  kofs3 = klast_ ? koffl3 : koff3;
-  const char* kbase = reinterpret_cast<const char*>(k + (int64_t)b * S * ldk + h * 128);
-  const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S_pad);
+  const char* kbase = reinterpret_cast<const char*>(k + ((int64_t)b * S + (int64_t)t0 * KVB) * ldk + h * 128);
+  const char* vbase = reinterpret_cast<const char*>(vt + ((int64_t)(b * H + h) * 128) * S_pad + (int64_t)t0 * KVB);
   const int64_t ktile_bytes = (int64_t)KVB * ldk * 2;
   // tiles past the end re-fetch the last one into a free slot: the DMA count per iteration stays 8
   auto k_src = [&](int tt) { tt = tt < ntiles ? tt : ntiles - 1; return uniform_u64((uint64_t)(uintptr_t)(kbase + tt * ktile_bytes)); };
@@ -221,7 +254,12 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
   int tid2 = threadIdx.x;
   asm volatile("" : "+v"(tid2));
   const int ql2 = tid2 & 31, hi2 = (tid2 >> 5) & 1;
-  const int q02 = (rem % nqb) * QBLK + __builtin_amdgcn_readfirstlane(tid2 >> 6) * 64;
+  const int q02 = qblk * QBLK + __builtin_amdgcn_readfirstlane(tid2 >> 6) * 64;
+  // where this segment's rows go: the caller's O / lse, or partial slot pidx ([256][128] bf16 + [256] f32, rows relative to the block)
+  const bool part = pidx >= 0;                                   // (uniform)
+  bf16_t* const obase = part ? po + ((int64_t)pidx * QBLK - (int64_t)qblk * QBLK) * 128 : o + (int64_t)b * S * ldo + h * 128;
+  const int64_t ld_o = part ? 128 : ldo;
+  float* const lbase = part ? plse + ((int64_t)pidx * QBLK - (int64_t)qblk * QBLK) : (lse != nullptr ? lse + ((int64_t)b * H + h) * S_pad : nullptr);
 
   // ---- normalise and store, one 32-row tile of O^T at a time: lane (q, hi) holds O[q][32 d + 8 g + 4 hi + 0..3] in ox[4 g + 0..3].
   // One permlane32 exchange per register pairs the two half-waves' 8-byte pieces into 16 contiguous bytes per lane (8 instead of
@@ -246,8 +284,8 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     const float l_tot = lsum + __shfl_xor(lsum, 32, 64);                                                           \
     const float inv = 1.0f / l_tot;                                                                                \
     const int row = q02 + (SL) * 32 + ql2;                                                                         \
-    if (lse != nullptr && hi2 == 0 && row < S) lse[((int64_t)b * H + h) * S_pad + row] = (MRUN) * c + __log2f(l_tot); \
-    bf16_t* op = o + ((int64_t)b * S + row) * ldo + h * 128 + hi2 * 8;                                             \
+    if (lbase != nullptr && hi2 == 0 && row < S) lbase[row] = (MRUN) * c + __log2f(l_tot);                         \
+    bf16_t* op = obase + (int64_t)row * ld_o + hi2 * 8;                                                            \
     A3_READ_##SL##_0 store_tile(SL, 0, inv, row, op);                                                              \
     A3_READ_##SL##_1 store_tile(SL, 1, inv, row, op);                                                              \
     A3_READ_##SL##_2 store_tile(SL, 2, inv, row, op);                                                              \
@@ -315,6 +353,11 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     t4[6] = tr[2] - tr[1];      // phase B
   }
 #endif
+  if (si + 1 < nseg) {          // the next segment's DMA overwrites ring slots other waves may still be reading
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  }   // segments
 }
 
 }  // namespace a3
@@ -328,10 +371,188 @@ extern "C" int afx_debug_attn3_trace(unsigned* host_out) {      // [2 blocks][4 
 #endif
 }
 
+// Merge the partials of the split blocks: O = sum_p w_p O_p / sum_p w_p with w_p = exp2(lse_p - max_p lse_p); 4 work-groups x 64 rows per block,
+// 16 lanes x 16 bytes per row.
+__global__ __launch_bounds__(256) void attention_combine_kernel(const bf16_t* __restrict__ po, const float* __restrict__ plse, const a3::Comb* __restrict__ comb,
+                                                                bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse, int H, int S, int S_pad) {
+  const a3::Comb cb = comb[blockIdx.x >> 2];
+  const int sub = threadIdx.x & 15, rr = threadIdx.x >> 4;
+#pragma unroll 1
+  for (int pass = 0; pass < 4; ++pass) {
+    const int rloc = (blockIdx.x & 3) * 64 + pass * 16 + rr;
+    const int row = cb.qb * a3::QBLK + rloc;
+    if (row >= S) continue;
+    float ls[4], L = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ls[p] = p < cb.np ? plse[(int64_t)(cb.p0 + p) * a3::QBLK + rloc] : -INFINITY;
+      L = fmaxf(L, ls[p]);
+    }
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (p < cb.np) {
+        const float w = __builtin_amdgcn_exp2f(ls[p] - L);
+        wsum += w;
+        float x[8];
+        unpack8(*reinterpret_cast<const u32x4_t*>(po + ((int64_t)(cb.p0 + p) * a3::QBLK + rloc) * 128 + sub * 8), x);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += w * x[e];
+      }
+    }
+    const float inv = 1.0f / wsum;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= inv;
+    *reinterpret_cast<u32x4_t*>(o + ((int64_t)cb.b * S + row) * ldo + cb.h * 128 + sub * 8) = pack8(acc);
+    if (lse != nullptr && sub == 0) lse[((int64_t)cb.b * H + cb.h) * S_pad + row] = L + __log2f(wsum);
+  }
+}
+
 bool attention_v3_eligible(int S) { return S > a3::KVB; }        // >= 2 KV tiles (the pipeline's tile 0 is never the last one)
 
+namespace {
+// The balanced schedule of one (B, H, S) shape on one stream: per XCD the 256-query blocks of its heads in dispatch order -- whole rounds of
+// whole blocks first, then the blocks of the under-filled last round cut into one equal run of key tiles per CU.
+struct SplitPlan {
+  bool split = false;
+  int grid = 0, ncomb = 0, nparts = 0;
+  a3::Item* items = nullptr;
+  a3::Comb* comb = nullptr;
+  uint16_t* po = nullptr;
+  float* plse = nullptr;
+};
+constexpr int MIN_SEG = 4;          // key tiles: no segment shorter than this (a segment pays a prologue + an epilogue)
+
+bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, std::vector<a3::Comb>& comb, int& nparts, int& grid) {
+  const int nqb = (S + a3::QBLK - 1) / a3::QBLK, ntiles = (int)(attn_spad(S) / a3::KVB), hx = (H + 7) / 8, cu = ncu / 8;
+  if (cu < 1 || ntiles < 4 * MIN_SEG) return false;
+  std::vector<std::vector<a3::Item>> per(8);
+  bool any = false;
+  nparts = 0;
+  for (int x = 0; x < 8; ++x) {
+    std::vector<a3::Seg> blocks;
+    for (int hh = 0; hh < hx; ++hh)
+      for (int b = 0; b < B; ++b)
+        for (int qb = 0; qb < nqb; ++qb)
+          if (x + 8 * hh < H) blocks.push_back(a3::Seg{x + 8 * hh, b, qb, 0, ntiles, -1});
+    const int nx = (int)blocks.size(), rem = nx % cu, full = nx - rem;
+    auto whole = [&](const a3::Seg& sg) { a3::Item it{}; it.nseg = 1; it.seg[0] = sg; per[x].push_back(it); };
+    for (int i = 0; i < full; ++i) whole(blocks[i]);
+    if (rem == 0) continue;
+    if (rem * 8 > cu * 7) {               // the last round is at least 7/8 full: not worth the partials
+      for (int i = full; i < nx; ++i) whole(blocks[i]);
+      continue;
+    }
+    const int64_t T = (int64_t)rem * ntiles;
+    // one run per CU -- fewer when the runs would get short: a run of at least a third of a block keeps a block's partials at <= 4
+    const int m = (int)std::min<int64_t>(cu, T / std::max(2 * MIN_SEG, ntiles / 3 + 2));
+    if (m <= rem) {
+      for (int i = full; i < nx; ++i) whole(blocks[i]);
+      continue;
+    }
+    any = true;
+    std::vector<int64_t> bd(m + 1);
+    for (int j = 0; j <= m; ++j) {
+      int64_t v = j * T / m;
+      const int r = (int)(v % ntiles);
+      if (r > 0 && r < MIN_SEG) v -= r;
+      else if (r > ntiles - MIN_SEG) v += ntiles - r;
+      bd[j] = v;
+    }
+    int cur_block = -1;                  // block (index into the remainder) whose Comb entry is open
+    for (int j = 0; j < m; ++j) {
+      a3::Item it{};
+      int64_t pos = bd[j];
+      while (pos < bd[j + 1]) {
+        const int bi = (int)(pos / ntiles), t0 = (int)(pos % ntiles);
+        const int n = (int)std::min<int64_t>(bd[j + 1] - pos, ntiles - t0);
+        if (it.nseg >= 2) return false;
+        a3::Seg sg = blocks[full + bi];
+        sg.t0 = t0; sg.n = n;
+        if (n < ntiles) {
+          sg.pidx = nparts++;
+          if (bi != cur_block) { comb.push_back(a3::Comb{sg.h, sg.b, sg.qb, sg.pidx, 0, {0, 0, 0}}); cur_block = bi; }
+          if (++comb.back().np > 4) return false;
+        }
+        it.seg[it.nseg++] = sg;
+        pos += n;
+      }
+      per[x].push_back(it);
+    }
+  }
+  if (!any) return false;
+  size_t slots = 0;
+  for (int x = 0; x < 8; ++x) slots = std::max(slots, per[x].size());
+  grid = (int)slots * 8;
+  items.assign(grid, a3::Item{});
+  for (int x = 0; x < 8; ++x)
+    for (size_t i = 0; i < per[x].size(); ++i) items[i * 8 + x] = per[x][i];
+  return true;
+}
+
+SplitPlan* plan_for(int B, int H, int S, hipStream_t stream) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int, hipStream_t>, SplitPlan> cache;
+  static int enabled = -1;
+  std::lock_guard<std::mutex> lock(mu);
+  if (enabled < 0) {
+    const char* e = getenv("AFX_ATTN_SPLIT");            // 0: the plain grid (A/B runs)
+    enabled = (e && e[0] == '0') ? 0 : 1;
+  }
+  if (!enabled) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  const auto key = std::make_tuple(dev, B, H, S, stream);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second.split ? &it->second : nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // no allocation inside a capture
+  int ncu = 0;
+  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
+  SplitPlan pl;
+  std::vector<a3::Item> items;
+  std::vector<a3::Comb> comb;
+  if (build_plan(B, H, S, ncu, items, comb, pl.nparts, pl.grid)) {
+    pl.ncomb = (int)comb.size();
+    const size_t ib = items.size() * sizeof(a3::Item), cb = comb.size() * sizeof(a3::Comb);
+    const size_t pb = (size_t)pl.nparts * a3::QBLK * 128 * 2, lb = (size_t)pl.nparts * a3::QBLK * 4;
+    char* base = nullptr;
+    const size_t o1 = (ib + 255) / 256 * 256, o2 = o1 + (cb + 255) / 256 * 256, o3 = o2 + (pb + 255) / 256 * 256;
+    if (hipMalloc((void**)&base, o3 + lb) == hipSuccess && hipMemcpy(base, items.data(), ib, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemcpy(base + o1, comb.data(), cb, hipMemcpyHostToDevice) == hipSuccess) {
+      pl.items = reinterpret_cast<a3::Item*>(base);
+      pl.comb = reinterpret_cast<a3::Comb*>(base + o1);
+      pl.po = reinterpret_cast<uint16_t*>(base + o2);
+      pl.plse = reinterpret_cast<float*>(base + o3);
+      pl.split = true;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  auto& slot = cache[key] = pl;
+  return slot.split ? &slot : nullptr;
+}
+}  // namespace
+
+// test hook: the schedule of a shape as plain integers (items: nseg, then 6 per segment; comb: 5 per entry)
+extern "C" int afx_debug_attn_plan(int B, int H, int S, int ncu, int* items_out, int max_items, int* comb_out, int max_comb, int* nparts, int* grid) {
+  std::vector<a3::Item> items;
+  std::vector<a3::Comb> comb;
+  int np = 0, g = 0;
+  if (!build_plan(B, H, S, ncu, items, comb, np, g)) return 0;
+  *nparts = np; *grid = g;
+  if ((int)items.size() > max_items || (int)comb.size() > max_comb) return -1;
+  for (size_t i = 0; i < items.size(); ++i) {
+    int* d = items_out + i * 13;
+    d[0] = items[i].nseg;
+    for (int s_ = 0; s_ < 2; ++s_) { const a3::Seg& sg = items[i].seg[s_]; int* e = d + 1 + 6 * s_; e[0] = sg.h; e[1] = sg.b; e[2] = sg.qb; e[3] = sg.t0; e[4] = sg.n; e[5] = sg.pidx; }
+  }
+  for (size_t i = 0; i < comb.size(); ++i) { int* d = comb_out + i * 5; d[0] = comb[i].h; d[1] = comb[i].b; d[2] = comb[i].qb; d[3] = comb[i].p0; d[4] = comb[i].np; }
+  return (int)comb.size();
+}
+
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
-                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8) {
+                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8, bool split) {
   uint8_t* o8 = mx8 ? mx8->o8 : nullptr;
   uint8_t* omx = mx8 ? mx8->mx : nullptr;
   const int64_t ldo8 = mx8 ? mx8->ldo8 : 0, ld_omx = mx8 ? mx8->ld_mx : 0;
@@ -344,17 +565,30 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   }
   const int nqb = (S + a3::QBLK - 1) / a3::QBLK;
   const int S_pad = (int)attn_spad(S);
-  const dim3 grid(8 * ((H + 7) / 8) * nqb * B);
   static int dbg = -1;
   if (dbg < 0) {
     const char* e = getenv("AFX_ATTN3_DBG");
     dbg = e ? atoi(e) : 0;
   }
-  if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
-    hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
-                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx);
+  SplitPlan* pl = (split && o8 == nullptr && dbg == 0) ? plan_for(B, H, S, stream) : nullptr;      // (the block-scaled fp8 output keeps the plain grid)
+  const dim3 grid(pl ? pl->grid : 8 * ((H + 7) / 8) * nqb * B);
+  const a3::Item* items = pl ? pl->items : nullptr;
+  uint16_t* po = pl ? pl->po : nullptr;
+  float* plse = pl ? pl->plse : nullptr;
+  hipEvent_t ev0 = launch_timer().start, ev1 = launch_timer().stop;
+  const bool timed = ev0 != nullptr && ev1 != nullptr;
+  if (timed)      // with a combine launch behind it the pair brackets both kernels
+    hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, ev0, pl ? nullptr : ev1, 0,
+                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse);
   else
-    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx);
+    hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx,
+                       items, po, plse);
+  if (pl) {
+    if (timed)
+      hipExtLaunchKernelGGL(attention_combine_kernel, dim3(pl->ncomb * 4), dim3(256), 0, stream, nullptr, ev1, 0, po, plse, pl->comb, o, ldo, lse, H, S, S_pad);
+    else
+      hipLaunchKernelGGL(attention_combine_kernel, dim3(pl->ncomb * 4), dim3(256), 0, stream, po, plse, pl->comb, o, ldo, lse, H, S, S_pad);
+  }
   return hipGetLastError();
 }
 

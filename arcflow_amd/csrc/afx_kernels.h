@@ -111,8 +111,8 @@ hipError_t launch_attention(const uint16_t* q, int64_t ldq, const uint16_t* k, i
 // one-wave-per-SIMD kernel (afx_attn3.hip): any S > 64 (ragged tails handled); launch_attention dispatches to it (AFX_ATTN_IMPL=1 / attn_set_impl(1): 4-wave kernel)
 bool attention_v3_eligible(int S);
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
-                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8 = nullptr);
-void attn_set_impl(int impl);               // 0 = default (v3 where eligible), 1 = 4-wave kernel, 2 = 8-wave ping-pong (experimental), 3 = v3
+                               int64_t ldo, int B, int H, int S, hipStream_t stream, float* lse, const AttnMx8* mx8 = nullptr, bool split = true);
+void attn_set_impl(int impl);               // 0 = default (v3 where eligible, under-filled last round KV-split), 1 = 4-wave kernel, 2 = 8-wave ping-pong (experimental), 3 = v3 on the plain grid
 // K, Q <- RoPE(RMSNorm(.) w) in place (same row stride) and V -> V^T (key-permuted), one launch
 hipError_t launch_kv_prep(uint16_t* k, uint16_t* q, int64_t ldk, const float* wk_txt, const float* wk_img, const float* wq_txt,
                           const float* wq_img, const float* cos_t, const float* sin_t, int n_txt, const uint16_t* v, int64_t ldv,

@@ -67,8 +67,8 @@ def set_gemm_mode(impl: int = 3, tile: int = 0) -> None:
 
 
 def set_attn_impl(impl: int = 0) -> None:
-    """Kernel choice of the joint attention (``afx_attn_set_impl``): 0 = one-wave-per-SIMD kernel where eligible (default), 1 = 4-wave
-    kernel always, 2 = 8-wave ping-pong kernel (experimental)."""
+    """Kernel choice of the joint attention (``afx_attn_set_impl``): 0 = one-wave-per-SIMD kernel where eligible, the blocks of an under-filled
+    last round KV-split (default), 1 = 4-wave kernel always, 2 = 8-wave ping-pong kernel (experimental), 3 = as 0 on the plain grid."""
     _lib.check(_lib.load().afx_attn_set_impl(impl))
 
 

@@ -407,7 +407,8 @@ int afx_linear_sk_last_split(void);
 int afx_gemm_set_mode(int32_t impl, int32_t tile);
 /* Kernel choice of every joint attention launch (process-wide; same meaning as AFX_ATTN_IMPL, which it overrides): 0 (default) = the
  * one-wave-per-SIMD kernel (afx_attn3.hip: 64 queries per wave, any S > 64: ragged tails handled) where eligible, else the 4-wave kernel; 1 = 4-wave kernel
- * always; 2 = 8-wave ping-pong kernel (experimental).  For A/B runs and the parity tests.  Returns 0. */
+ * always; 2 = 8-wave ping-pong kernel (experimental); 3 = the one-wave-per-SIMD kernel on its plain grid (0 cuts the 256-query blocks of an under-filled
+ * last round into one run of key tiles per CU and merges the partial results: afx_attn3.hip).  For A/B runs and the parity tests.  Returns 0. */
 int afx_attn_set_impl(int32_t impl);
 int afx_linear_bf16_sk(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias,
                        void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,

@@ -98,14 +98,15 @@ def qk(sl, m):
 
 
 def mask_ops(sl):
-    """Ragged S, last tile only (cold): scores of the keys past the end -> -inf before the slab's softmax reads them.  Score register
+    """Ragged key range (KS keys in the segment, KS_pad = its tiles x 64), last tile only (cold): scores of the keys past the end -> -inf
+    before the slab's softmax reads them.  Score register
     i = 16 kb + r of a lane holds key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi of the tile (the MFMA D layout).  The K rows behind them are
     clamped copies of row S - 1 (finite), V^T is zero there."""
     lines = [f'#define A3_MASK_S{sl} \\']
     for i in range(32):
         kb, r = i >> 4, i & 15
         key = 32 * kb + (r & 3) + 8 * (r >> 2)
-        lines.append(f'  {{ const float pen_ = last0 + {key} + 4 * hi >= S ? -INFINITY : 0.f; '
+        lines.append(f'  {{ const float pen_ = last0 + {key} + 4 * hi >= KS ? -INFINITY : 0.f; '
                      f'asm volatile("v_add_f32 {Sx(sl, i)}, {Sx(sl, i)}, %0" : : "v"(pen_)); }} \\')
     lines.append('  asm volatile("s_nop 1");')
     return lines
@@ -318,7 +319,7 @@ def body(J):
     cnt = valu_counts(False)
     k = 0
     out.append('// ---- phase B')
-    out.append('if (__builtin_expect(S != S_pad && t + 2 == ntiles, 0)) { A3_MASK_S0 }')
+    out.append('if (__builtin_expect(KS != KS_pad && t + 2 == ntiles, 0)) { A3_MASK_S0 }')
     for m in range(32):
         if m < 16:
             out.append(qk(1, m))
@@ -340,7 +341,7 @@ def final():
     out = ['// generated by tools/gen_attn3.py -- last tile t = ntiles - 1 (runtime ring slot: vs = (t & 3) * 16384)']
     out.append(wait('s_waitcnt vmcnt(8) lgkmcnt(0)\\n\\ts_barrier', own=True))
     out += [read_v(i, 0, 'vs') for i in range(16)]
-    out.append('if (S != S_pad) { A3_MASK_S1 }')
+    out.append('if (KS != KS_pad) { A3_MASK_S1 }')
     out += emit(softmax_ops(1))
     out.append(wait('s_waitcnt lgkmcnt(0)\\n\\ts_nop 3'))
     out += [pv(0, m) for m in range(16)]
