@@ -79,23 +79,27 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 // One tile = iteration t with ring slot J = t & 3 (gen/a3_body{J}.inc):
 //   phase A   MFMA: S_A^T(t+1) (16), O_A^T += V^T(t) P_A^T(t) (16)   VALU: softmax of S_B(t)     LDS: V^T(t) fragments | DMA K(t+4)
 //   phase B   MFMA: S_B^T(t+1) (16), O_B^T += V^T(t) P_B^T(t) (16)   VALU: softmax of S_A(t+1)   DMA V^T(t+2) | LDS: K(t+2) fragments
-// KV-split of the under-filled last round (round 5; launch_attention_v3 builds the table): 432 work-groups on 256 CUs are 1.69 rounds and cost
-// two (tools/round_probe.py: time follows ceil(rounds), not the work).  With a work table a work-group runs one or two SEGMENTS = (head,
-// 256-query block, key tiles [t0, t0 + n)); the q-blocks of the last round are cut into equal runs of key tiles, one run per CU.  A segment that
-// does not cover its block's whole key range writes a PARTIAL: O normalised by its own row sum as bf16 [256][128] + the row's log2-sum-exp;
-// attention_combine_kernel merges the 2-3 partials of a block (softmax is associative under exp2(lse_p - max) weights).
+// Balanced last round (round 5; launch_attention_v3 builds the table): 432 work-groups on 256 CUs are 1.69 rounds and cost two
+// (tools/round_probe.py: a launch's time follows ceil(rounds), not its work).  With a work table a work-group runs a list of SEGMENTS =
+// (head, 256-query block, key tiles [t0, t0 + n)).  The blocks of the under-filled last round are cut once, at key tile L: the SHORT ends
+// [L, ntiles) run first, beside the previous round's whole blocks, and leave a PARTIAL (O normalised by its own row sum as bf16 [256][128] + the
+// row's log2-sum-exp, published with an agent-scope release + a generation flag); the LONG parts [0, L) run last, take the partials as their
+// initial (m, l, O) state -- m = lse / c, l = 1, O = the partial rows (several partials: merged with exp2(lse_p - max) weights) -- and write the
+// final rows themselves: no merge pass, no atomics, and every CU ends up with (blocks x tiles) / CUs key tiles.  A long part that does not see its
+// partials published within a bounded number of polls (HIP promises no dispatch order) computes the whole key range itself.
 // Softmax of one slab and tile = 134 instructions (gen_attn3.softmax_ops): two interleaved v_max3 chains, the xor-32 exchange,
 // the rescale decision (cold branch), then per score fma / exp2 / row-sum add and per pair cvt_pk, software-pipelined so that a
 // v_exp_f32 result is never consumed by the next instruction (trans -> VALU use needs a wait state hipcc cannot add here).
-struct Seg { int h, b, qb, t0, n, pidx; };            // pidx < 0: the whole key range -> final output; else partial slot pidx
-struct Item { int nseg, pad_; Seg seg[2]; int pad2_[2]; };   // 64 bytes: one work-group's run of key tiles (at most two blocks touched)
-struct Comb { int h, b, qb, p0, np, pad_[3]; };       // a split block: partial slots [p0, p0 + np)
+constexpr int MAX_SEG = 8;
+struct Seg { int h, b, qb, t0, n, out, nin, in0; };   // out >= 0: write partial slot `out` (else the final rows); nin > 0: start from partial slots [in0, in0 + nin) (then t0 = 0)
+struct Item { int nseg, pad_[3]; Seg seg[MAX_SEG]; }; // 272 bytes: one work-group's list
 
 __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) void attention_v3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k,
                                                                   int64_t ldk, const bf16_t* __restrict__ vt, bf16_t* __restrict__ o,
                                                                   int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg,
                                                                   uint8_t* __restrict__ o8, int64_t ldo8, uint8_t* __restrict__ omx, int64_t ld_omx,
-                                                                  const Item* __restrict__ work, bf16_t* __restrict__ po, float* __restrict__ plse) {
+                                                                  const Item* __restrict__ work, bf16_t* __restrict__ po, float* __restrict__ plse,
+                                                                  int* __restrict__ pflag, int gen, int wt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nseg = work != nullptr ? __builtin_amdgcn_readfirstlane(work[blockIdx.x].nseg) : 1;
 #pragma unroll 1
@@ -107,11 +111,36 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ql = lane & 31, hi = lane >> 5;
-  int h, b, qblk, t0, ntiles, pidx;
+  int h, b, qblk, t0, ntiles, pidx, nin = 0, in0 = 0;
   if (work != nullptr) {                                         // (uniform)
     const Seg& sg = work[blockIdx.x].seg[si];
     h = __builtin_amdgcn_readfirstlane(sg.h); b = __builtin_amdgcn_readfirstlane(sg.b); qblk = __builtin_amdgcn_readfirstlane(sg.qb);
-    t0 = __builtin_amdgcn_readfirstlane(sg.t0); ntiles = __builtin_amdgcn_readfirstlane(sg.n); pidx = __builtin_amdgcn_readfirstlane(sg.pidx);
+    t0 = __builtin_amdgcn_readfirstlane(sg.t0); ntiles = __builtin_amdgcn_readfirstlane(sg.n); pidx = __builtin_amdgcn_readfirstlane(sg.out);
+    nin = __builtin_amdgcn_readfirstlane(sg.nin); in0 = __builtin_amdgcn_readfirstlane(sg.in0);
+    if (nin > 0) {
+      // consumer side of the hand-over: ONE lane polls the generation flags (relaxed, agent scope, bounded), the verdict goes through LDS (free between
+      // segments), then every wave takes an agent-scope acquire before the plain loads of the partial rows
+      if (tid == 0) {
+        int ok = 1;
+        for (int p = 0; p < nin && ok; ++p) {
+          int spins = 0;
+          while (__hip_atomic_load(pflag + in0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+            if (++spins > (1 << 15)) { ok = 0; break; }
+            __builtin_amdgcn_s_sleep(32);
+          }
+        }
+        *reinterpret_cast<volatile int*>(smem) = ok;
+      }
+      __syncthreads();
+      const int ok = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem));
+      __syncthreads();                                           // (the word is read before the prologue's DMA may overwrite it)
+      if (ok) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      } else {                                                   // never published (dispatch order?): the whole key range, from zero
+        nin = 0;
+        ntiles = S_pad / KVB;
+      }
+    }
   } else {
     // head -> XCD affinity as in the 4-wave kernel: XCD x owns heads x, x + 8, ...
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
@@ -199,6 +228,45 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
   }
 #include A3_INC(a3_prologue_dma.inc)
   A3_DBG(2)
+  if (nin > 0) {      // (uniform) continue from the handed-over partial results of this block's other key tiles: m = lse / c, l = sum of weights, O = weighted rows
+    // (the prologue's loads stay in flight; hipcc's own waits for these loads are conservative -- VMEM retires in order -- and the counted waits of tile 0 only
+    // ever wait for MORE than they need when other loads are outstanding)
+    const float inv_c = 1.0f / c;
+    float ox[16];
+    // the partial rows were written through (sc0 sc1): read them with agent-scope loads (sc1, served past this CU's L1) -- MI355X_MICROARCH "sc1 stores AND sc1 loads"
+#define A3_LD_LSE(P) __hip_atomic_load(plse + (int64_t)(in0 + (P)) * QBLK + rloc_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define A3_INIT_TILE(SL, D)                                                                                        \
+    {                                                                                                              \
+      _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) ox[r_] = 0.f;                                              \
+      for (int p_ = 0; p_ < nin; ++p_) {                                                                           \
+        const float w_ = __builtin_amdgcn_exp2f(A3_LD_LSE(p_) - lmax_);                                            \
+        const bf16_t* src_ = po + ((int64_t)(in0 + p_) * QBLK + rloc_) * 128 + (D) * 32 + hi * 4;                  \
+        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                         \
+          const uint64_t v64_ = __hip_atomic_load(reinterpret_cast<const uint64_t*>(src_ + 8 * g_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+          const uint32_t v_[2] = {(uint32_t)v64_, (uint32_t)(v64_ >> 32)};                                         \
+          ox[4 * g_ + 0] += w_ * __uint_as_float(v_[0] << 16);                                                     \
+          ox[4 * g_ + 1] += w_ * __uint_as_float(v_[0] & 0xffff0000u);                                             \
+          ox[4 * g_ + 2] += w_ * __uint_as_float(v_[1] << 16);                                                     \
+          ox[4 * g_ + 3] += w_ * __uint_as_float(v_[1] & 0xffff0000u);                                             \
+        }                                                                                                          \
+      }                                                                                                            \
+      A3_WRITE_##SL##_##D                                                                                          \
+    }
+#define A3_INIT_SLAB(SL, MV, L0V, L1V)                                                                             \
+    {                                                                                                              \
+      const int rloc_ = wave * 64 + (SL) * 32 + ql;                                                                \
+      float lmax_ = -INFINITY, wsum_ = 0.f;                                                                        \
+      for (int p_ = 0; p_ < nin; ++p_) lmax_ = fmaxf(lmax_, A3_LD_LSE(p_));                                        \
+      for (int p_ = 0; p_ < nin; ++p_) wsum_ += __builtin_amdgcn_exp2f(A3_LD_LSE(p_) - lmax_);                     \
+      A3_INIT_TILE(SL, 0) A3_INIT_TILE(SL, 1) A3_INIT_TILE(SL, 2) A3_INIT_TILE(SL, 3)                              \
+      MV = lmax_ * inv_c;                                                                                          \
+      L0V = hi == 0 ? wsum_ : 0.f;      /* a row's sum lives as two partial sums, one per half-wave */                \
+      L1V = 0.f;                                                                                                   \
+    }
+    A3_INIT_SLAB(0, mA, lA0, lA1)
+    A3_INIT_SLAB(1, mB, lB0, lB1)
+    asm volatile("s_nop 7" ::: "memory");                          // accumulator write -> MFMA SrcC
+  }
 
 #ifdef AFX_ATTN_TRACE
   unsigned tr[16];
@@ -275,7 +343,11 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
       const uint32_t by = pack_bf16x2(ox[4 * g1 + 2] * inv, ox[4 * g1 + 3] * inv);
       const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
       const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-      if (row < S) *reinterpret_cast<u32x4_t*>(op + d * 32 + kk * 16) = (u32x4_t){rx[0], ry[0], rx[1], ry[1]};
+      const u32x4_t val = (u32x4_t){rx[0], ry[0], rx[1], ry[1]};
+      // write-through: the payload of a hand-over (see the publish below).  The s_nop is the wait a VALU write of a > 8-byte store's data registers needs
+      // behind the store (gfx940+: 2 states) -- hipcc's hazard recogniser cannot see into the asm, and without it one build stored the NEXT step's values in some lanes
+      if (part && wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(op + d * 32 + kk * 16), "v"(val) : "memory");
+      else if (part || row < S) *reinterpret_cast<u32x4_t*>(op + d * 32 + kk * 16) = val;
     }
   };
 #define A3_STORE_SLAB(SL, LSUM, MRUN)                                                                              \
@@ -284,7 +356,11 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     const float l_tot = lsum + __shfl_xor(lsum, 32, 64);                                                           \
     const float inv = 1.0f / l_tot;                                                                                \
     const int row = q02 + (SL) * 32 + ql2;                                                                         \
-    if (lbase != nullptr && hi2 == 0 && row < S) lbase[row] = (MRUN) * c + __log2f(l_tot);                         \
+    if (part) {                                                                                                    \
+      const float lv_ = (MRUN) * c + __log2f(l_tot);                                                               \
+      if (hi2 == 0 && wt) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(lbase + row), "v"(lv_) : "memory"); \
+      else if (hi2 == 0) lbase[row] = lv_;                                                                         \
+    } else if (lbase != nullptr && hi2 == 0 && row < S) lbase[row] = (MRUN) * c + __log2f(l_tot);                  \
     bf16_t* op = obase + (int64_t)row * ld_o + hi2 * 8;                                                            \
     A3_READ_##SL##_0 store_tile(SL, 0, inv, row, op);                                                              \
     A3_READ_##SL##_1 store_tile(SL, 1, inv, row, op);                                                              \
@@ -353,6 +429,18 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     t4[6] = tr[2] - tr[1];      // phase B
   }
 #endif
+  if (part) {                   // producer side of the hand-over: the rows went out as write-through (sc0 sc1) stores -- no L2 write-back fence, which stalls the
+                                // whole XCD's L2 for microseconds per publish -- every wave drains its own, then ONE lane raises the slot's generation flag (sc1 store)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid2 == 0) {
+      if (!wt) {                // (AFX_ATTN_HANDOVER=fence, A/B: plain stores + an agent-scope release)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __hip_atomic_store(pflag + pidx, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   if (si + 1 < nseg) {          // the next segment's DMA overwrites ring slots other waves may still be reading
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -371,61 +459,35 @@ extern "C" int afx_debug_attn3_trace(unsigned* host_out) {      // [2 blocks][4 
 #endif
 }
 
-// Merge the partials of the split blocks: O = sum_p w_p O_p / sum_p w_p with w_p = exp2(lse_p - max_p lse_p); 4 work-groups x 64 rows per block,
-// 16 lanes x 16 bytes per row.
-__global__ __launch_bounds__(256) void attention_combine_kernel(const bf16_t* __restrict__ po, const float* __restrict__ plse, const a3::Comb* __restrict__ comb,
-                                                                bf16_t* __restrict__ o, int64_t ldo, float* __restrict__ lse, int H, int S, int S_pad) {
-  const a3::Comb cb = comb[blockIdx.x >> 2];
-  const int sub = threadIdx.x & 15, rr = threadIdx.x >> 4;
-#pragma unroll 1
-  for (int pass = 0; pass < 4; ++pass) {
-    const int rloc = (blockIdx.x & 3) * 64 + pass * 16 + rr;
-    const int row = cb.qb * a3::QBLK + rloc;
-    if (row >= S) continue;
-    float ls[4], L = -INFINITY;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      ls[p] = p < cb.np ? plse[(int64_t)(cb.p0 + p) * a3::QBLK + rloc] : -INFINITY;
-      L = fmaxf(L, ls[p]);
-    }
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wsum = 0.f;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      if (p < cb.np) {
-        const float w = __builtin_amdgcn_exp2f(ls[p] - L);
-        wsum += w;
-        float x[8];
-        unpack8(*reinterpret_cast<const u32x4_t*>(po + ((int64_t)(cb.p0 + p) * a3::QBLK + rloc) * 128 + sub * 8), x);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += w * x[e];
-      }
-    }
-    const float inv = 1.0f / wsum;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] *= inv;
-    *reinterpret_cast<u32x4_t*>(o + ((int64_t)cb.b * S + row) * ldo + cb.h * 128 + sub * 8) = pack8(acc);
-    if (lse != nullptr && sub == 0) lse[((int64_t)cb.b * H + cb.h) * S_pad + row] = L + __log2f(wsum);
-  }
-}
-
 bool attention_v3_eligible(int S) { return S > a3::KVB; }        // >= 2 KV tiles (the pipeline's tile 0 is never the last one)
 
 namespace {
-// The balanced schedule of one (B, H, S) shape on one stream: per XCD the 256-query blocks of its heads in dispatch order -- whole rounds of
-// whole blocks first, then the blocks of the under-filled last round cut into one equal run of key tiles per CU.
+// The balanced schedule of one (B, H, S) shape on one stream (see the kernel's header): per XCD the 256-query blocks of its heads in dispatch
+// order.  How work-groups reach CUs (tools/dispatch_probe.hip, a one-work-group-per-CU kernel with table-driven run times; for speed only, nothing
+// below depends on it for correctness): work-group b runs on XCD b % 8; inside an XCD the j-th work-group goes to shader engine perm[j % 4] (8 CUs
+// each) and waits -- IN ORDER, blocking every work-group behind it -- until that engine has a free CU.  So a schedule is four interleaved
+// sub-lists, one per engine, and the start times it plans must not decrease along the merged list.  With R whole rounds and `rem` blocks left
+// over, the last whole round and the remainder are dealt to the engines (8 whole blocks + rem_k = rem / 4 (+ 1) blocks to cut, each), and engine k runs
+//     [rem_k whole blocks] [8 - rem_k runs of SHORT ends] [8 - rem_k whole blocks] [rem_k LONG parts]
+// so that a CU gets either whole + long or short run + whole: the same number of key tiles (+ the segment overheads folded into the cut point L_k).
+// Engines with more runs come first in the rotation: where the sub-lists differ, a whole block that starts when a run ends precedes a long part
+// that starts when a whole block ends.
 struct SplitPlan {
   bool split = false;
-  int grid = 0, ncomb = 0, nparts = 0;
+  int grid = 0, nparts = 0, gen = 0;
   a3::Item* items = nullptr;
-  a3::Comb* comb = nullptr;
   uint16_t* po = nullptr;
   float* plse = nullptr;
+  int* pflag = nullptr;
 };
-constexpr int MIN_SEG = 4;          // key tiles: no segment shorter than this (a segment pays a prologue + an epilogue)
+constexpr int MIN_SEG = 4;          // key tiles: no segment shorter than this
+constexpr int SIG_SHORT = 5;        // cost of a short segment beyond its key tiles, in key tiles (prologue, epilogue, publish): measured ~7 us
+constexpr int SIG_LONG = 2;         // cost of the hand-over init of a long part
 
-bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, std::vector<a3::Comb>& comb, int& nparts, int& grid) {
-  const int nqb = (S + a3::QBLK - 1) / a3::QBLK, ntiles = (int)(attn_spad(S) / a3::KVB), hx = (H + 7) / 8, cu = ncu / 8;
-  if (cu < 1 || ntiles < 4 * MIN_SEG) return false;
+bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, int& nparts, int& grid) {
+  constexpr int NSE = 4;
+  const int nqb = (S + a3::QBLK - 1) / a3::QBLK, ntiles = (int)(attn_spad(S) / a3::KVB), hx = (H + 7) / 8, cu = ncu / 8, cs = cu / NSE;
+  if (cu < 2 * NSE || cu % NSE != 0 || ntiles < 4 * MIN_SEG) return false;
   std::vector<std::vector<a3::Item>> per(8);
   bool any = false;
   nparts = 0;
@@ -434,51 +496,71 @@ bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, std:
     for (int hh = 0; hh < hx; ++hh)
       for (int b = 0; b < B; ++b)
         for (int qb = 0; qb < nqb; ++qb)
-          if (x + 8 * hh < H) blocks.push_back(a3::Seg{x + 8 * hh, b, qb, 0, ntiles, -1});
-    const int nx = (int)blocks.size(), rem = nx % cu, full = nx - rem;
-    auto whole = [&](const a3::Seg& sg) { a3::Item it{}; it.nseg = 1; it.seg[0] = sg; per[x].push_back(it); };
-    for (int i = 0; i < full; ++i) whole(blocks[i]);
-    if (rem == 0) continue;
-    if (rem * 8 > cu * 7) {               // the last round is at least 7/8 full: not worth the partials
-      for (int i = full; i < nx; ++i) whole(blocks[i]);
-      continue;
+          if (x + 8 * hh < H) blocks.push_back(a3::Seg{x + 8 * hh, b, qb, 0, ntiles, -1, 0, 0});
+    const int nx = (int)blocks.size(), R = nx / cu, rem = nx % cu;
+    auto item1 = [](const a3::Seg& sg) { a3::Item it{}; it.nseg = 1; it.seg[0] = sg; return it; };
+    // engine k (in rotation order): rem_k blocks to cut, fewest first (= most runs first)
+    int remk[NSE], Lk[NSE];
+    bool ok = rem >= NSE && R >= 1 && rem * 4 <= cu * 3;       // every engine gets a block to cut; a round in front to hide the short ends in; a last round at most 3/4 full
+    for (int k = 0; k < NSE && ok; ++k) {
+      remk[k] = rem / NSE + (k >= NSE - rem % NSE ? 1 : 0);
+      const int n2 = cs - remk[k];
+      Lk[k] = (int)(((int64_t)remk[k] * (ntiles + SIG_SHORT) - (int64_t)SIG_LONG * n2) / cs);
+      ok = n2 >= 1 && Lk[k] >= 2 * MIN_SEG && ntiles - Lk[k] >= 2 * MIN_SEG;
     }
-    const int64_t T = (int64_t)rem * ntiles;
-    // one run per CU -- fewer when the runs would get short: a run of at least a third of a block keeps a block's partials at <= 4
-    const int m = (int)std::min<int64_t>(cu, T / std::max(2 * MIN_SEG, ntiles / 3 + 2));
-    if (m <= rem) {
-      for (int i = full; i < nx; ++i) whole(blocks[i]);
+    if (!ok) {
+      for (int i = 0; i < nx; ++i) per[x].push_back(item1(blocks[i]));
       continue;
     }
     any = true;
-    std::vector<int64_t> bd(m + 1);
-    for (int j = 0; j <= m; ++j) {
-      int64_t v = j * T / m;
-      const int r = (int)(v % ntiles);
-      if (r > 0 && r < MIN_SEG) v -= r;
-      else if (r > ntiles - MIN_SEG) v += ntiles - r;
-      bd[j] = v;
-    }
-    int cur_block = -1;                  // block (index into the remainder) whose Comb entry is open
-    for (int j = 0; j < m; ++j) {
-      a3::Item it{};
-      int64_t pos = bd[j];
-      while (pos < bd[j + 1]) {
-        const int bi = (int)(pos / ntiles), t0 = (int)(pos % ntiles);
-        const int n = (int)std::min<int64_t>(bd[j + 1] - pos, ntiles - t0);
-        if (it.nseg >= 2) return false;
-        a3::Seg sg = blocks[full + bi];
-        sg.t0 = t0; sg.n = n;
-        if (n < ntiles) {
-          sg.pidx = nparts++;
-          if (bi != cur_block) { comb.push_back(a3::Comb{sg.h, sg.b, sg.qb, sg.pidx, 0, {0, 0, 0}}); cur_block = bi; }
-          if (++comb.back().np > 4) return false;
-        }
-        it.seg[it.nseg++] = sg;
-        pos += n;
+    const int first_full = (R - 1) * cu, first_split = R * cu;
+    for (int i = 0; i < first_full; ++i) per[x].push_back(item1(blocks[i]));
+    std::vector<a3::Item> sub[NSE];
+    int split0 = first_split;
+    for (int k = 0; k < NSE; ++k) {
+      const int rk = remk[k], n2 = cs - rk, L = Lk[k], s = ntiles - L;
+      const a3::Seg* F = &blocks[first_full + k * cs];         // this engine's whole blocks
+      const a3::Seg* X = &blocks[split0];                      // and the blocks it cuts
+      split0 += rk;
+      for (int i = 0; i < rk; ++i) sub[k].push_back(item1(F[i]));
+      // the short ends [L, ntiles) of the rk blocks, end to end, cut into n2 runs of equal length
+      const int64_t Ts = (int64_t)rk * s;
+      std::vector<int64_t> bd(n2 + 1);
+      for (int j = 0; j <= n2; ++j) {
+        int64_t v = j * Ts / n2;
+        const int r = (int)(v % s);
+        if (r > 0 && r < MIN_SEG) v -= r;
+        else if (r > s - MIN_SEG) v += s - r;
+        bd[j] = v;
       }
-      per[x].push_back(it);
+      std::vector<int> in0(rk, 0), nin(rk, 0);
+      for (int j = 0; j < n2; ++j) {
+        a3::Item it{};
+        int64_t pos = bd[j];
+        while (pos < bd[j + 1]) {
+          const int bi = (int)(pos / s), off = (int)(pos % s);
+          const int n = (int)std::min<int64_t>(bd[j + 1] - pos, s - off);
+          if (it.nseg >= a3::MAX_SEG) return false;
+          a3::Seg sg = X[bi];
+          sg.t0 = L + off; sg.n = n; sg.out = nparts++;
+          if (nin[bi]++ == 0) in0[bi] = sg.out;
+          it.seg[it.nseg++] = sg;
+          pos += n;
+        }
+        if (it.nseg == 0) return false;                        // (an empty work-group would still wait for a CU of its engine)
+        sub[k].push_back(it);
+      }
+      for (int i = rk; i < cs; ++i) sub[k].push_back(item1(F[i]));
+      for (int i = 0; i < rk; ++i) {
+        a3::Seg sg = X[i];
+        sg.n = L; sg.nin = nin[i]; sg.in0 = in0[i];
+        if (nin[i] < 1) return false;
+        sub[k].push_back(item1(sg));
+      }
+      if ((int)sub[k].size() != 2 * cs) return false;
     }
+    for (int i = 0; i < 2 * cs; ++i)
+      for (int k = 0; k < NSE; ++k) per[x].push_back(sub[k][i]);
   }
   if (!any) return false;
   size_t slots = 0;
@@ -500,30 +582,30 @@ SplitPlan* plan_for(int B, int H, int S, hipStream_t stream) {
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
   if (!enabled) return nullptr;
+  // the generation number is a kernel argument: a captured launch would replay a stale one (and nothing may be allocated inside a capture)
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   const auto key = std::make_tuple(dev, B, H, S, stream);
   auto it = cache.find(key);
   if (it != cache.end()) return it->second.split ? &it->second : nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;      // no allocation inside a capture
   int ncu = 0;
   if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
   SplitPlan pl;
   std::vector<a3::Item> items;
-  std::vector<a3::Comb> comb;
-  if (build_plan(B, H, S, ncu, items, comb, pl.nparts, pl.grid)) {
-    pl.ncomb = (int)comb.size();
-    const size_t ib = items.size() * sizeof(a3::Item), cb = comb.size() * sizeof(a3::Comb);
-    const size_t pb = (size_t)pl.nparts * a3::QBLK * 128 * 2, lb = (size_t)pl.nparts * a3::QBLK * 4;
+  if (build_plan(B, H, S, ncu, items, pl.nparts, pl.grid)) {
+    const size_t ib = items.size() * sizeof(a3::Item);
+    const size_t pb = (size_t)pl.nparts * a3::QBLK * 128 * 2, lb = (size_t)pl.nparts * a3::QBLK * 4, fb = (size_t)pl.nparts * 4;
     char* base = nullptr;
-    const size_t o1 = (ib + 255) / 256 * 256, o2 = o1 + (cb + 255) / 256 * 256, o3 = o2 + (pb + 255) / 256 * 256;
-    if (hipMalloc((void**)&base, o3 + lb) == hipSuccess && hipMemcpy(base, items.data(), ib, hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemcpy(base + o1, comb.data(), cb, hipMemcpyHostToDevice) == hipSuccess) {
+    const size_t o1 = (ib + 255) / 256 * 256, o2 = o1 + (pb + 255) / 256 * 256, o3 = o2 + (lb + 255) / 256 * 256;
+    if (hipMalloc((void**)&base, o3 + fb) == hipSuccess && hipMemcpy(base, items.data(), ib, hipMemcpyHostToDevice) == hipSuccess &&
+        hipMemset(base + o1, getenv("AFX_ATTN_FILL") ? 0xff : 0, o3 - o1) == hipSuccess && hipMemset(base + o3, 0, fb) == hipSuccess &&
+        hipDeviceSynchronize() == hipSuccess) {
       pl.items = reinterpret_cast<a3::Item*>(base);
-      pl.comb = reinterpret_cast<a3::Comb*>(base + o1);
-      pl.po = reinterpret_cast<uint16_t*>(base + o2);
-      pl.plse = reinterpret_cast<float*>(base + o3);
+      pl.po = reinterpret_cast<uint16_t*>(base + o1);
+      pl.plse = reinterpret_cast<float*>(base + o2);
+      pl.pflag = reinterpret_cast<int*>(base + o3);
       pl.split = true;
     } else {
       (void)hipGetLastError();
@@ -534,21 +616,24 @@ SplitPlan* plan_for(int B, int H, int S, hipStream_t stream) {
 }
 }  // namespace
 
-// test hook: the schedule of a shape as plain integers (items: nseg, then 6 per segment; comb: 5 per entry)
-extern "C" int afx_debug_attn_plan(int B, int H, int S, int ncu, int* items_out, int max_items, int* comb_out, int max_comb, int* nparts, int* grid) {
+// test hook: the schedule of a shape as plain integers (per item: nseg, then 8 per segment x MAX_SEG)
+extern "C" int afx_debug_attn_plan(int B, int H, int S, int ncu, int* items_out, int max_items, int* nparts, int* grid) {
   std::vector<a3::Item> items;
-  std::vector<a3::Comb> comb;
   int np = 0, g = 0;
-  if (!build_plan(B, H, S, ncu, items, comb, np, g)) return 0;
+  if (!build_plan(B, H, S, ncu, items, np, g)) return 0;
   *nparts = np; *grid = g;
-  if ((int)items.size() > max_items || (int)comb.size() > max_comb) return -1;
+  if ((int)items.size() > max_items) return -1;
+  constexpr int W = 1 + 8 * a3::MAX_SEG;
   for (size_t i = 0; i < items.size(); ++i) {
-    int* d = items_out + i * 13;
+    int* d = items_out + i * W;
     d[0] = items[i].nseg;
-    for (int s_ = 0; s_ < 2; ++s_) { const a3::Seg& sg = items[i].seg[s_]; int* e = d + 1 + 6 * s_; e[0] = sg.h; e[1] = sg.b; e[2] = sg.qb; e[3] = sg.t0; e[4] = sg.n; e[5] = sg.pidx; }
+    for (int s_ = 0; s_ < a3::MAX_SEG; ++s_) {
+      const a3::Seg& sg = items[i].seg[s_];
+      int* e = d + 1 + 8 * s_;
+      e[0] = sg.h; e[1] = sg.b; e[2] = sg.qb; e[3] = sg.t0; e[4] = sg.n; e[5] = sg.out; e[6] = sg.nin; e[7] = sg.in0;
+    }
   }
-  for (size_t i = 0; i < comb.size(); ++i) { int* d = comb_out + i * 5; d[0] = comb[i].h; d[1] = comb[i].b; d[2] = comb[i].qb; d[3] = comb[i].p0; d[4] = comb[i].np; }
-  return (int)comb.size();
+  return (int)items.size();
 }
 
 hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* vt, uint16_t* o,
@@ -575,20 +660,19 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   const a3::Item* items = pl ? pl->items : nullptr;
   uint16_t* po = pl ? pl->po : nullptr;
   float* plse = pl ? pl->plse : nullptr;
-  hipEvent_t ev0 = launch_timer().start, ev1 = launch_timer().stop;
-  const bool timed = ev0 != nullptr && ev1 != nullptr;
-  if (timed)      // with a combine launch behind it the pair brackets both kernels
-    hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, ev0, pl ? nullptr : ev1, 0,
-                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse);
+  int* pflag = pl ? pl->pflag : nullptr;
+  const int gen = pl ? ++pl->gen : 0;
+  static int wt = -1;
+  if (wt < 0) {
+    const char* e = getenv("AFX_ATTN_HANDOVER");         // "fence": plain stores + release fence instead of write-through stores (A/B)
+    wt = (e && e[0] == 'f') ? 0 : 1;
+  }
+  if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
+    hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
+                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse, pflag, gen, wt);
   else
     hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx,
-                       items, po, plse);
-  if (pl) {
-    if (timed)
-      hipExtLaunchKernelGGL(attention_combine_kernel, dim3(pl->ncomb * 4), dim3(256), 0, stream, nullptr, ev1, 0, po, plse, pl->comb, o, ldo, lse, H, S, S_pad);
-    else
-      hipLaunchKernelGGL(attention_combine_kernel, dim3(pl->ncomb * 4), dim3(256), 0, stream, po, plse, pl->comb, o, ldo, lse, H, S, S_pad);
-  }
+                       items, po, plse, pflag, gen, wt);
   return hipGetLastError();
 }
 

@@ -1,10 +1,13 @@
-"""The KV-split schedule of the one-wave-per-SIMD attention (afx_attn3.hip build_plan): host logic, checked on the CPU through the
-library's test hook.  Every (head, sample, 256-query block, key tile) is covered exactly once; whole rounds keep whole blocks; the blocks
-of the under-filled last round are cut into one run of key tiles per CU; partial slots of a block are consecutive."""
+"""The balanced schedule of the one-wave-per-SIMD attention's last round (afx_attn3.hip build_plan): host logic, checked on the CPU through
+the library's test hook.  Every (head, sample, 256-query block, key tile) is covered exactly once; the blocks of the under-filled last round are
+cut once (long part [0, L) + short end [L, ntiles)); a long part names exactly the partial slots its block's short pieces write, and those pieces come
+EARLIER in the XCD's dispatch order; a greedy list schedule of the items ends close to (blocks x tiles) / CUs."""
 import ctypes as C
 
 import numpy as np
 import pytest
+
+W = 1 + 8 * 8
 
 
 @pytest.fixture(scope='module')
@@ -15,74 +18,112 @@ def lib():
 
 
 def plan(lib, B, H, S, ncu=256):
-    items = (C.c_int * (13 * 8192))()
-    comb = (C.c_int * (5 * 4096))()
+    items = (C.c_int * (W * 16384))()
     nparts, grid = C.c_int(0), C.c_int(0)
     lib.afx_debug_attn_plan.restype = C.c_int
-    n = lib.afx_debug_attn_plan(B, H, S, ncu, items, 8192, comb, 4096, C.byref(nparts), C.byref(grid))
+    n = lib.afx_debug_attn_plan(B, H, S, ncu, items, 16384, C.byref(nparts), C.byref(grid))
     if n <= 0:
         return None
-    it = np.frombuffer(items, dtype=np.int32)[:13 * grid.value].reshape(grid.value, 13).copy()
-    cb = np.frombuffer(comb, dtype=np.int32)[:5 * n].reshape(n, 5).copy()
-    return it, cb, nparts.value, grid.value
+    it = np.frombuffer(items, dtype=np.int32)[:W * grid.value].reshape(grid.value, W).copy()
+    return it, nparts.value, grid.value
 
 
-@pytest.mark.parametrize('B,H,S', [(1, 24, 4608), (1, 24, 4224), (1, 24, 4173), (2, 24, 4608), (1, 8, 4608), (1, 16, 2048), (1, 3, 1000), (4, 24, 4608)])
+def segs(it, i):
+    return [tuple(it[i, 1 + 8 * s: 9 + 8 * s]) for s in range(it[i, 0])]
+
+
+def worth_splitting(nblk, ntiles):
+    R, rem = divmod(nblk, 32)
+    if not (rem >= 4 and R >= 1 and rem * 4 <= 32 * 3 and ntiles >= 16):
+        return False
+    for k in range(4):
+        rk = rem // 4 + (1 if k >= 4 - rem % 4 else 0)
+        L = (rk * (ntiles + 5) - 2 * (8 - rk)) // 8          # the cut point of engine k: whole + long = short run + whole, segment overheads folded in
+        if 8 - rk < 1 or L < 8 or ntiles - L < 8:
+            return False
+    return True
+
+
+def simulate(it, x, grid, cost):
+    """The dispatcher tools/dispatch_probe.hip shows: the j-th work-group of an XCD goes to engine j % 4 (8 CUs) and waits IN ORDER -- blocking
+    the ones behind it -- until that engine has a free CU.  Returns the makespan of XCD x's list."""
+    free = np.zeros((4, 8))
+    now = 0.0
+    j = 0
+    for i in range(x, grid, 8):
+        sg = segs(it, i)
+        if not sg:
+            continue
+        e = j % 4
+        j += 1
+        c = int(np.argmin(free[e]))
+        now = max(now, free[e, c])
+        free[e, c] = now + cost(sg)
+    return free.max()
+
+
+@pytest.mark.parametrize('B,H,S', [(1, 24, 4608), (1, 24, 4224), (1, 24, 4173), (2, 24, 4608), (1, 8, 4608), (1, 16, 2048), (1, 3, 1000), (4, 24, 4608),
+                                   (1, 40, 4608), (3, 24, 1024)])
 def test_plan_covers_every_tile_once(lib, B, H, S):
     p = plan(lib, B, H, S)
     nqb, ntiles = (S + 255) // 256, (S + 63) // 64
-    if p is None:        # no XCD has an under-filled last round worth splitting
-        per_xcd = [sum(1 for h in range(H) if h % 8 == x) * nqb * B for x in range(8)]
-        assert all(n % 32 == 0 or (n % 32) * 8 > 32 * 7 for n in per_xcd) or ntiles < 16
+    per_xcd = [sum(1 for h in range(H) if h % 8 == x) * nqb * B for x in range(8)]
+    if p is None:
+        assert not any(worth_splitting(n, ntiles) for n in per_xcd)
         return
-    lmin = max(8, ntiles // 3 + 2)
-    it, cb, nparts, grid = p
+    it, nparts, grid = p
     assert grid % 8 == 0
     cover = np.zeros((H, B, nqb, ntiles), dtype=np.int32)
-    seen_parts = set()
-    load = np.zeros(grid, dtype=np.int64)
+    writer = {}                      # partial slot -> (item index, block)
     for i in range(grid):
-        nseg = it[i, 0]
-        assert 0 <= nseg <= 2
-        for s in range(nseg):
-            h, b, qb, t0, n, pidx = it[i, 1 + 6 * s: 7 + 6 * s]
+        assert 0 <= it[i, 0] <= 8
+        for (h, b, qb, t0, n, out, nin, in0) in segs(it, i):
             assert h % 8 == i % 8, 'a head stays on its XCD'
             assert n >= 4 and t0 >= 0 and t0 + n <= ntiles
             cover[h, b, qb, t0:t0 + n] += 1
-            load[i] += n
-            if n == ntiles:
-                assert pidx == -1
-            else:
-                assert 0 <= pidx < nparts and pidx not in seen_parts
-                seen_parts.add(pidx)
+            if out >= 0:
+                assert 0 <= out < nparts and out not in writer and nin == 0
+                writer[out] = (i, (h, b, qb))
     assert (cover == 1).all()
-    assert len(seen_parts) == nparts
-    # partial slots of a split block are consecutive and listed once
-    for h, b, qb, p0, np_ in cb:
-        assert 2 <= np_ <= 4
-        segs = sorted((t0, n, pidx) for i in range(grid) for s in range(it[i, 0])
-                      for (hh, bb, qq, t0, n, pidx) in [it[i, 1 + 6 * s: 7 + 6 * s]] if (hh, bb, qq) == (h, b, qb))
-        assert [x[2] for x in segs] == list(range(p0, p0 + np_))
-        assert segs[0][0] == 0 and sum(x[1] for x in segs) == ntiles
-    assert sum(c[4] for c in cb) == nparts
-    # balance: per XCD, the CU that gets slot j of the whole rounds and slot j of the split round carries about the mean load
+    assert len(writer) == nparts
+    used = set()
+    for i in range(grid):
+        for (h, b, qb, t0, n, out, nin, in0) in segs(it, i):
+            if nin == 0:
+                continue
+            assert out == -1 and t0 == 0 and 1 <= nin <= 4
+            for s in range(in0, in0 + nin):
+                wi, blk = writer[s]
+                assert blk == (h, b, qb), 'a long part starts from ITS block\'s partials'
+                assert wi % 8 == i % 8 and wi < i, 'written earlier in the same XCD\'s dispatch order'
+                assert s not in used
+                used.add(s)
+            # long part + its short pieces = the whole key range
+            assert n + sum(sg[4] for j in range(grid) for sg in segs(it, j) if sg[5] in range(in0, in0 + nin)) == ntiles
+    assert used == set(writer)
+    # makespan under the in-order, engine-rotating dispatcher; cost = key tiles + a per-segment overhead
+    def cost(sg):
+        return sum(s_[4] + (5 if s_[5] >= 0 else 3 + (2 if s_[6] else 0)) for s_ in sg)
     for x in range(8):
-        lx = load[x::8]
-        nblk = sum(1 for h in range(H) if h % 8 == x) * nqb * B
-        if nblk % 32 == 0 or (nblk % 32) * 8 > 32 * 7:
+        if not worth_splitting(per_xcd[x], ntiles):
             continue
-        rem = nblk % 32
-        m = min(32, rem * ntiles // lmin)
-        if m <= rem:
-            continue
-        tail = lx[nblk - rem:nblk - rem + m]
-        assert tail.max() - tail.min() <= 8 and abs(tail.mean() - rem * ntiles / m) < 1e-6
-        assert (lx[nblk - rem + m:] == 0).all()
+        span = simulate(it, x, grid, cost)
+        ideal = per_xcd[x] * (ntiles + 3) / 32
+        plain = -(-per_xcd[x] // 32) * (ntiles + 3)
+        assert span <= 1.10 * ideal + 6, (span, ideal, plain)
+        assert span < plain - 0.4 * (plain - ideal), (span, ideal, plain)
 
 
 def test_flux_shape_numbers(lib):
-    it, cb, nparts, grid = plan(lib, 1, 24, 4608)
-    assert grid == 512                       # two rounds of 256 work-groups
-    assert len(cb) == 8 * 22                 # the 22 blocks of each XCD's second round are split
-    assert (it[:256, 0] == 1).all() and (it[:256, 5] == 72).all()
-    assert it[256:, 5].max() <= 54           # 49.5 key tiles per CU in the second round (+- snapping)
+    it, nparts, grid = plan(lib, 1, 24, 4608)
+    assert grid == 8 * 64
+    x0 = [segs(it, i) for i in range(0, grid, 8)]
+    # engine k = slots k, k + 4, ...: [rem_k whole] [8 - rem_k runs of short ends] [8 - rem_k whole] [rem_k long parts], rem_k = 5, 5, 6, 6
+    for k, rk in enumerate((5, 5, 6, 6)):
+        sub = x0[k::4]
+        assert len(sub) == 16
+        assert all(len(s) == 1 and s[0][4] == 72 and s[0][5] == -1 and s[0][6] == 0 for s in sub[:rk] + sub[8:16 - rk])
+        assert all(1 <= len(s) <= 8 and all(g[5] >= 0 for g in s) for s in sub[rk:8])
+        L = sub[16 - rk][0][4]
+        assert 40 <= L <= 62 and all(len(s) == 1 and s[0][4] == L and s[0][6] >= 1 and s[0][3] == 0 for s in sub[16 - rk:])
+    assert nparts >= 8 * 22

@@ -31,7 +31,7 @@ It writes arcflow_amd/csrc/gen/a3_*.inc (committed; the build does not run this 
     a3_body{0..3}.inc one loop iteration with ring slot J (see the phase table in afx_attn3.hip)
     a3_final.inc     the last tile
     a3_rescale.inc   cold path: O^T of a slab times alpha (two macros)
-    a3_readout.inc   accumulator file -> VGPR scalars, one 32-row tile of O^T at a time (macros for the epilogue)
+    a3_readout.inc   accumulator file <-> VGPR scalars, one 32-row tile of O^T at a time (macros for the epilogue / the hand-over init)
 Usage: python tools/gen_attn3.py
 """
 import argparse
@@ -370,6 +370,13 @@ def readout():
             text = '\\n\\t'.join(f'v_accvgpr_read_b32 %{r}, a{lo + r}' for r in range(16))
             outs = ', '.join(f'"=v"(ox[{r}])' for r in range(16))
             out.append(f'#define A3_READ_{sl}_{d} ' + asm(text, outs, ''))
+    # the reverse (a segment that continues from handed-over partial results): ox[0..15] -> one 32-row tile of O^T
+    for sl in range(2):
+        for d in range(4):
+            lo = 64 * sl + 16 * d
+            text = '\\n\\t'.join(f'v_accvgpr_write_b32 a{lo + r}, %{r}' for r in range(16))
+            ins = ', '.join(f'"v"(ox[{r}])' for r in range(16))
+            out.append(f'#define A3_WRITE_{sl}_{d} ' + asm(text, '', ins))
     return out
 
 
