@@ -99,9 +99,10 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
                                                                   int64_t ldo, int H, int S, int S_pad, int nqb, int B, float* __restrict__ lse, int dbg,
                                                                   uint8_t* __restrict__ o8, int64_t ldo8, uint8_t* __restrict__ omx, int64_t ld_omx,
                                                                   const Item* __restrict__ work, bf16_t* __restrict__ po, float* __restrict__ plse,
-                                                                  int* __restrict__ pflag, int gen, int wt) {
+                                                                  int* __restrict__ pflag, int gen, int wt, unsigned long long* __restrict__ tl) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int nseg = work != nullptr ? __builtin_amdgcn_readfirstlane(work[blockIdx.x].nseg) : 1;
+  if (tl != nullptr && threadIdx.x == 0) tl[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();       // (afx_debug_attn_timeline: when each work-group ran, 100 MHz ticks)
 #pragma unroll 1
   for (int si = 0; si < nseg; ++si) {
   // every lane constant is derived INSIDE the segment loop from an opaque copy of threadIdx: nothing a segment computes lives through the
@@ -233,21 +234,23 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     // ever wait for MORE than they need when other loads are outstanding)
     const float inv_c = 1.0f / c;
     float ox[16];
-    // the partial rows were written through (sc0 sc1): read them with agent-scope loads (sc1, served past this CU's L1) -- MI355X_MICROARCH "sc1 stores AND sc1 loads"
-#define A3_LD_LSE(P) __hip_atomic_load(plse + (int64_t)(in0 + (P)) * QBLK + rloc_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+    // Plain loads: the acquire above emptied this CU's L1, and no L2 can hold an older copy of a slot -- a launch starts with the L2s' stale lines
+    // invalidated and nobody reads a slot before its producer has written it through.  The weights of the (at most 4) partials are formed once per
+    // slab and every load of a tile is independent of the others, so hipcc batches them (the first version paid two serial fabric latencies per tile: 13-16 us).
+#define A3_LD_LSE(P) plse[(int64_t)(in0 + (P)) * QBLK + rloc_]
 #define A3_INIT_TILE(SL, D)                                                                                        \
     {                                                                                                              \
       _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) ox[r_] = 0.f;                                              \
-      for (int p_ = 0; p_ < nin; ++p_) {                                                                           \
-        const float w_ = __builtin_amdgcn_exp2f(A3_LD_LSE(p_) - lmax_);                                            \
-        const bf16_t* src_ = po + ((int64_t)(in0 + p_) * QBLK + rloc_) * 128 + (D) * 32 + hi * 4;                  \
-        _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                         \
-          const uint64_t v64_ = __hip_atomic_load(reinterpret_cast<const uint64_t*>(src_ + 8 * g_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
-          const uint32_t v_[2] = {(uint32_t)v64_, (uint32_t)(v64_ >> 32)};                                         \
-          ox[4 * g_ + 0] += w_ * __uint_as_float(v_[0] << 16);                                                     \
-          ox[4 * g_ + 1] += w_ * __uint_as_float(v_[0] & 0xffff0000u);                                             \
-          ox[4 * g_ + 2] += w_ * __uint_as_float(v_[1] << 16);                                                     \
-          ox[4 * g_ + 3] += w_ * __uint_as_float(v_[1] & 0xffff0000u);                                             \
+      _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) {                                                           \
+        if (p_ < nin) {                                                                                            \
+          const bf16_t* src_ = po + ((int64_t)(in0 + p_) * QBLK + rloc_) * 128 + (D) * 32 + hi * 4;                \
+          _Pragma("unroll") for (int g_ = 0; g_ < 4; ++g_) {                                                       \
+            const u32x2_t v_ = *reinterpret_cast<const u32x2_t*>(src_ + 8 * g_);                                   \
+            ox[4 * g_ + 0] += w_[p_] * __uint_as_float(v_[0] << 16);                                               \
+            ox[4 * g_ + 1] += w_[p_] * __uint_as_float(v_[0] & 0xffff0000u);                                       \
+            ox[4 * g_ + 2] += w_[p_] * __uint_as_float(v_[1] << 16);                                               \
+            ox[4 * g_ + 3] += w_[p_] * __uint_as_float(v_[1] & 0xffff0000u);                                       \
+          }                                                                                                        \
         }                                                                                                          \
       }                                                                                                            \
       A3_WRITE_##SL##_##D                                                                                          \
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
 #define A3_INIT_SLAB(SL, MV, L0V, L1V)                                                                             \
     {                                                                                                              \
       const int rloc_ = wave * 64 + (SL) * 32 + ql;                                                                \
-      float lmax_ = -INFINITY, wsum_ = 0.f;                                                                        \
-      for (int p_ = 0; p_ < nin; ++p_) lmax_ = fmaxf(lmax_, A3_LD_LSE(p_));                                        \
-      for (int p_ = 0; p_ < nin; ++p_) wsum_ += __builtin_amdgcn_exp2f(A3_LD_LSE(p_) - lmax_);                     \
+      float w_[4], lmax_ = -INFINITY, wsum_ = 0.f;                                                                 \
+      _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) { w_[p_] = p_ < nin ? A3_LD_LSE(p_) : -INFINITY; lmax_ = fmaxf(lmax_, w_[p_]); } \
+      _Pragma("unroll") for (int p_ = 0; p_ < 4; ++p_) { w_[p_] = __builtin_amdgcn_exp2f(w_[p_] - lmax_); wsum_ += w_[p_]; }           \
       A3_INIT_TILE(SL, 0) A3_INIT_TILE(SL, 1) A3_INIT_TILE(SL, 2) A3_INIT_TILE(SL, 3)                              \
       MV = lmax_ * inv_c;                                                                                          \
       L0V = hi == 0 ? wsum_ : 0.f;      /* a row's sum lives as two partial sums, one per half-wave */                \
@@ -446,6 +449,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     __builtin_amdgcn_s_barrier();
   }
   }   // segments
+  if (tl != nullptr && threadIdx.x == 0) tl[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 }  // namespace a3
@@ -481,8 +485,8 @@ struct SplitPlan {
   int* pflag = nullptr;
 };
 constexpr int MIN_SEG = 4;          // key tiles: no segment shorter than this
-constexpr int SIG_SHORT = 5;        // cost of a short segment beyond its key tiles, in key tiles (prologue, epilogue, publish): measured ~7 us
-constexpr int SIG_LONG = 2;         // cost of the hand-over init of a long part
+constexpr int SIG_SHORT = 7;        // cost of a short segment beyond its key tiles, in key tiles (prologue, two unpipelined tiles, epilogue, publish): 11.5 us measured (tools/attn_timeline.py)
+constexpr int SIG_LONG = 2;         // cost of a long part beyond a whole block's own overhead (flag wait, acquire, init from the partials)
 
 bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, int& nparts, int& grid) {
   constexpr int NSE = 4;
@@ -544,6 +548,7 @@ bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, int&
           a3::Seg sg = X[bi];
           sg.t0 = L + off; sg.n = n; sg.out = nparts++;
           if (nin[bi]++ == 0) in0[bi] = sg.out;
+          if (nin[bi] > 4) return false;                       // (the hand-over init merges at most 4 partials)
           it.seg[it.nseg++] = sg;
           pos += n;
         }
@@ -616,6 +621,23 @@ SplitPlan* plan_for(int B, int H, int S, hipStream_t stream) {
 }
 }  // namespace
 
+// debug hook (tools/attn_timeline.py): record start / end of every work-group of the NEXT launches (enable = 1), read them back (start, end) x grid
+namespace {
+unsigned long long* g_tl = nullptr;
+int g_tl_cap = 0, g_tl_grid = 0;
+}
+extern "C" int afx_debug_attn_timeline(int enable) {
+  if (!enable) { g_tl_cap = -1; return 0; }
+  if (g_tl == nullptr && hipMalloc((void**)&g_tl, 2 * 8192 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  g_tl_cap = 8192;
+  return 0;
+}
+extern "C" int afx_debug_attn_timeline_read(unsigned long long* host, int max_wg) {
+  if (g_tl == nullptr || g_tl_grid > max_wg) return -1;
+  if (hipMemcpy(host, g_tl, 2 * (size_t)g_tl_grid * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return g_tl_grid;
+}
+
 // test hook: the schedule of a shape as plain integers (per item: nseg, then 8 per segment x MAX_SEG)
 extern "C" int afx_debug_attn_plan(int B, int H, int S, int ncu, int* items_out, int max_items, int* nparts, int* grid) {
   std::vector<a3::Item> items;
@@ -662,6 +684,8 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   float* plse = pl ? pl->plse : nullptr;
   int* pflag = pl ? pl->pflag : nullptr;
   const int gen = pl ? ++pl->gen : 0;
+  unsigned long long* tl = nullptr;
+  if (g_tl_cap > 0 && (int)grid.x <= g_tl_cap) { tl = g_tl; g_tl_grid = (int)grid.x; }
   static int wt = -1;
   if (wt < 0) {
     const char* e = getenv("AFX_ATTN_HANDOVER");         // "fence": plain stores + release fence instead of write-through stores (A/B)
@@ -669,10 +693,10 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
-                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse, pflag, gen, wt);
+                          q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse, pflag, gen, wt, tl);
   else
     hipLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx,
-                       items, po, plse, pflag, gen, wt);
+                       items, po, plse, pflag, gen, wt, tl);
   return hipGetLastError();
 }
 
