@@ -36,12 +36,8 @@ def worth_splitting(nblk, ntiles):
     R, rem = divmod(nblk, 32)
     if not (rem >= 4 and R >= 1 and rem * 4 <= 32 * 3 and ntiles >= 16):
         return False
-    for k in range(4):
-        rk = rem // 4 + (1 if k >= 4 - rem % 4 else 0)
-        L = (rk * (ntiles + 7) - 2 * (8 - rk)) // 8          # the cut point of engine k: whole + long = short run + whole, segment overheads folded in
-        if 8 - rk < 1 or L < 8 or ntiles - L < 8:
-            return False
-    return True
+    L = (rem * (ntiles + 7) - 2 * (32 - rem)) // 32           # the cut point: whole + long = short run + whole, segment overheads folded in
+    return L >= 8 and ntiles - L >= 8 and 8 - (rem // 4 + (1 if rem % 4 else 0)) >= 1
 
 
 def simulate(it, x, grid, cost):
@@ -125,5 +121,5 @@ def test_flux_shape_numbers(lib):
         assert all(len(s) == 1 and s[0][4] == 72 and s[0][5] == -1 and s[0][6] == 0 for s in sub[:rk] + sub[8:16 - rk])
         assert all(1 <= len(s) <= 8 and all(g[5] >= 0 for g in s) for s in sub[rk:8])
         L = sub[16 - rk][0][4]
-        assert 40 <= L <= 62 and all(len(s) == 1 and s[0][4] == L and s[0][6] >= 1 and s[0][3] == 0 for s in sub[16 - rk:])
+        assert L == x0[60][0][4] and 48 <= L <= 58 and all(len(s) == 1 and s[0][4] == L and s[0][6] >= 1 and s[0][3] == 0 for s in sub[16 - rk:])
     assert nparts >= 8 * 22

@@ -29,18 +29,18 @@ for impl, name in ((3, 'plain grid'), (0, 'balanced')):
     assert lib.afx_debug_attn_timeline(1) == 0
     ops.attention(q, k, v)
     torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (2 * 8192))()
+    buf = (C.c_ulonglong * (4 * 8192))()
     lib.afx_debug_attn_timeline_read.restype = C.c_int
     ng = lib.afx_debug_attn_timeline_read(buf, 8192)
     lib.afx_debug_attn_timeline(0)
-    t = np.frombuffer(buf, dtype=np.uint64)[:2 * ng].reshape(ng, 2).astype(np.int64)
+    t = np.frombuffer(buf, dtype=np.uint64)[:4 * ng].reshape(ng, 4).astype(np.int64)
     t0 = t[:, 0].min()
     us = (t - t0) / 100.0
-    print(f'== {name}: {ng} work-groups, makespan {us[:, 1].max():.1f} us; per XCD: ' + ' '.join(f'{us[x::8, 1].max():.0f}' for x in range(8)))
+    print(f'== {name}: {ng} work-groups, makespan {us[:, 3].max():.1f} us; per XCD: ' + ' '.join(f'{us[x::8, 3].max():.0f}' for x in range(8)))
     for i in range(0, ng, 8):
         desc = ''
         if impl == 0 and plan is not None:
             ns = plan[i, 0]
             desc = ' | '.join(f'h{plan[i, 1 + 8 * s_]} q{plan[i, 3 + 8 * s_]} [{plan[i, 4 + 8 * s_]},+{plan[i, 5 + 8 * s_]}) out {plan[i, 6 + 8 * s_]} in {plan[i, 7 + 8 * s_]}' for s_ in range(ns))
-        print(f'{i // 8:3d} se{(i // 8) % 4}  {us[i, 0]:7.1f} {us[i, 1]:7.1f}  ({us[i, 1] - us[i, 0]:6.1f})  {desc}')
+        print(f'{i // 8:3d} se{(i // 8) % 4}  {us[i, 0]:7.1f} {us[i, 3]:7.1f}  ({us[i, 3] - us[i, 0]:6.1f}; last segment: prologue issued +{us[i, 1] - us[i, 0]:5.1f}, loop entered +{us[i, 2] - us[i, 0]:5.1f})  {desc}')
 ops.set_attn_impl(0)
