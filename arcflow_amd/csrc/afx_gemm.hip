@@ -629,9 +629,12 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
     // The per-lane test `column >= gelu_col0` made every one of the 32 steps its own basic block behind an exec-mask branch (a lone wave pays ~30 cycles of
     // refetch per taken branch, and no step overlaps the next one's exchange / loads): 14.6 k cycles per 256 x 256 tile against 10.2 k without GELU.  A wave's
     // columns are (in every launch of the forward) all activated or none: decide once, wave-uniformly, and run straight-line code.
+#ifndef AFX_GELU_PER_LANE         // (-DAFX_GELU_PER_LANE: the per-lane test everywhere, for A/B builds)
     if (col_base >= P.gelu_col0) epi_store_fast<EPI_GELU_ALL, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
     else if (col_base + 16 * NJ <= P.gelu_col0) epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
-    else epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+    else
+#endif
+    epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
   }
   else if (SWAP && !FP8 && !PRE && !(MI == 8 && NJ == 4) && P.bias_rows) epi_store_fast<EPI_NONE, MI, NJ, SWAP, false, false, true>(P, acc, row_base, col_base, frow, fq);
   else epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
