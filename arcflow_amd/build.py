@@ -29,18 +29,21 @@ def audit_no_scratch(asm_path: str, kernel_substrs) -> None:
     """Every kernel of the file whose mangled name contains one of `kernel_substrs` must have private_segment_fixed_size 0."""
     import re
     text = open(asm_path).read()
-    seen = 0
+    seen = {k: 0 for k in kernel_substrs}
     for m in re.finditer(r'\.amdhsa_kernel (\S+)', text):
         name = m.group(1)
-        if not any(k in name for k in kernel_substrs):
+        hits = [k for k in kernel_substrs if k in name]
+        if not hits:
             continue
-        seen += 1
+        for k in hits:
+            seen[k] += 1
         size = re.search(r'private_segment_fixed_size\s+(\d+)', text[m.start():m.start() + 4000])
         if size is None or int(size.group(1)) != 0:
             raise RuntimeError(f'{asm_path}: kernel {name} uses {size.group(1) if size else "?"} bytes of scratch: a spill inside an inline-asm MFMA stream '
                                f'is not hazard-checked by hipcc -- reduce its register pressure')
-    if seen == 0:
-        raise RuntimeError(f'{asm_path}: none of {kernel_substrs} found by the scratch audit')
+    missing = [k for k, n in seen.items() if n == 0]
+    if missing:       # a listed instantiation that no longer exists (a changed template signature) would silently drop out of the audit
+        raise RuntimeError(f'{asm_path}: the scratch audit found no kernel matching {missing}: update NO_SCRATCH in arcflow_amd/build.py')
 
 
 def lib_path() -> str:

@@ -1956,8 +1956,9 @@ bool gemm_fp8_mx_ok(int64_t rows_total, int N, int K) {
   (void)rows_total; (void)N;                       // a block-scaled launch always takes the one-wave-per-SIMD kernel, whatever its tile count
   const char* e = getenv("AFX_FP8_V3");
   const char* k = getenv("AFX_GEMM_SK");
-  const char* m = getenv("AFX_GEMM_IMPL");
-  return !(e && e[0] == '0') && !(k && atoi(k) != 0) && !(m && (m[0] == '1' || m[0] == '2')) && K % 512 == 0 && K >= 512;
+  if (gemm_mode().impl < 0) (void)gemm_qk_fusion_available();      // (reads AFX_GEMM_IMPL once, like launch_gemm's first call)
+  // the same predicate launch_gemm applies: the kernel choice may have been overridden by afx_gemm_set_mode() (parity tests, A/B runs), not only by the environment
+  return !(e && e[0] == '0') && !(k && atoi(k) != 0) && gemm_mode().impl == 3 && K % 512 == 0 && K >= 512;
 }
 
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {

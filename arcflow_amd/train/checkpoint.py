@@ -147,6 +147,13 @@ def wait_pending_save() -> None:
         raise _pending_error.pop()
 
 
+def check_pending_save() -> None:
+    """Cheap, non-blocking: re-raise the error of a background save that has already failed (tools/train.py calls it every iteration, so a full
+    disk stops the run at once instead of at the next save_interval)."""
+    if _pending_error:
+        raise _pending_error.pop()
+
+
 def save_checkpoint_async(distiller, out_dir: str, filename_tmpl: str = 'iter_{}.pth', create_symlink: bool = True, **kw) -> str:
     """``save_checkpoint`` with the file write off the training loop: the state is copied to host memory here (that part synchronises the device:
     ~1 s for the Qwen-Image adapter set), pickling and the ~6 GB write run in a thread.  The file appears under its final name only when complete
@@ -158,18 +165,25 @@ def save_checkpoint_async(distiller, out_dir: str, filename_tmpl: str = 'iter_{}
     ckpt = build_checkpoint(distiller, **kw)
 
     def work():
+        tmp = path + '.tmp'
         try:
-            tmp = path + '.tmp'
             with open(tmp, 'wb') as f:
                 torch.save(ckpt, f)
                 f.flush()
+                os.fsync(f.fileno())            # the data is on the disk before the final name exists
             os.replace(tmp, path)
-            if create_symlink:
-                link = os.path.join(out_dir, 'latest.pth')
-                if os.path.lexists(link):
-                    os.remove(link)
-                os.symlink(os.path.basename(path), link)
-        except BaseException as e:      # noqa: BLE001  (handed to the training thread by wait_pending_save)
+            if create_symlink:                  # latest.pth moves atomically too: a kill between "remove" and "symlink" would leave a run without it
+                link, tmp_link = os.path.join(out_dir, 'latest.pth'), os.path.join(out_dir, '.latest.pth.tmp')
+                if os.path.lexists(tmp_link):
+                    os.remove(tmp_link)
+                os.symlink(os.path.basename(path), tmp_link)
+                os.replace(tmp_link, link)
+        except BaseException as e:      # noqa: BLE001  (handed to the training thread by wait_pending_save / check_pending_save)
+            try:
+                if os.path.exists(tmp):
+                    os.remove(tmp)              # no multi-GB *.tmp left behind by a failed write
+            except OSError:
+                pass
             _pending_error.append(e)
 
     _pending_save = threading.Thread(target=work, name='arcflow-checkpoint-writer')

@@ -140,7 +140,8 @@ class ArcFlowDistiller:
         packed['mod_final.weight'], packed['mod_final.bias'] = self.w_no, self.b_no
         self._sync_working_copies()
         self.trunk = None
-        if cfg.lora_rank > 0:      # adapted weights get private merged copies inside `packed` (teacher keeps the frozen ones)
+        if cfg.lora_rank > 0:      # the adapters run UN-merged through the trunk on the frozen tensors (shared with the teacher) + their own B columns;
+                                   # the student ENGINE stays bound to the frozen weights until student_forward() asks the trunk for W + B A copies
             self.trunk = LoraTrunk(self.student, packed, cfg.lora_rank, self.params, self._off[4],
                                    generator=torch.Generator(device=self.device).manual_seed(init_seed))
             self.ema[self._off[4]:].copy_(self.params[self._off[4]:])
@@ -233,8 +234,16 @@ class ArcFlowDistiller:
         return (self.iteration * 7919 + step_id * 104729 + self.reducer.rank * 15485863 + getattr(self, '_chunk', 0) * 32452843 + 12345) & 0x7fffffff
 
     def _student(self, x, sigma, cond):
+        if self.trunk is not None:
+            self.trunk.ensure_merged()      # the engine must see W + B A of the LIVE adapters (stale after every optimizer step / checkpoint load)
         return self.student(x.to(torch.bfloat16), sigma, cond['prompt_embeds'], cond.get('pooled'),
                             self._guid(x.shape[0]), cond['hp'], cond['wp'])
+
+    def student_forward(self, x, sigma, cond):
+        """The live student through the inference engine (validation, sampling, export checks): with LoRA adapters the engine is re-bound to
+        W + B A of the current parameters first (lazily: only when an optimizer step or a checkpoint load changed them since).  Without dropout
+        this equals student_forward_unmerged() up to one bf16 rounding of the merged weights."""
+        return self._student(x, sigma, cond)
 
     def _guid(self, B, teacher: bool = False):
         if self.family != 'flux' or not self.student.guidance_embeds:

@@ -30,6 +30,8 @@ def init_distributed(local_rank: int):
     backend = os.environ.get('ARCFLOW_DIST_BACKEND', 'nccl')
     index = 0 if os.environ.get('ARCFLOW_DIST_ONE_DEVICE', '0') == '1' else local_rank
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    # (HSA_ENABLE_IPC_MODE_LEGACY=0 must be set before the process's FIRST torch.cuda call to have any effect: launchers export it, tools/train.py
+    # sets it at the top of main(); here it only covers callers that have not touched the device yet)
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(index)
     if backend == 'nccl':

@@ -130,6 +130,7 @@ class LoraTrunk:
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
         self._ones: Dict[int, torch.Tensor] = {}
         self._merged: Dict[str, torch.Tensor] = {}   # bind_merged(): private merged copies for the student engine, on request
+        self._merged_dirty = True                    # the engine's weights are NOT W + B A of the live adapters (refresh() sets it, bind_merged() clears it)
         # Keep instead of recompute (288 GB HBM): the training forward leaves the outputs of every block's GEMMs and attention in `stash`
         # and the backward reads them back; only element-wise work (LayerNorm-modulate, RoPE, GELU, dropout) is redone.  The reference
         # checkpoints every block and recomputes its whole forward (arcflux.py:181-189) because it has to fit 80 GB.  ARCFLOW_TRAIN_RECOMPUTE=1
@@ -173,8 +174,9 @@ class LoraTrunk:
 
     def refresh(self):
         """After an optimizer step (or a checkpoint load): bf16 working copies of A / B and the B columns / B^T rows of the extended
-        weights.  Nothing else changes -- W is frozen."""
+        weights.  Nothing else changes -- W is frozen.  Whatever bind_merged() gave the student engine is stale from here on."""
         r = self.r
+        self._merged_dirty = True
         for sp in self.specs:
             a16 = ops.cast_bf16(self.A(sp))
             b16 = ops.cast_bf16(self.B(sp))
@@ -295,9 +297,16 @@ class LoraTrunk:
             out[sp.name] = ops.linear(b16, at, None, epilogue='gate_res', gate=ones, residual=w.contiguous(), rows_per_batch=sp.out_f)
         return out
 
+    def ensure_merged(self) -> None:
+        """bind_merged() if the adapters changed since the last one (every optimizer step / checkpoint load does): what a forward of the student
+        ENGINE has to call first -- bound to the frozen weights it would silently evaluate the un-adapted trunk with the trained heads."""
+        if self._merged_dirty:
+            self.bind_merged()
+
     def bind_merged(self) -> None:
         """Give the student ENGINE the merged weights W + B A of the live adapters (validation / inference with the distiller's own
-        student; the training step itself never needs them: its blocks run through this trunk on the extended frozen weights)."""
+        student; the training step itself never needs them: its blocks run through this trunk on the extended frozen weights).
+        ArcFlowDistiller.student_forward() does this lazily through ensure_merged()."""
         ms = self.merged_state()
         upd = {}
         for key, sps in self.by_key.items():
@@ -308,6 +317,7 @@ class LoraTrunk:
                 m[sp.row0:sp.row0 + sp.out_f].copy_(ms[sp.name])
             upd[key + '.weight'] = m
         self.eng.bind_packed(upd)
+        self._merged_dirty = False
 
     # ------------------------------------------------------------------ LoRA gradients of one linear
     def _dmod_ln(self, x: torch.Tensor, dxn: torch.Tensor, off_scale: int, off_shift: int) -> None:

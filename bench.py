@@ -116,15 +116,31 @@ def cpu_baseline(budget_s: float = 12.0):
 GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 7, false> + afx::gemm_kernel_v3<8, 8, false>'
 if os.environ.get('AFX_GEMM_IMPL', '3')[:1] == '2':
     GEMM_KERNEL_NAME = 'afx::gemm_kernel_v2<false>'
+# --fp8: the one-wave-per-SIMD fp8 kernel, plain (row-scaled operands out of LayerNorm) and block-scaled (v_mfma_scale) instances; AFX_FP8_V3=0: the 8-phase kernel
+FP8_KERNEL_NAME = 'afx::gemm_kernel_v2<true>' if os.environ.get('AFX_FP8_V3', '1')[:1] == '0' else 'afx::gemm_kernel_v3f8<8, 8, false> + afx::gemm_kernel_v3f8<8, 8, true>'
 POWER_CAPPED_MFMA_TF = 1950.0
 
 
+def _kernel_source_sha():
+    """sha256 (first 16 hex digits) of the GEMM kernel's sources: profiles/traffic.json carries the value of the build its PMC pass measured."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ('afx_gemm.hip', 'afx_common.h', 'afx_kernels.h'):
+        with open(os.path.join(ROOT, 'arcflow_amd', 'csrc', f), 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _traffic(model):
-    """HBM-side bytes per GEMM launch from the last committed PMC pass (profiles/traffic.json); bench.py cannot
-    run rocprofv3 on itself, so the corrected counter value is recorded there per round, or null."""
+    """HBM-side bytes per GEMM launch from the last committed PMC pass (profiles/traffic.json; tools/update_traffic.py writes it from the
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of tools/profile_round.sh).  bench.py cannot run rocprofv3 on itself, so the value is only
+    printed when the pass measured THIS build of the kernel (the file carries the sha of the kernel sources); otherwise null."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f)[model]['bytes_per_launch']
+            t = json.load(f)
+        if t.get('kernel_source_sha16') != _kernel_source_sha():
+            return None
+        return t[model]['bytes_per_launch']
     except Exception:
         return None
 
@@ -193,6 +209,13 @@ def train_main(args, rank, world, dev, dist):
         sps = world * B * args.steps / dt
         ach = B * args.steps * fwd_equiv * per_fwd / dt / 1e12           # per GPU
         peak = MFMA_BF16_PEAK_TF
+        # with fp8 forwards the forward-equivalents that run their GEMMs on the fp8 MFMA (5 PF dense) have a higher ceiling than 2.5 PF: blended peak =
+        # work / (time at each part's own peak), GEMM share of a forward's flops 0.80 (FLUX) / 0.813 (Qwen-Image), attention and the backward at the bf16 peak
+        f_gemm = 0.80 if flux else 0.813
+        n_teacher = fwd_equiv - 6
+        n_fp8 = (n_teacher if args.teacher_fp8 else 0) + (2 if args.student_fp8 else 0)
+        t_units = n_fp8 * (f_gemm / (2 * peak) + (1 - f_gemm) / peak) + (fwd_equiv - n_fp8) / peak
+        peak_blended = fwd_equiv / t_units
         line = {
             'metric': f'distillation samples/sec ({"ArcFlow-FLUX-12B" if flux else "ArcFlow-Qwen-Image-20B"} architecture, data-free '
                       f'trajectory matching, 2 student steps x 4 teacher states, LoRA r=256 + heads + norm_out trainable)',
@@ -212,6 +235,9 @@ def train_main(args, rank, world, dev, dist):
                                       f'sliced per block and overlapped with the last backward'},
             'roofline': {'bound': 'mfma', 'kernel': 'whole iteration (denoiser forward-equivalents, SURVEY 3.3)', 'achieved': ach,
                          'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                         'peak_blended': peak_blended, 'frac_of_blended_peak': ach / peak_blended,
+                         'peak_note': (f'{n_fp8} of the {fwd_equiv} forward-equivalents run their GEMMs on the fp8 MFMA (5 PF dense): `frac` is against the bf16 peak, '
+                                       f'`frac_of_blended_peak` against work / (time of each part at its own peak)') if n_fp8 else 'all bf16: the blended peak is the bf16 peak',
                          'forward_equivalents_per_sample': fwd_equiv,
                          'note': f'algorithmic work = student 2 + teacher {fwd_equiv - 6} + backward 4 forward-equivalents; the reference additionally '
                                  f'recomputes 2 (its cost model: {fwd_equiv_ref}), which this engine ' + ('EXECUTES in this run (ARCFLOW_TRAIN_RECOMPUTE=1)' if recompute else 'replaces by keeping the forward outputs in HBM'),
@@ -536,7 +562,8 @@ def infer_main(args, model, rank, world, dev, dist):
                       f'architecture, denoiser + ArcFlow integrator)',
             'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'fp8 e4m3 block linears (row-wise scales) + bf16 attention / embedders / head: REDUCED PRECISION, not the headline' if args.fp8 else 'bf16', 'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt '
+            'dtype': ('fp8 e4m3 block linears (weights: one scale per output channel; activations: one scale per row out of LayerNorm-modulate, E8M0 block scales '
+                      'per row x 128 columns out of the GEMM / attention epilogues) + bf16 attention / embedders / head: REDUCED PRECISION, not the headline') if args.fp8 else 'bf16', 'data': 'synthetic (random-init weights of the exact architecture, synthetic prompt '
                                      'embeddings, seeded noise latents)',
             'config': {'workload': 'ArcFlow-FLUX-12B 2-NFE inference, 1024x1024, bs=1 per GPU' if model == 'flux'
                        else 'ArcFlow-Qwen-Image-20B 2-NFE inference, 1024x1024, bs=1 per GPU, T=128',
@@ -548,7 +575,7 @@ def infer_main(args, model, rank, world, dev, dist):
         if prof and gemm_n:
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
             line['roofline'] = {
-                'bound': 'mfma', 'kernel': 'afx::gemm_kernel_v2<true>' if args.fp8 else GEMM_KERNEL_NAME, 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1),
+                'bound': 'mfma', 'kernel': FP8_KERNEL_NAME if args.fp8 else GEMM_KERNEL_NAME, 'achieved': ach, 'peak': MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1),
                 'unit': 'TFLOP/s', 'frac': ach / (MFMA_BF16_PEAK_TF * (2 if args.fp8 else 1)), 'traffic': None if args.fp8 else _traffic(model),
                 'launches': gemm_n, 'avg_launch_us': gemm_ms * 1e3 / gemm_n,
                 'algorithmic_flops_per_launch': gemm_fl / gemm_n,

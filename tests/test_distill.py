@@ -858,6 +858,19 @@ def test_unmerged_trunk_forward_matches_merged_engine():
     assert dev_means < 1.5e-2 and dev_logg < 1.5e-2, (dev_means, dev_logg)           # folded vs un-fused: bf16 rounding of W + B A
     for got in (un, mg):
         assert rel(got[0], ref[0]) < 2.5e-2 and rel(got[2], ref[2]) < 2.5e-2 and (got[1] - ref[1]).abs().max().item() < 0.1
+    # a forward of the student ENGINE must never silently run the un-adapted trunk.  Changing the adapters marks the bound weights stale,
+    # and student_forward() re-merges before it runs; the engine evaluated WITHOUT the re-merge is the stale W + B_old A.
+    assert not tr._merged_dirty
+    for sp in tr.specs:
+        tr.B(sp).mul_(-1.0)
+    tr.refresh()
+    assert tr._merged_dirty
+    stale = d.student.forward(x.cuda().bfloat16(), sigma, cond['prompt_embeds'], cond['pooled'], torch.full((B,), 3.5, device='cuda'), hp, wp).means.float().cpu()
+    fresh = d.student_forward(x.cuda(), sigma, cond).means.float().cpu()
+    assert not tr._merged_dirty
+    un2, _ = d.student_forward_unmerged(x.cuda(), sigma, cond, 0.0, 0)
+    assert rel(fresh, un2.means.float().cpu()) < 1.5e-2
+    assert rel(stale, un2.means.float().cpu()) > 5e-2        # what the unguarded call would have returned
 
 
 @pytest.mark.gpu

@@ -20,6 +20,8 @@ cd $R
 ( echo '# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -- bench.py (forward) / tools/attn_bwd_bench.py: mean per dispatch by (kernel, grid)'; python tools/pmc_by_grid.py "$O/mfma_fwd/*/*counter_collection.csv" "$O/mfma_bwd/*/*counter_collection.csv" ) > $O/pmc_mfma_busy.txt 2>&1
 ( echo '== FETCH_SIZE (KiB per dispatch, mean)'; python tools/pmc_summary.py $(ls $O/fetch/*/*counter_collection.csv | head -1) | grep -A1 'gemm_kernel\|attention_v3' ;
   echo '== WRITE_SIZE'; python tools/pmc_summary.py $(ls $O/write/*/*counter_collection.csv | head -1) | grep -A1 'gemm_kernel\|attention_v3' ) > $O/pmc_fetch_write_size.txt 2>&1
+# profiles/traffic.json of THIS build (stamped with the kernel sources' sha; copy the printed file back: gpurun_out/<tag>/traffic.json)
+python tools/update_traffic.py $(ls $O/fetch/*/*counter_collection.csv | head -1) $(ls $O/write/*/*counter_collection.csv | head -1) $TAG > $O/traffic_update.txt 2>&1; cp profiles/traffic.json $O/traffic.json
 python tools/attn_bwd_bench.py > $O/attn_bwd_bench.txt 2>/dev/null
 # the headline with and without the per-launch HIP events, interleaved
 for i in 1 2; do

@@ -56,18 +56,21 @@ def _options(pairs):
 
 
 def main():
+    # the host driver only supports dmabuf IPC: must be in the environment BEFORE the first torch.cuda call initialises the HIP / HSA runtime
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     args = parse_args()
     from arcflow_amd.train import ArcFlowDistiller, checkpoint, config, data
     cfg = config.apply_options(config.load_config(args.config), _options(args.cfg_options))
     family, eng, dc, run = config.distill_setup(cfg)
     rank, world, local = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
-    torch.cuda.set_device(local if os.environ.get('ARCFLOW_DIST_ONE_DEVICE', '0') != '1' else 0)
-    dev = f'cuda:{torch.cuda.current_device()}'
     pg = None
     if args.launcher == 'pytorch' or world > 1:
         from arcflow_amd.train import init_distributed
-        dist, dev = init_distributed(local)           # RCCL, rank r on GPU r (train.py:182-185 init_dist('pytorch', backend='nccl'))
+        dist, dev = init_distributed(local)           # picks this rank's device, then RCCL: rank r on GPU r (train.py:182-185 init_dist('pytorch', backend='nccl'))
         pg = dist.group.WORLD
+    else:
+        torch.cuda.set_device(local)
+        dev = f'cuda:{torch.cuda.current_device()}'
     seed = args.seed + (rank if args.diff_seed else 0)              # train.py:222-225
     rng = torch.Generator(device=dev).manual_seed(seed)
 
@@ -154,6 +157,7 @@ def main():
     while dist_.iteration < total:
         cond = next(loader) if loader is not None else synth
         info = dist_.train_step(cond, B, rng=rng)
+        checkpoint.check_pending_save()        # a background save that failed stops the run now
         if rank == 0:
             now = time.perf_counter()
             print(json.dumps(dict(iter=dist_.iteration, time=round(now - t_last, 3), **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in info.items()})), flush=True)
