@@ -292,9 +292,14 @@ def flux_single_block(w, p: str, cfg: FluxCfg, x: Tensor, temb: Tensor, cos: Ten
     return gated_add(x, g, lin(w, p + 'proj_out', torch.cat([o, mlp], dim=2)))
 
 
+LAST_NORM_OUT_INPUT = None
+
+
 def arc_heads(w, temb: Tensor, x: Tensor, K: int, out_ch: int, lw_ch: int):
     """norm_out (AdaLayerNormContinuous, scale first) + three heads + log_softmax over K
     (arcflux.py:241-257)."""
+    global LAST_NORM_OUT_INPUT
+    LAST_NORM_OUT_INPUT = x.detach()          # (tests report how heavy-tailed the residual stream entering norm_out is)
     sc, sh = lin(w, 'norm_out.linear', _r(F.silu(temb))).chunk(2, dim=1)
     x = modulate(x, sc, sh)
     b, n, _ = x.shape
