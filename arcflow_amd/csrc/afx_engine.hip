@@ -909,6 +909,16 @@ int afx_arcflow_step_dropout(const float* x_in, const void* means, const void* l
   return AFX_OK;
 }
 
+int afx_linear_tn_f32out(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
+                         int32_t accumulate, void* stream) {
+  if (!X || !Y || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_tn_f32out");
+  if (M < 0 || N1 < 0 || N2 < 0 || N1 % 8 || N2 % 8 || ldx % 8 || ldy % 8 || ldc % 4 || ldx < N1 || ldy < N2 || ldc < N2)
+    return fail(AFX_E_INVALID, "afx_linear_tn_f32out: need N1%%8==0, N2%%8==0, ldx/ldy%%8==0, ldc%%4==0, leading dimensions >= the widths");
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)C) & 15) return fail(AFX_E_INVALID, "afx_linear_tn_f32out: operands must be 16-byte aligned");
+  HIP_TRY(launch_gemm_tn_f32((const uint16_t*)X, ldx, (const uint16_t*)Y, ldy, C, ldc, M, N1, N2, accumulate, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int32_t M,
                            int32_t N, int32_t K, int32_t accumulate, void* stream) {
   if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16_f32out");

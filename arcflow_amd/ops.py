@@ -303,6 +303,19 @@ def linear_f32out(a, w, out=None, accumulate: bool = False):
     return out
 
 
+def linear_tn_f32out(x, y, out=None, accumulate: bool = False):
+    """out (fp32) [N1,N2] (+)= x[M,N1].T @ y[M,N2]: the contraction runs over the ROWS of two token-major bf16 matrices (row strides = their
+    stride(0)); the LoRA weight gradients without transposed copies (afx_tn.hip)."""
+    lib = _lib.load()
+    M, N1 = x.shape
+    N2 = y.shape[1]
+    assert y.shape[0] == M and x.stride(1) == 1 and y.stride(1) == 1
+    if out is None:
+        out = torch.zeros(N1, N2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.afx_linear_tn_f32out(_p(x), x.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), M, N1, N2, int(accumulate), _s()))
+    return out
+
+
 def quant_rows_fp8(x: torch.Tensor):
     """bf16 [M,K] -> (q uint8 [M,K] OCP e4m3, scale fp32 [M]) with q = round(x / scale[r]), scale = absmax(row) / 448."""
     lib = _lib.load()

@@ -13,7 +13,8 @@ Design for MI355X:
     each block is recomputed from its checkpoint with the same kernels instead): the input gradient and dT = dy B come out of ONE GEMM on the transposed frozen weight with r extra rows
     [dx0 | dT] = dy [W^T ; B^T]^T  (N-extension; "wtcat"), then dx = dx0 + ((dT A) . keep/(1-p));
     flash-attention backward, LN / RMSNorm+RoPE / GELU backward kernels.
-  * LoRA gradients per adapted linear:   dB += dy^T t,  dA += dT^T dropout(x)   (rank-r skinny GEMMs, fp32 accumulate-into).
+  * LoRA gradients per adapted linear:   dB += dy^T t,  dA += dT^T dropout(x)   (rank-r products over the tokens, fp32 accumulate-into; round 5:
+    ONE TN launch each on the token-major operands -- afx_tn.hip gathers the MFMA fragments with ds_read_b64_tr_b16 -- instead of two transposes + an NT launch).
   * LoRA input dropout (0.05 in the reference config): a counter-hash mask regenerated wherever it is needed (forward,
     recompute, backward) from (step seed, adapter, global token row, column); nothing is stored across the forward.
   * The timestep-embedder LoRA pair is trained too: its gradient is the sum of EVERY block's AdaLN modulation gradients
@@ -35,6 +36,7 @@ from ..engine import MMDiTEngine
 
 
 _LORA_SPLITK = os.environ.get('ARCFLOW_LORA_SPLITK', '1') != '0'      # (0: A/B runs)
+_LORA_TN = os.environ.get('ARCFLOW_LORA_TN', '1') != '0'              # weight gradients by the TN kernel (0: transposes + NT kernel, A/B runs)
 
 
 def _p(t):
@@ -267,8 +269,14 @@ class LoraTrunk:
             for x_ in (dy, t, xd, dxe):                    # the allocator must not hand their memory out again before the side work has read it
                 x_.record_stream(self.aux)
         with (torch.cuda.stream(self.aux) if self.aux is not None else contextlib.nullcontext()):
-            ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)     # contraction over the tokens
-            ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
+            gB, gA = self.B(sp, grads), self.A(sp, grads)
+            if _LORA_TN and all(x_.data_ptr() % 16 == 0 for x_ in (dyl, t, dT, xd, gB, gA)):
+                # contraction over the tokens straight from the token-major operands (afx_tn.hip: LDS transpose reads; no transposed copies)
+                ops.linear_tn_f32out(dyl, t, out=gB, accumulate=True)
+                ops.linear_tn_f32out(dT, xd, out=gA, accumulate=True)
+            else:               # (ARCFLOW_LORA_TN=0, A/B -- or a slice of the flat buffers that is not 16-byte aligned: the round-4 path, four transposes + the NT kernel)
+                ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)
+                ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
         ops.lora_dropout(ops.linear(dxe[:, i:], self.at16p[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=3, out=dx)
         return dx
 

@@ -201,6 +201,11 @@ int afx_head_grad(const float* d_means, const float* d_logw, const float* d_logg
 /* C(float)[M,N] (+)= A[M,K] . W[N,K]^T, bf16 operands, fp32 result: weight gradients dW = dY^T . X on transposed copies */
 int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int32_t M,
                            int32_t N, int32_t K, int32_t accumulate, void* stream);
+/* C(float)[N1,N2] (+)= X^T . Y with X [M,N1], Y [M,N2] TOKEN-major bf16 (row strides ldx, ldy): the contraction runs over the rows.  The LoRA weight
+ * gradients dB += dy^T t, dA += dT^T dropout(x) of peft's adapted linears (reference arcflux.py:294-302) straight from the token-major activations --
+ * no transposed copies (ds_read_b64_tr_b16 gathers the MFMA fragments out of LDS).  N1, N2 multiples of 8; deterministic (no atomics). */
+int afx_linear_tn_f32out(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
+                         int32_t accumulate, void* stream);
 int afx_transpose_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, void* stream);
 int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, int32_t cols, void* stream);
 /* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn).  Keeps a per-(device, stream)

@@ -250,3 +250,31 @@ def test_elementwise_backward_kernels(ops):
     out = ops.add_scale(pre.cuda(), dh.cuda(), gate.cuda(), rows_per_batch=25)
     ref = (pre.float() + dh.float()) * gate.repeat_interleave(25, 0)
     assert ((out.float().cpu() - ref).norm() / ref.norm()).item() < 6e-3
+
+
+# ------------------------------------------------------------------------------------------ TN product (LoRA weight gradients, afx_tn.hip)
+@pytest.mark.parametrize('M,N1,N2', [(4608, 3072, 256), (4096, 256, 3072), (512, 12288, 256), (77, 256, 1024), (130, 64, 192), (4608, 256, 15360),
+                                     (64, 128, 128), (1, 8, 8), (333, 200, 72)])
+def test_linear_tn_f32out_matches_transposed_products(ops, M, N1, N2):
+    """C (+)= X^T Y straight from token-major operands (ds_read_b64_tr_b16 fragments) against fp32 math and against the round-4 path (two explicit
+    transposes + the NT kernel): the LoRA shapes (dB [out, 256] over 4608 / 512 tokens, dA [256, in]), ragged token counts (the last K-step's rows
+    past M are zeroed in LDS), widths below / off the 128-column tile, strided views (a column range of a wider buffer) and the accumulate mode.
+    The inputs are NOT symmetric: a swapped operand or a transposed output would show."""
+    g = torch.Generator(device='cuda').manual_seed(M + 3 * N1 + 7 * N2)
+    xw = torch.randn(M, N1 + 64, generator=g, device='cuda').bfloat16()
+    yw = (torch.randn(M, N2 + 8, generator=g, device='cuda') * 0.5 + 0.1).bfloat16()
+    x, y = xw[:, 32:32 + N1], yw[:, 8:8 + N2]                                  # views: row stride != width, 16-byte aligned starts
+    ref = x.float().t() @ y.float()
+    out = ops.linear_tn_f32out(x, y)
+    scale = ref.abs().max().item() + 1e-6
+    assert (out - ref).abs().max().item() <= 2e-5 * scale * max(1.0, (M / 64) ** 0.5), ((out - ref).abs().max().item(), scale)
+    c0 = torch.randn(N1, N2 + 4, generator=g, device='cuda')
+    c = c0.clone()
+    ops.linear_tn_f32out(x, y, out=c[:, :N2], accumulate=True)
+    assert torch.equal(c[:, N2:], c0[:, N2:])                                   # nothing written past the columns
+    assert (c[:, :N2] - (c0[:, :N2] + ref)).abs().max().item() <= 3e-5 * (scale + c0.abs().max().item()) * max(1.0, (M / 64) ** 0.5)
+    if True:                                                                   # the round-4 formulation: same products, fp32 accumulation in another order
+        old = ops.linear_f32out(ops.transpose(x.contiguous(), 64), ops.transpose(y.contiguous(), 64))
+        assert (out - old).abs().max().item() <= 2e-5 * scale * (M / 64) ** 0.5
+    # deterministic: a second launch is bit-identical
+    assert torch.equal(out, ops.linear_tn_f32out(x, y))
