@@ -138,6 +138,9 @@ class LoraTrunk:
         # checkpoints every block and recomputes its whole forward (arcflux.py:181-189) because it has to fit 80 GB.  ARCFLOW_TRAIN_RECOMPUTE=1
         # (or use_stash = False) selects the recompute path (A/B runs, the parity tests run both).
         self.use_stash = os.environ.get('ARCFLOW_TRAIN_RECOMPUTE', '0') != '1'
+        # ... and (round 5) the adapters' dropped inputs xd = dropout(x): the backward needs them for dA += dT^T xd only, and regenerating them cost a
+        # LayerNorm-modulate / GELU pass plus a dropout pass per adapted linear (37 GB more for FLUX at 4 samples; ARCFLOW_TRAIN_KEEP_XD=0: regenerate, A/B)
+        self.keep_xd = os.environ.get('ARCFLOW_TRAIN_KEEP_XD', '1') != '0'
         # The text stream of a double block (512 / <= 128 rows beside 4096) is a chain of launches that fill a fraction of the chip; between
         # the two attention joins it is independent of the image stream, so it runs on a SIDE HIP stream and its work-groups take the
         # compute units the image stream's launches leave idle in their last rounds (ARCFLOW_TRAIN_TXT_STREAM=0: one stream, for A/B runs).
@@ -228,14 +231,20 @@ class LoraTrunk:
         columns (A is zero-padded to rp rows, so the columns past r come out as exact zeros)."""
         return torch.empty(rows, in_f + self.rp, dtype=torch.bfloat16, device=self.dev)
 
-    def _adapted(self, sp: LoraSpec, xe: torch.Tensor, row_off: int, out: Optional[torch.Tensor] = None, main: bool = True):
+    def _adapted(self, sp: LoraSpec, xe: torch.Tensor, row_off: int, out: Optional[torch.Tensor] = None, main: bool = True,
+                 xd_out: Optional[torch.Tensor] = None):
         """peft LoRA linear on xe = [x | . ] ([M, in + rp], x already in place):  xd = dropout(x);  t = xd A^T -> xe[:, in:in+r];
         out = [x | t] [W | B]^T + bias for ALL rows of the packed weight (the fused single-block weight carries zero B columns on its
         k|v|q rows).  main=False: only xd and t (the recompute of a branch's last linear, whose output the backward does not need).
-        Returns (xd, t, out)."""
+        xd_out: where dropout(x) is written (the stash).  Returns (xd, t, out)."""
         i, r, key = sp.in_f, self.r, sp.packed_key
         x, t = xe[:, :i], xe[:, i:i + r]
-        xd = x if self.p_drop <= 0 else ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1)
+        if self.p_drop <= 0:
+            xd = x
+            if xd_out is not None:
+                xd_out.copy_(x)             # (kept for the backward's dA product: x itself lives in a temporary operand buffer)
+        else:                               # xd_out: straight into the stash
+            xd = ops.lora_dropout(x, self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=1, out=xd_out)
         self._skinny(xd, self.a16p[sp.name], out=xe[:, i:])
         if not main:
             return xd, t, None
@@ -435,11 +444,13 @@ class LoraTrunk:
     # ------------------------------------------------------------------ the stash of one student forward
     def stash_bytes(self, rows: int) -> int:
         D = self.D
-        return 2 * rows * (self.nd * 9 * D + self.ns * 8 * D + 2 * (self.nd + self.ns) * self.rp)
+        xd = (self.nd * 5 * D + self.ns * 6 * D) if self.keep_xd else 0
+        return 2 * rows * (self.nd * 9 * D + self.ns * 8 * D + 2 * (self.nd + self.ns) * self.rp + xd)
 
     def _stash_for(self, rows: int) -> Optional[Dict[str, torch.Tensor]]:
         """Per (block, token): double blocks k|v|q pre-norm (3D), O (D), X1 (D), the mlp pre-activation (4D); single blocks the fused
-        k|v|q|mlp pre-activation (7D) and O (D); t = dropout(x) A^T of both adapters of every block (2 rp).  FLUX at 4 samples: 54 GB."""
+        k|v|q|mlp pre-activation (7D) and O (D); t = dropout(x) A^T of both adapters of every block (2 rp); with keep_xd the adapters' dropped
+        inputs (5D / 6D).  FLUX at 4 samples: 54 GB + 37 GB."""
         if self.stash is None or self.stash['rows'] < rows:      # grow-only: prompt lengths (Qwen-Image) vary from batch to batch, the row ranges used are [0, B S)
             D, bf = self.D, dict(dtype=torch.bfloat16, device=self.dev)
             self.stash = None
@@ -456,6 +467,9 @@ class LoraTrunk:
             self.stash = dict(rows=rows, qkv=torch.empty(self.nd, rows, 3 * D, **bf), o=torch.empty(self.nd + self.ns, rows, D, **bf),
                               x1=torch.empty(self.nd, rows, D, **bf), pre=torch.empty(self.nd, rows, 4 * D, **bf),
                               fp=torch.empty(self.ns, rows, 7 * D, **bf), t=torch.empty(2 * (self.nd + self.ns), rows, self.rp, **bf))
+            if self.keep_xd:      # dropout(x) of every adapted linear: double blocks mlp1 (D) / mlp2 (4D) inputs, single blocks proj_mlp (D) / proj_out (5D) inputs
+                self.stash.update(xd1=torch.empty(self.nd, rows, D, **bf), xd2=torch.empty(self.nd, rows, 4 * D, **bf),
+                                  xdm=torch.empty(self.ns, rows, D, **bf), xdo=torch.empty(self.ns, rows, 5 * D, **bf))
         return self.stash
 
     # ------------------------------------------------------------------ block forward / recompute + backward (one sample)
@@ -475,6 +489,7 @@ class LoraTrunk:
         st = self.stash if self.use_stash else None
         restore = st is not None and not fwd_only           # backward with the forward's GEMM / attention outputs at hand
         keepf = st is not None and fwd_only                 # forward that leaves them there
+        kxd = st is not None and 'xd1' in st                # ... and the adapters' dropped inputs
         QKVp = st['qkv'][i, R] if st is not None else torch.empty(S, 3 * D, **bf)       # pre-norm k | v | q
         if not restore:
             Xn1 = torch.empty(S, D, **bf)
@@ -504,14 +519,22 @@ class LoraTrunk:
         for s, rows, _, on_stream in self._streams(T, S):
             with on_stream:
                 sp1, sp2 = self._spec(p + s + '_mlp1'), self._spec(p + s + '_mlp2')
-                if restore:         # element-wise work only: Xn2 -> dropout, gelu(Pre) -> dropout; t1 / t2 come back from the stash
+                if restore:         # t1 / t2 come back from the stash, and so do the dropped inputs (keep_xd) -- else element-wise work only: Xn2 -> dropout, gelu(Pre) -> dropout
                     xd1 = t1 = xd2 = t2 = None
                     if sp1 is not None:
-                        ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
-                        xd1, t1 = self._dropped(sp1, Xn2[rows], rows.start), st['t'][2 * i, R][rows][:, :self.r]
+                        if kxd:
+                            xd1 = st['xd1'][i, R][rows]
+                        else:
+                            ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
+                            xd1 = self._dropped(sp1, Xn2[rows], rows.start)
+                        t1 = st['t'][2 * i, R][rows][:, :self.r]
                     if sp2 is not None:
-                        ops.gelu(Pre[rows], out=Hh[rows])
-                        xd2, t2 = self._dropped(sp2, Hh[rows], rows.start), st['t'][2 * i + 1, R][rows][:, :self.r]
+                        if kxd:
+                            xd2 = st['xd2'][i, R][rows]
+                        else:
+                            ops.gelu(Pre[rows], out=Hh[rows])
+                            xd2 = self._dropped(sp2, Hh[rows], rows.start)
+                        t2 = st['t'][2 * i + 1, R][rows][:, :self.r]
                     keep[s] = (xd1, t1, xd2, t2)
                     continue
                 if fwd_only:        # keep the pre-gate branch output: the backward needs it for d_gate
@@ -522,7 +545,7 @@ class LoraTrunk:
                     self._lin(O[rows], p + s + '_out', epilogue='gate_res', gate=mv[(s, 2)], residual=X[rows], out=X1[rows])
                 ops.norm_modulate(X1[rows], mv[(s, 4)], mv[(s, 3)], out=Xn2[rows])
                 if sp1 is not None:
-                    xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows])
+                    xd1, t1, _ = self._adapted(sp1, Xe2[rows], rows.start, out=Pre[rows], xd_out=st['xd1'][i, R][rows] if (keepf and kxd) else None)
                     if keepf:
                         st['t'][2 * i, R][rows].copy_(Xe2[rows][:, D:])
                 else:
@@ -531,7 +554,7 @@ class LoraTrunk:
                 ops.gelu(Pre[rows], out=Hh[rows])
                 y2 = self.ybuf[2 * i + 1, self.row0:self.row0 + S][rows] if fwd_only else None
                 if sp2 is not None:
-                    xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only)
+                    xd2, t2, _ = self._adapted(sp2, He[rows], rows.start, out=y2, main=fwd_only, xd_out=st['xd2'][i, R][rows] if (keepf and kxd) else None)
                     if keepf:
                         st['t'][2 * i + 1, R][rows].copy_(He[rows][:, 4 * D:])
                 else:
@@ -601,36 +624,46 @@ class LoraTrunk:
         restore = st is not None and not fwd_only
         keepf = st is not None and fwd_only
         bi = self.nd + i                                         # block index in the o / t / lse stashes
-        Xe = self._xe(S, D)                                      # [Xn | t_mlp]: operand of the fused k|v|q|mlp launch
-        Xn = Xe[:, :D]
-        ops.norm_modulate(X, sc, sh, out=Xn)
+        kxd = st is not None and 'xdm' in st
         Fp = st['fp'][i, R] if st is not None else torch.empty(S, 7 * D, **bf)          # pre-activation k|v|q|mlp
-        if restore:
-            xd_m, t_m = self._dropped(sp_mlp, Xn, 0), st['t'][2 * bi, R][:, :self.r]
+        if restore and kxd:
+            xd_m, t_m = st['xdm'][i, R], st['t'][2 * bi, R][:, :self.r]
         else:
-            xd_m, t_m, _ = self._adapted(sp_mlp, Xe, 0, out=Fp)  # (the k|v|q rows of wcat carry zero B columns)
+            Xe = self._xe(S, D)                                  # [Xn | t_mlp]: operand of the fused k|v|q|mlp launch
+            Xn = Xe[:, :D]
+            ops.norm_modulate(X, sc, sh, out=Xn)
+        if restore and not kxd:
+            xd_m, t_m = self._dropped(sp_mlp, Xn, 0), st['t'][2 * bi, R][:, :self.r]
+        elif not restore:
+            xd_m, t_m, _ = self._adapted(sp_mlp, Xe, 0, out=Fp, xd_out=st['xdm'][i, R] if (keepf and kxd) else None)  # (the k|v|q rows of wcat carry zero B columns)
             if keepf:
                 st['t'][2 * bi, R].copy_(Xe[:, D:])
         Kp, V, Qp, Mp = Fp[:, :D], Fp[:, D:2 * D], Fp[:, 2 * D:3 * D], Fp[:, 3 * D:]
         K, Q = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
-        Ge = self._xe(S, 5 * D)                                  # [O | gelu(mlp) | t_out] = proj_out operand
-        G = Ge[:, :5 * D]
         self._rope(Kp, K, qkn[1], qkn[1], cos, sin, S, T)
         self._rope(Qp, Q, qkn[0], qkn[0], cos, sin, S, T)
-        if restore:
-            lse = self._lse[(bi, self.row0)]
-            G[:, :D].copy_(st['o'][bi, R])
-        else:
-            lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
-            if keepf:
-                self._lse[(bi, self.row0)] = lse
-                st['o'][bi, R].copy_(G[:, :D])
-        ops.gelu(Mp, out=G[:, D:])
         y = self.ybuf[2 * self.nd + i, self.row0:self.row0 + S] if fwd_only else None
-        if restore:
-            xd_o, t_o = self._dropped(sp_out, G, 0), st['t'][2 * bi + 1, R][:, :self.r]
+        if restore and kxd:         # O, t and dropout([O | gelu(mlp)]) all come back from the stash: no GELU pass, no copy, no dropout pass
+            lse = self._lse[(bi, self.row0)]
+            O = st['o'][bi, R]
+            xd_o, t_o = st['xdo'][i, R], st['t'][2 * bi + 1, R][:, :self.r]
         else:
-            xd_o, t_o, _ = self._adapted(sp_out, Ge, 0, out=y, main=fwd_only)
+            Ge = self._xe(S, 5 * D)                              # [O | gelu(mlp) | t_out] = proj_out operand
+            G = Ge[:, :5 * D]
+            O = G[:, :D]
+            if restore:
+                lse = self._lse[(bi, self.row0)]
+                G[:, :D].copy_(st['o'][bi, R])
+            else:
+                lse = ops.attention_fwd_lse_2d(Q, K, V, G[:, :D], 1, S, self.H)
+                if keepf:
+                    self._lse[(bi, self.row0)] = lse
+                    st['o'][bi, R].copy_(G[:, :D])
+            ops.gelu(Mp, out=G[:, D:])
+            if restore:
+                xd_o, t_o = self._dropped(sp_out, G, 0), st['t'][2 * bi + 1, R][:, :self.r]
+            else:
+                xd_o, t_o, _ = self._adapted(sp_out, Ge, 0, out=y, main=fwd_only, xd_out=st['xdo'][i, R] if (keepf and kxd) else None)
             if keepf:
                 st['t'][2 * bi + 1, R].copy_(Ge[:, 5 * D:])
         if fwd_only:
@@ -641,7 +674,7 @@ class LoraTrunk:
         dFp = torch.empty(S, 7 * D, **bf)
         ops.gelu(Mp, dh=dG[:, D:], out=dFp[:, 3 * D:])
         dQ, dK = torch.empty(S, D, **bf), torch.empty(S, D, **bf)
-        ops.attention_bwd_2d(Q, K, V, G[:, :D], dG[:, :D], lse, dQ, dK, dFp[:, D:2 * D], 1, S, self.H)
+        ops.attention_bwd_2d(Q, K, V, O, dG[:, :D], lse, dQ, dK, dFp[:, D:2 * D], 1, S, self.H)
         self._rope(Kp, dFp[:, :D], qkn[1], qkn[1], cos, sin, S, T, dy=dK)
         self._rope(Qp, dFp[:, 2 * D:3 * D], qkn[0], qkn[0], cos, sin, S, T, dy=dQ)
         dXn = self._adapted_backward(sp_mlp, dFp, xd_m, t_m, grads, 0)        # dgrad over all 7D columns; dT / dB from the mlp columns
