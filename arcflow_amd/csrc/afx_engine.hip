@@ -1085,6 +1085,22 @@ static int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, c
   return AFX_OK;
 }
 
+int afx_linear_bf16_dropres(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                            const void* res, int64_t ldr, float p, uint32_t seed, int64_t row0, void* stream) {
+  if (!A || !W || !C || !res) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16_dropres");
+  if (M < 0 || N < 0 || K <= 0 || K % 64 || N % 8 || lda % 8 || ldw % 8 || ldc % 8 || ldr % 8 || !(p >= 0.f && p < 1.f))
+    return fail(AFX_E_INVALID, "afx_linear_bf16_dropres: need K%%64==0, N%%8==0, strides%%8==0, 0 <= p < 1");
+  GemmBatch gb{};
+  gb.nprob = 1;
+  GemmProblem& q = gb.p[0];
+  q = GemmProblem{};
+  q.A = (const uint16_t*)A; q.lda = lda; q.W = (const uint16_t*)W; q.ldw = ldw; q.C = (uint16_t*)C; q.ldc = ldc; q.M = M; q.N = N; q.K = K;
+  q.epi = EPI_GATE_RES; q.rows_per_batch = M > 0 ? M : 1; q.res = (const uint16_t*)res; q.ldr = ldr;
+  q.drop_on = 1; q.drop_thresh = (uint32_t)((double)p * 4294967296.0); q.drop_seed = seed; q.drop_inv_keep = 1.0f / (1.0f - p); q.drop_row0 = row0;
+  HIP_TRY(launch_gemm(gb, (hipStream_t)stream));
+  return AFX_OK;
+}
+
 int64_t afx_attention_ws_bytes(int32_t batch, int32_t heads, int32_t S) {
   if (batch < 1 || heads < 1 || S < 1) return fail(AFX_E_INVALID, "bad attention shape");
   return (int64_t)batch * heads * 128 * attn_spad(S) * 2;

@@ -158,7 +158,11 @@ AFX_DEV __amdgpu_buffer_rsrc_t uniform_rsrc(T* p, int bytes) {
 // PRE: a bf16 [M, N] term (GemmProblem::pre, the LoRA-dropout correction) is added before the activation / gate.
 // CONV: the rows are pixels of a zero-bordered [conv_hp][conv_wp] grid (implicit 3x3 convolution): border pixels are stored as zero.
 constexpr int EPI_GELU_ALL = 3;      // (internal) EPI_GELU with every column of the wave at or past gelu_col0: no per-lane test
-template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false, bool GN = false>
+AFX_DEV uint32_t drop_mix32(uint32_t h) {          // (= mix32 of afx_train.hip's lora_dropout_kernel: the masks must be the same bits)
+  h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+  return h;
+}
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false, bool GN = false, bool DROP = false>
 AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? (NJ + 1) / 2 : NJ; // steps per row tile (SWAP with an odd NJ: the last step pairs the lone column tile with
@@ -387,6 +391,14 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = gelu_tanh(v[e]);
       } else if constexpr (EPI == EPI_GATE_RES) {
+        if constexpr (DROP) {        // the LoRA branch's input gradient: the product is masked (keep / (1 - p) or 0), then added to the residual
+          const uint32_t hr = drop_mix32(P.drop_seed ^ (uint32_t)((P.drop_row0 + row_base + ii * 16 + frow) * 0x9e3779b1u));
+#pragma unroll
+          for (int e = 0; e < CW; ++e) {
+            const bool keep = drop_mix32(hr + (uint32_t)(gcol[st] + e) * 0x85ebca77u) >= P.drop_thresh;
+            v[e] = keep ? v[e] * P.drop_inv_keep : 0.f;
+          }
+        }
 #pragma unroll
         for (int e = 0; e < CW; ++e) {
           const uint32_t w = rw[ii % (PF + 1)][st][e >> 1];
@@ -624,8 +636,12 @@ AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], in
   if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4) && NJ % 2 == 0) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
     if (P.out_f32 == 1 || P.out_f32 == 2) { epi_store_f32<MI, NJ>(P, acc, row_base, col_base, frow, fq); return; }
   }
-  if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
-  else if (P.epi == EPI_GELU) {
+  if (P.epi == EPI_GATE_RES) {
+    if constexpr (SWAP && !FP8 && !PRE) {
+      if (P.drop_on) { epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, false, false, false, false, false, true>(P, acc, row_base, col_base, frow, fq); return; }
+    }
+    epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+  } else if (P.epi == EPI_GELU) {
     // The per-lane test `column >= gelu_col0` made every one of the 32 steps its own basic block behind an exec-mask branch (a lone wave pays ~30 cycles of
     // refetch per taken branch, and no step overlaps the next one's exchange / loads): 14.6 k cycles per 256 x 256 tile against 10.2 k without GELU.  A wave's
     // columns are (in every launch of the forward) all activated or none: decide once, wave-uniformly, and run straight-line code.
@@ -2000,7 +2016,10 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     const GemmProblem& p = batch.p[i];
     const bool bf16_out = p.out_f32 == 0, f32_out = (p.out_f32 == 1 || p.out_f32 == 2) && p.epi == EPI_NONE;     // (3 = split-K slabs: 8-phase)
     v3_ok = v3_ok && (bf16_out || f32_out) && p.fp8 == 0 && p.conv_cin_tiles == 0 && p.conv_wp == 0 && p.pre == nullptr && p.K >= BK;
+    if (p.drop_on && (p.epi != EPI_GATE_RES || p.gate != nullptr || p.out_f32 != 0)) return hipErrorInvalidValue;
   }
+  for (int i = 0; i < batch.nprob; ++i)
+    if (batch.p[i].drop_on && !v3_ok) return hipErrorInvalidValue;        // the masked residual add lives in the one-wave-per-SIMD kernel's epilogue only
   // ---- the VAE decoders' 3x3 convolutions: the same kernel with the implicit-GEMM address stream and the border-zeroing epilogue;
   // 256x128 tiles for the <= 128-channel layers (the full-resolution stage and conv_out, half of a 256-wide tile otherwise)
   bool conv_all = impl == 3 && tile_env == 0 && batch.nprob >= 1;

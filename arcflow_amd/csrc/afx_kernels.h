@@ -66,6 +66,13 @@ struct GemmProblem {
   // padded grid [conv_hp][conv_wp], the taps are 2 x 2 starting at (py - 1, px - 1), and the epilogue scatters row (yy, xx) to pixel
   // (2 yy + py - 1, 2 xx + px - 1) of the [2 conv_hp - 2][2 conv_wp - 2] output grid (border pixels as zeros, positions outside dropped).
   int32_t up_phase;
+  // LoRA input-dropout mask on the PRODUCT of a residual-add launch (EPI_GATE_RES without a gate; one-wave-per-SIMD kernel): C = res + (A . W^T) . keep / (1 - p)
+  // with keep(row, col) = the counter hash of afx_lora_dropout_bf16 (seed, drop_row0 + row, col) -- the input gradient of the LoRA branch,
+  // dx = dx0 + ((dy B) A) . mask, without the [M, in] product in memory and without the separate mask-and-add pass.  drop_on == 0: off.
+  int32_t drop_on;
+  uint32_t drop_thresh, drop_seed;
+  float drop_inv_keep;
+  int64_t drop_row0;
   int32_t tiles_m, tiles_n, tile_start;   // filled by the launcher
 };
 

@@ -303,6 +303,19 @@ def linear_f32out(a, w, out=None, accumulate: bool = False):
     return out
 
 
+def linear_dropres(a, w, residual, p: float, seed: int, row0: int = 0, out=None):
+    """out = residual + (a @ w.T) * keep/(1-p) with the LoRA-dropout mask of ``lora_dropout`` (seed, row0 + row, column) applied to the fp32 product in
+    the GEMM's epilogue (one launch instead of product + mask-and-add pass).  out may be ``residual``."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    _lib.check(lib.afx_linear_bf16_dropres(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, _p(residual), residual.stride(0),
+                                           float(p), seed & 0xffffffff, row0, _s()))
+    return out
+
+
 def linear_tn_f32out(x, y, out=None, accumulate: bool = False):
     """out (fp32) [N1,N2] (+)= x[M,N1].T @ y[M,N2]: the contraction runs over the ROWS of two token-major bf16 matrices (row strides = their
     stride(0)); the LoRA weight gradients without transposed copies (afx_tn.hip)."""

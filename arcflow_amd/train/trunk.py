@@ -36,6 +36,7 @@ from ..engine import MMDiTEngine
 
 
 _LORA_SPLITK = os.environ.get('ARCFLOW_LORA_SPLITK', '1') != '0'      # (0: A/B runs)
+_LORA_DROPRES = os.environ.get('ARCFLOW_LORA_DROPRES', '1') != '0'    # the LoRA branch's input gradient masked + added in the GEMM epilogue (0: separate pass, A/B)
 _LORA_TN = os.environ.get('ARCFLOW_LORA_TN', '1') != '0'              # weight gradients by the TN kernel (0: transposes + NT kernel, A/B runs)
 
 
@@ -286,7 +287,10 @@ class LoraTrunk:
             else:               # (ARCFLOW_LORA_TN=0, A/B -- or a slice of the flat buffers that is not 16-byte aligned: the round-4 path, four transposes + the NT kernel)
                 ops.linear_f32out(ops.transpose(dyl, 64), ops.transpose(t, 64), out=self.B(sp, grads), accumulate=True)
                 ops.linear_f32out(ops.transpose(dT, 64), ops.transpose(xd, 64), out=self.A(sp, grads), accumulate=True)
-        ops.lora_dropout(ops.linear(dxe[:, i:], self.at16p[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=3, out=dx)
+        if _LORA_DROPRES:   # dx = dx0 + ((dy B) A) . keep/(1-p): the mask is applied in the product's epilogue (round 5)
+            ops.linear_dropres(dxe[:, i:], self.at16p[sp.name], dx, self.p_drop, self._site_seed(sp), self.row0 + row_off, out=dx)
+        else:               # (ARCFLOW_LORA_DROPRES=0, A/B: the product to memory, then a mask-and-add pass)
+            ops.lora_dropout(ops.linear(dxe[:, i:], self.at16p[sp.name]), self.p_drop, self._site_seed(sp), self.row0 + row_off, mode=3, out=dx)
         return dx
 
     def block_slice(self, block: int) -> Tuple[int, int]:

@@ -206,6 +206,10 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
  * no transposed copies (ds_read_b64_tr_b16 gathers the MFMA fragments out of LDS).  N1, N2 multiples of 8; deterministic (no atomics). */
 int afx_linear_tn_f32out(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
                          int32_t accumulate, void* stream);
+/* C = res + (A . W^T) . keep / (1 - p): the input gradient of peft's LoRA branch with lora_dropout, dx = dx0 + ((dy B) A) . mask, in ONE launch -- the mask
+ * (the counter hash of afx_lora_dropout_bf16: seed, row0 + row, column) is applied to the fp32 product in the GEMM's epilogue; res may alias C.  bf16. */
+int afx_linear_bf16_dropres(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                            const void* res, int64_t ldr, float p, uint32_t seed, int64_t row0, void* stream);
 int afx_transpose_bf16(const void* x, int64_t ldx, void* y, int64_t ldy, int32_t rows, int32_t cols, void* stream);
 int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, int32_t cols, void* stream);
 /* AdaLayerNormContinuous backward w.r.t. (scale, shift): dmod_accum[B,2,D] += sum_rows (dxn * LN(x) | dxn).  Keeps a per-(device, stream)

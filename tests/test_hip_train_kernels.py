@@ -278,3 +278,27 @@ def test_linear_tn_f32out_matches_transposed_products(ops, M, N1, N2):
         assert (out - old).abs().max().item() <= 2e-5 * scale * (M / 64) ** 0.5
     # deterministic: a second launch is bit-identical
     assert torch.equal(out, ops.linear_tn_f32out(x, y))
+
+
+@pytest.mark.parametrize('M,N,K,p', [(4608, 3072, 256, 0.05), (512, 12288, 256, 0.05), (130, 192, 64, 0.3), (4096, 15360, 256, 0.0)])
+def test_linear_dropres_matches_product_then_masked_add(ops, M, N, K, p):
+    """dx = dx0 + ((dy B) A) . keep/(1-p) in the GEMM's epilogue against the round-4 formulation (product to memory as bf16, then lora_dropout mode 3):
+    the SAME mask bits (dropped positions keep the residual bit for bit), kept positions equal up to the bf16 rounding of the product that no longer happens;
+    in place over the residual; every tile shape the launcher picks for these sizes."""
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    a = torch.randn(M, K, generator=g, device='cuda').bfloat16()
+    w = (torch.randn(N, K, generator=g, device='cuda') * 0.1).bfloat16()
+    res = torch.randn(M, N, generator=g, device='cuda').bfloat16()
+    seed, row0 = 0x1234567, 4608
+    old = res.clone()
+    ops.lora_dropout(ops.linear(a, w), p, seed, row0, mode=3, out=old)
+    new = res.clone()
+    ops.linear_dropres(a, w, new, p, seed, row0, out=new)
+    prod = a.float() @ w.float().t()
+    keep = ops.lora_dropout(torch.ones(M, N, device='cuda', dtype=torch.bfloat16), p, seed, row0, mode=1) > 0
+    ref = res.float() + torch.where(keep, prod / (1.0 - p), torch.zeros_like(prod))
+    assert torch.equal(new[~keep], res[~keep])                                 # dropped: the residual, untouched
+    assert abs(float((~keep).float().mean()) - p) < 0.01
+    scale = ref.abs().max().item()
+    assert (new.float() - ref).abs().max().item() <= 2 ** -8 * scale           # one bf16 rounding of the sum
+    assert (new.float() - ref).abs().max().item() <= (old.float() - ref).abs().max().item() + 1e-6
