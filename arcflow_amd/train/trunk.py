@@ -256,8 +256,8 @@ class LoraTrunk:
         aq, asc = ops.quant_rows_fp8(x)
         y = ops.linear_fp8(aq, asc, q, sc, b, out=out)
         yl = y[:, sp.row0:sp.row0 + sp.out_f]
-        corr = ops.linear(xe[:, i:], self.wcat[key][sp.row0:sp.row0 + sp.out_f, i:])      # t B^T  (K = rp)
-        ops.add_scale(yl, b=corr, out=yl)
+        # + t B^T (K = rp), added in place by the product's own epilogue (plain residual add: no [M, out] correction in memory, no add pass)
+        ops.linear(xe[:, i:], self.wcat[key][sp.row0:sp.row0 + sp.out_f, i:], epilogue='gate_res', residual=yl, out=yl)
         return xd, t, y
 
     def _dropped(self, sp: LoraSpec, x: torch.Tensor, row_off: int) -> torch.Tensor:
