@@ -122,7 +122,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
       // consumer side of the hand-over: ONE lane polls the generation flags (relaxed, agent scope, bounded), the verdict goes through LDS (free between
       // segments), then every wave takes an agent-scope acquire before the plain loads of the partial rows
       if (tid == 0) {
-        int ok = 1;
+        int ok = (wt & 2) ? 0 : 1;               // (bit 1 of the mode word, AFX_ATTN_HANDOVER=lost: pretend no partial is ever published -- the tests' way into the fallback)
         for (int p = 0; p < nin && ok; ++p) {
           int spins = 0;
           while (__hip_atomic_load(pflag + in0 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gen) {
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
       const u32x4_t val = (u32x4_t){rx[0], ry[0], rx[1], ry[1]};
       // write-through: the payload of a hand-over (see the publish below).  The s_nop is the wait a VALU write of a > 8-byte store's data registers needs
       // behind the store (gfx940+: 2 states) -- hipcc's hazard recogniser cannot see into the asm, and without it one build stored the NEXT step's values in some lanes
-      if (part && wt) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(op + d * 32 + kk * 16), "v"(val) : "memory");
+      if (part && (wt & 1)) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(op + d * 32 + kk * 16), "v"(val) : "memory");
       else if (part || row < S) *reinterpret_cast<u32x4_t*>(op + d * 32 + kk * 16) = val;
     }
   };
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     const int row = q02 + (SL) * 32 + ql2;                                                                         \
     if (part) {                                                                                                    \
       const float lv_ = (MRUN) * c + __log2f(l_tot);                                                               \
-      if (hi2 == 0 && wt) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(lbase + row), "v"(lv_) : "memory"); \
+      if (hi2 == 0 && (wt & 1)) asm volatile("global_store_dword %0, %1, off sc0 sc1" ::"v"(lbase + row), "v"(lv_) : "memory"); \
       else if (hi2 == 0) lbase[row] = lv_;                                                                         \
     } else if (lbase != nullptr && hi2 == 0 && row < S) lbase[row] = (MRUN) * c + __log2f(l_tot);                  \
     bf16_t* op = obase + (int64_t)row * ld_o + hi2 * 8;                                                            \
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(THREADS, 1) __attribute__((amdgpu_num_vgpr(96))) vo
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid2 == 0) {
-      if (!wt) {                // (AFX_ATTN_HANDOVER=fence, A/B: plain stores + an agent-scope release)
+      if (!(wt & 1)) {          // (AFX_ATTN_HANDOVER=fence, A/B: plain stores + an agent-scope release)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -692,11 +692,10 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
   const int gen = pl ? ++pl->gen : 0;
   unsigned long long* tl = nullptr;
   if (g_tl_cap > 0 && (int)grid.x <= g_tl_cap) { tl = g_tl; g_tl_grid = (int)grid.x; }
-  static int wt = -1;
-  if (wt < 0) {
-    const char* e = getenv("AFX_ATTN_HANDOVER");         // "fence": plain stores + release fence instead of write-through stores (A/B)
-    wt = (e && e[0] == 'f') ? 0 : 1;
-  }
+  // AFX_ATTN_HANDOVER: "fence" = plain stores + release fence instead of write-through stores (A/B); "lost" = the long parts never see a partial published and
+  // compute their whole key range themselves (the fallback for a dispatch order the schedule does not expect; read per launch: the tests flip it)
+  const char* hv = getenv("AFX_ATTN_HANDOVER");
+  const int wt = (hv && hv[0] == 'f') ? 0 : (hv && hv[0] == 'l') ? 3 : 1;
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
     hipExtLaunchKernelGGL(a3::attention_v3_kernel, grid, dim3(a3::THREADS), a3::LDS_BYTES, stream, launch_timer().start, launch_timer().stop, 0,
                           q, ldq, k, ldk, vt, o, ldo, H, S, S_pad, nqb, B, lse, dbg, o8, ldo8, omx, ld_omx, items, po, plse, pflag, gen, wt, tl);

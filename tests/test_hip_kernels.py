@@ -221,6 +221,25 @@ def test_attention_kv_split_of_the_last_round(ops, B, S, H):
     assert (outs[0][1] - outs[3][1]).abs().max().item() < 2e-3
 
 
+def test_attention_hand_over_fallback_when_partials_never_arrive(ops, monkeypatch):
+    """HIP promises no dispatch order: a long part that does not see its block's partials published must still produce the right rows.  With
+    AFX_ATTN_HANDOVER=lost the long parts act as if no flag were ever raised and compute their whole key range from zero (the short ends' work is
+    then wasted, never wrong)."""
+    g = torch.Generator(device='cuda').manual_seed(99)
+    B, S, H = 1, 4608, 24
+    q, k, v = (torch.randn(B, S, H, 128, generator=g, device='cuda').bfloat16() for _ in range(3))
+    ops.set_attn_impl(3)
+    plain = ops.attention(q, k, v).float()
+    ops.set_attn_impl(0)
+    monkeypatch.setenv('AFX_ATTN_HANDOVER', 'lost')
+    lost = ops.attention(q, k, v).float()
+    monkeypatch.delenv('AFX_ATTN_HANDOVER')
+    torch.cuda.synchronize()
+    assert torch.equal(lost, plain)            # whole key range, same order of operations: the plain grid's bits
+    handed = ops.attention(q, k, v).float()
+    assert not torch.equal(handed, plain) and rel_l2(handed, plain) < 4e-3
+
+
 # ------------------------------------------------------------------------------------------ races / determinism (tools/race_probe*.py)
 def _count_nonidentical(fn, reps, junk):
     ref = fn().clone()
