@@ -391,11 +391,13 @@ class ArcFlowDistiller:
         gbuf = self.grad
         dy = ops.head_grad(d_means, d_logw, d_logg, logw, self.head_n)                 # [M, head_n] bf16
         M = B * N
-        Mp = (M + 63) // 64 * 64
-        if Mp != M:
-            raise ValueError('batch x tokens must be a multiple of 64 for the weight-gradient GEMM')
-        dyt, xnt = ops.transpose(dy), ops.transpose(xn)                               # contraction over tokens
-        ops.linear_f32out(dyt, xnt, out=self._view(gbuf, 0).view(self.head_n, self.D), accumulate=True)
+        gw = self._view(gbuf, 0).view(self.head_n, self.D)
+        if self.head_n % 8 == 0 and gw.data_ptr() % 16 == 0:     # contraction over the tokens, straight from the token-major operands (afx_tn.hip)
+            ops.linear_tn_f32out(dy[:, :self.head_n], xn, out=gw, accumulate=True)
+        else:
+            if M % 64:
+                raise ValueError('batch x tokens must be a multiple of 64 for the weight-gradient GEMM')
+            ops.linear_f32out(ops.transpose(dy), ops.transpose(xn), out=gw, accumulate=True)
         ops.colsum(dy, self._view(gbuf, 1))
         dxn = ops.linear(dy, ops.transpose(self.w_head))                               # [M, D] bf16 = dY . W_head
         dmod = ops.normout_backward(xf, dxn, torch.zeros(B, 2, self.D, dtype=torch.float32, device=dev), N)
