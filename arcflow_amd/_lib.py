@@ -29,7 +29,7 @@ EXPORTS = [
     'afx_linear_bf16_pre', 'afx_linear_bf16_sk', 'afx_linear_sk_ws_bytes', 'afx_linear_sk_last_split', 'afx_gemm_set_mode', 'afx_attn_set_impl', 'afx_mmdit_prepare_steps', 'afx_mmdit_use_prepared_step', 'afx_lora_dropout_bf16', 'afx_mmdit_forward_stage', 'afx_mmdit_import_tokens',
     'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override', 'afx_set_fp8_linear',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
-    'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_linear_tn_f32out', 'afx_linear_bf16_dropres', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward',
+    'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_linear_tn_f32out', 'afx_linear_bf16_dropres', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward', 'afx_normout_backward_split',
     'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_adamw8bit_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
 ]
 
@@ -153,6 +153,7 @@ def load() -> C.CDLL:
     lib.afx_transpose_bf16.argtypes = [vp, i64, vp, i64, i32, i32, vp]
     lib.afx_colsum_bf16.argtypes = [vp, i64, vp, i32, i32, vp]
     lib.afx_normout_backward.argtypes = [vp, i64, vp, i64, vp, i32, i32, i32, vp]
+    lib.afx_normout_backward_split.argtypes = [vp, i64, vp, i64, vp, vp, i32, i32, vp]
     lib.afx_outer_accum.argtypes = [vp, vp, vp, i32, i32, i32, vp]
     lib.afx_mmdit_export.argtypes = [vp, C.c_char_p, vp, i32, i32, i32, vp]
     lib.afx_sumsq.argtypes = [vp, vp, i64, vp]

@@ -484,8 +484,8 @@ __global__ __launch_bounds__(256) void normout_bwd_kernel(const bf16_t* __restri
 }
 
 // dmod[b][j] += sum over the waves w of batch entry b of part[w][j]; blockIdx.y splits a batch entry's waves, one atomic per (split, column)
-__global__ __launch_bounds__(256) void normout_reduce_kernel(const float* __restrict__ part, float* __restrict__ dmod, int waves_per_batch,
-                                                             int twoD, int splits) {
+__global__ __launch_bounds__(256) void normout_reduce_kernel(const float* __restrict__ part, float* __restrict__ d_scale, float* __restrict__ d_shift,
+                                                             int64_t batch_stride, int waves_per_batch, int twoD, int splits) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= twoD) return;
   const int b = blockIdx.y / splits, sp = blockIdx.y % splits;
@@ -498,7 +498,8 @@ __global__ __launch_bounds__(256) void normout_reduce_kernel(const float* __rest
     a0 += p[0]; a1 += p[twoD]; a2 += p[2 * (int64_t)twoD]; a3 += p[3 * (int64_t)twoD];
   }
   for (; w < w1; ++w, p += twoD) a0 += p[0];
-  atomicAdd(dmod + (int64_t)b * twoD + j, (a0 + a1) + (a2 + a3));
+  const int D_ = twoD >> 1;         // column j < D: d_scale, else d_shift (afx_normout_backward: one [B, 2, D] block; afx_normout_backward_split: two vectors)
+  atomicAdd((j < D_ ? d_scale + j : d_shift + (j - D_)) + (int64_t)b * batch_stride, (a0 + a1) + (a2 + a3));
 }
 
 // dW[j, k] += sum_b dmod[b, j] * x[b, k]   (rank-B update of the norm_out.linear weight, B <= 8)
@@ -714,9 +715,24 @@ int afx_gemv_t_bf16(const float* x, int64_t ldx, const void* W, int64_t ldw, flo
   return AFX_OK;
 }
 
+static int normout_backward_impl(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* d_scale, float* d_shift, int64_t batch_stride, int32_t rows,
+                                 int32_t D, int32_t rows_per_batch, void* stream);
+
 int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
                          int32_t D, int32_t rows_per_batch, void* stream) {
-  if (!x || !dxn || !dmod_accum || rows < 1 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1 || rows % rows_per_batch)
+  if (!dmod_accum) return fail(AFX_E_INVALID, "bad argument to afx_normout_backward");
+  return normout_backward_impl(x, ldx, dxn, ldd, dmod_accum, dmod_accum + D, 2 * (int64_t)D, rows, D, rows_per_batch, stream);
+}
+
+int afx_normout_backward_split(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* d_scale_accum, float* d_shift_accum, int32_t rows,
+                               int32_t D, void* stream) {
+  if (!d_scale_accum || !d_shift_accum) return fail(AFX_E_INVALID, "bad argument to afx_normout_backward_split");
+  return normout_backward_impl(x, ldx, dxn, ldd, d_scale_accum, d_shift_accum, 0, rows, D, rows, stream);
+}
+
+static int normout_backward_impl(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* d_scale, float* d_shift, int64_t batch_stride, int32_t rows,
+                                 int32_t D, int32_t rows_per_batch, void* stream) {
+  if (!x || !dxn || rows < 1 || D < 8 || D % 8 || D > 4096 || rows_per_batch < 1 || rows % rows_per_batch)
     return fail(AFX_E_INVALID, "bad argument to afx_normout_backward");
   // rows per wave: 8 (a 4608-row call = 576 waves on 256 CUs; the first version's 32 left it with 36 work-groups).  AFX_NORMOUT_RPW overrides.
   static int rpw_env = -1;
@@ -762,7 +778,7 @@ int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ld
   hipLaunchKernelGGL(normout_bwd_kernel, dim3((waves + 3) / 4), dim3(256), 0, st, (const bf16_t*)x, ldx, (const bf16_t*)dxn, ldd, part, rows, D,
                      rows_per_batch, rpw);
   const int splits = wpb >= 64 ? 8 : 1;
-  hipLaunchKernelGGL(normout_reduce_kernel, dim3((2 * D + 255) / 256, nb * splits), dim3(256), 0, st, part, dmod_accum, wpb, 2 * D, splits);
+  hipLaunchKernelGGL(normout_reduce_kernel, dim3((2 * D + 255) / 256, nb * splits), dim3(256), 0, st, part, d_scale, d_shift, batch_stride, wpb, 2 * D, splits);
   HIP_TRY(hipGetLastError());
   return AFX_OK;
 }

@@ -476,6 +476,13 @@ def normout_backward(x, dxn, dmod_accum, rows_per_batch: int):
     return dmod_accum
 
 
+def normout_backward_split(x, dxn, d_scale_accum, d_shift_accum):
+    """d_scale_accum[D] += sum_rows dxn * LN(x), d_shift_accum[D] += sum_rows dxn (all rows one batch entry; fp32 vectors, e.g. slices of a larger buffer)."""
+    lib = _lib.load()
+    assert d_scale_accum.is_contiguous() and d_shift_accum.is_contiguous() and d_scale_accum.dtype == torch.float32
+    _lib.check(lib.afx_normout_backward_split(_p(x), x.stride(0), _p(dxn), dxn.stride(0), _p(d_scale_accum), _p(d_shift_accum), x.shape[0], x.shape[1], _s()))
+
+
 def outer_accum(dmod, x, dW_accum):
     lib = _lib.load()
     B, J = dmod.shape

@@ -343,12 +343,8 @@ class LoraTrunk:
     # ------------------------------------------------------------------ LoRA gradients of one linear
     def _dmod_ln(self, x: torch.Tensor, dxn: torch.Tensor, off_scale: int, off_shift: int) -> None:
         """xn = LN(x) (1 + scale) + shift:  d_scale += sum_rows dxn * LN(x),  d_shift += sum_rows dxn."""
-        on_side = self.side is not None and torch.cuda.current_stream(self.dev) == self.side
-        tmp = self._tmp2_side if on_side else self._tmp2          # one scratch per stream: the two token streams run concurrently
-        tmp.zero_()
-        ops.normout_backward(x, dxn, tmp.view(1, 2, self.D), x.shape[0])
-        self.dmod[off_scale:off_scale + self.D] += tmp[0]
-        self.dmod[off_shift:off_shift + self.D] += tmp[1]
+        # straight into the sample's modulation-gradient vector (float atomics per column: the two token streams add into different slices)
+        ops.normout_backward_split(x, dxn, self.dmod[off_scale:off_scale + self.D], self.dmod[off_shift:off_shift + self.D])
 
     # ------------------------------------------------------------------ timestep embedder with its LoRA pair (host-sized math)
     def _keep_scale(self, sp: LoraSpec, rows: int, cols: int) -> Optional[torch.Tensor]:

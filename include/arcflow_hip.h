@@ -217,6 +217,10 @@ int afx_colsum_bf16(const void* x, int64_t ldx, float* out_accum, int32_t rows, 
  * long row ranges are folded in 8 splits that meet in float atomics, so the result is reproducible to the rounding of that sum's order. */
 int afx_normout_backward(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* dmod_accum, int32_t rows,
                          int32_t D, int32_t rows_per_batch, void* stream);
+/* The same sums for ONE batch entry into two separate fp32 [D] accumulators (d_scale += sum_rows dxn * LN(x), d_shift += sum_rows dxn): the training trunk adds
+ * every block's AdaLN modulation gradients straight into its per-sample [n_mod] vector -- no scratch pair, no add passes. */
+int afx_normout_backward_split(const void* x, int64_t ldx, const void* dxn, int64_t ldd, float* d_scale_accum, float* d_shift_accum, int32_t rows,
+                               int32_t D, void* stream);
 /* Modulation gradients of the blocks (needed by the timestep-embedder LoRA pair, configs/flux/arcflux_2nfe_k16.py:46-47):
  * out_accum[c] += sum_r a[r,c] b[r,c] (d_gate = sum_tokens dX_out * branch output);  out = res + gate[c] * y (gated residual kept
  * apart from the GEMM so that y can be stored);  out_accum[b,k] += sum_n x[b,n] W[n,k] (d silu(temb) through the stacked
