@@ -126,8 +126,6 @@ class LoraTrunk:
         self.bt16: Dict[str, torch.Tensor] = {}
         self.ybuf: Optional[torch.Tensor] = None     # [2 nd + ns, B*S, D] pre-gate branch outputs of the last training forward
         self.dmod: Optional[torch.Tensor] = None     # [n_mod] fp32: modulation gradients of the sample being back-propagated
-        self._tmp2 = torch.zeros(2, self.D, dtype=torch.float32, device=self.dev)
-        self._tmp2_side = torch.zeros(2, self.D, dtype=torch.float32, device=self.dev)
         self.p_drop = 0.0           # LoRA input dropout (peft lora_dropout); masks are regenerated from (seed, site, row, col)
         self.seed = 0
         self.row0 = 0               # global row of this sample's first token: the batched masks are indexed by global row
