@@ -44,6 +44,14 @@ def test_argument_validation_no_gpu(lib):
     assert lib.afx_mmdit_forward(ctx, None, None, None, None, None, None, None, 1, 4, 4, None, None, None, None) == -1
     assert lib.afx_linear_bf16(None, 8, None, 8, None, None, 8, 1, 8, 64, 0, 0, None, 0, 1, None, 0, None) == -1
     assert lib.afx_arcflow_step(None, None, None, None, 1, 1.0, 1.0, 0.5, None, 1e-4, None, 1, 1, 16, 64, 4, None) == -1
+    # round-5 entry points: nulls, misaligned / non-multiple-of-8 widths are refused before any launch
+    assert lib.afx_linear_tn_f32out(None, 8, None, 8, None, 8, 64, 8, 8, 0, None) == -1
+    assert lib.afx_linear_tn_f32out(C.c_void_p(4096), 8, C.c_void_p(8192), 8, C.c_void_p(16384), 8, 64, 12, 8, 0, None) == -1      # N1 % 8
+    assert lib.afx_linear_tn_f32out(C.c_void_p(4096 + 2), 8, C.c_void_p(8192), 8, C.c_void_p(16384), 8, 64, 8, 8, 0, None) == -1   # 16-byte alignment
+    assert b'afx_linear_tn_f32out' in lib.afx_last_error()
+    assert lib.afx_linear_bf16_dropres(None, 64, None, 64, None, 8, 1, 8, 64, None, 8, 0.05, 1, 0, None) == -1
+    assert lib.afx_linear_bf16_dropres(C.c_void_p(4096), 64, C.c_void_p(8192), 64, C.c_void_p(16384), 8, 1, 8, 64, C.c_void_p(16384), 8, 1.5, 1, 0, None) == -1   # p >= 1
+    assert lib.afx_normout_backward_split(None, 8, None, 8, None, None, 1, 8, None) == -1
     assert lib.afx_destroy(ctx) == 0
 
 
