@@ -79,10 +79,16 @@ class _Base:
         return t.to(self.dev, torch.float32).contiguous()
 
     def _linear(self, x, w, b=None, residual=None):
-        """y = x w^T (+ b) (+ residual).  A prompt is one or two 256-row tiles: when M x N alone cannot fill the chip the
-        K range is split across work-groups (ops.linear_splitk), otherwise the plain fused-epilogue GEMM runs."""
+        """y = x w^T (+ b) (+ residual).  A prompt is one or two 256-row tiles.  Measured on every encoder shape (tools/t5_gemm_probe.py, round 5: the
+        rule of round 2 predates the 128x128 / 256x224 shapes of the one-wave-per-SIMD kernel and sent T5-XXL's q|k|v, o and wi launches to split-K at
+        1.5-1.9x the plain kernel's time): the plain fused GEMM (the launcher picks 128x128 tiles, two work-groups per CU, when 256x256 would leave half the
+        chip idle) costs ~0.6 us per 64-wide K-tile whatever N; splitting K pays only when the K loop itself is long (K >= 8192: T5's wo 85 -> 59 us with 8
+        chunks, Qwen2.5-VL's down projection 146 -> 48 us with 16) or when even the small tiles are a handful (<= 80 of them, K >= 3072)."""
         M, N, K = x.shape[0], w.shape[0], w.shape[1]
-        if ((M + 255) // 256) * ((N + 255) // 256) <= 170 and K >= 512:
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        if K >= 8192:
+            return ops.linear_splitk(x, w, b, residual, split_k=8 if K < 16384 else 16)
+        if K >= 3072 and t128 <= 80:
             return ops.linear_splitk(x, w, b, residual)
         if residual is not None:
             return ops.linear(x, w, b, epilogue='gate_res', residual=residual)
