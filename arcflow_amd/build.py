@@ -14,11 +14,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libarcflow_hip.so'
-SOURCES = ['afx_gemm.hip', 'afx_attn.hip', 'afx_attn3.hip', 'afx_attn_bwd.hip', 'afx_elementwise.hip', 'afx_train.hip', 'afx_vae.hip', 'afx_text.hip', 'afx_tn.hip', 'afx_engine.hip']
+SOURCES = ['afx_gemm.hip', 'afx_attn.hip', 'afx_attn3.hip', 'afx_attn_bwd.hip', 'afx_attn_bwd3.hip', 'afx_elementwise.hip', 'afx_train.hip', 'afx_vae.hip', 'afx_text.hip', 'afx_tn.hip', 'afx_engine.hip']
 HEADERS = ['afx_common.h', 'afx_kernels.h', 'afx_api_util.h', os.path.join('..', '..', 'include', 'arcflow_hip.h')]
 HEADERS += [os.path.join('gen', f) for f in sorted(os.listdir(os.path.join(CSRC, 'gen'))) if f.endswith('.inc')]
 # sources whose kernels OWN registers by literal name (tools/gen_attn3.py): their ISA is audited after every build
-ASM_OWNED = {'afx_attn3.hip': 'attention_v3_kernel'}
+ASM_OWNED = {'afx_attn3.hip': ('attention_v3_kernel', 96), 'afx_attn_bwd3.hip': ('attn_bwd_dkv3_kernel', 64)}
 # kernels whose accumulators are written by inline-asm MFMAs the compiler cannot see into: a register spill there may store an accumulator straight
 # behind the MFMA that is still writing it (happened to gemm_kernel_v3f8 once its epilogue grew) -- they must not use scratch at all
 NO_SCRATCH = {'afx_gemm.hip': ['gemm_kernel_v3f8', 'gemm_kernel_v3ILi8ELi8ELb0ELi0E', 'gemm_kernel_v3ILi8ELi7ELb0ELi0E', 'gemm_kernel_v3ILi7ELi8ELb0ELi0E',
@@ -134,7 +134,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose and log.strip():
             print(log)
         if src in ASM_OWNED:
-            audit_asm_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ASM_OWNED[src])
+            audit_asm_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), *ASM_OWNED[src])
         if src in NO_SCRATCH:
             audit_no_scratch(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), NO_SCRATCH[src])
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out]
@@ -165,7 +165,7 @@ def build_variant(name: str, extra_flags, sources) -> str:
             if r.returncode != 0:
                 raise RuntimeError(f'hipcc failed on {src} ({name}):\n{r.stdout}')
             if src in ASM_OWNED:
-                audit_asm_owned(os.path.join(vdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ASM_OWNED[src])
+                audit_asm_owned(os.path.join(vdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), *ASM_OWNED[src])
         objs.append(obj)
     out = os.path.join(LIBDIR, f'libarcflow_hip_{name}.so')
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,

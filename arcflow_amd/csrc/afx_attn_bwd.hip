@@ -11,6 +11,8 @@
 //                 operands of dV^T += dO^T P and dK^T += Q^T dS (Q^T / dO^T tiles pre-transposed, queries permuted)
 // S and dP are recomputed in both kernels (7 matmuls instead of 5) in exchange for determinism and zero
 // inter-work-group traffic.  Tiles stream HBM -> LDS by LDS-DMA into 2-stage XOR-swizzled rings.
+#include <cstdlib>
+
 #include "afx_common.h"
 #include "afx_kernels.h"
 
@@ -495,7 +497,16 @@ __global__ __launch_bounds__(DKV_THREADS, 1) void attn_bwd_dkv_kernel(
 
 int64_t attn_bwd_ws_bytes(int B, int H, int S) {
   const int64_t S_pad = attn_spad(S);
-  return 3 * (int64_t)B * H * HD * S_pad * 2 + (int64_t)B * H * S_pad * 4;
+  return 3 * (int64_t)B * H * HD * S_pad * 2 + (int64_t)B * H * S_pad * 4 + attn_bwd3_stats_bytes(B, H, S);
+}
+
+// 3 (default): the generated one-wave-per-SIMD dK / dV kernel of afx_attn_bwd3.hip (no Q / dO transposes); 2: the round-4 kernel (A/B, AFX_ATTN_BWD_IMPL=2)
+static int attn_bwd_impl() {
+  static const int impl = [] {
+    const char* e = getenv("AFX_ATTN_BWD_IMPL");
+    return e != nullptr ? atoi(e) : 3;
+  }();
+  return impl;
 }
 
 hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
@@ -508,14 +519,20 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
   uint16_t* qt = kt + tsz;
   uint16_t* dot = qt + tsz;
   float* delta = (float*)(dot + tsz);
+  float* stats = delta + (int64_t)B * H * S_pad;
+  const bool v3 = attn_bwd_impl() != 2 && S_pad / 32 >= 4;
   hipError_t e;
-  if ((e = hipMemsetAsync(delta, 0, (size_t)B * H * S_pad * 4, stream)) != hipSuccess) return e;
   if ((e = launch_v_transpose(k, ldk, kt, B, H, S, stream)) != hipSuccess) return e;
-  if ((e = launch_v_transpose(q, ldq, qt, B, H, S, stream)) != hipSuccess) return e;
-  if ((e = launch_v_transpose(dout, lddo, dot, B, H, S, stream)) != hipSuccess) return e;
-  const int64_t total = (int64_t)B * S * H * 16;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, o, ldo, dout, lddo,
-                     delta, H, S, S_pad, total);
+  if (v3) {
+    if ((e = launch_attn_bwd_stats(o, ldo, dout, lddo, lse, stats, delta, B, H, S, stream)) != hipSuccess) return e;
+  } else {
+    if ((e = hipMemsetAsync(delta, 0, (size_t)B * H * S_pad * 4, stream)) != hipSuccess) return e;
+    if ((e = launch_v_transpose(q, ldq, qt, B, H, S, stream)) != hipSuccess) return e;
+    if ((e = launch_v_transpose(dout, lddo, dot, B, H, S, stream)) != hipSuccess) return e;
+    const int64_t total = (int64_t)B * S * H * 16;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, o, ldo, dout, lddo,
+                       delta, H, S, S_pad, total);
+  }
   static bool attr = false;
   if (!attr) {
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -528,6 +545,7 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
   const int nq = (S + DQ_WAVES * 32 - 1) / (DQ_WAVES * 32);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(8 * hpx * nq * B), dim3(DQ_THREADS), 2 * DQ_STAGE, stream, q, ldq, k, ldk, v,
                      ldv, kt, dout, lddo, lse, delta, dq, lddq, H, S, S_pad, nq, B);
+  if (v3) return launch_attn_bwd_dkv3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dk, lddk, dv, lddv, B, H, S, stream);
   const int nk = (S + DKV_WAVES * 32 - 1) / (DKV_WAVES * 32);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(8 * hpx * nk * B), dim3(DKV_THREADS), 2 * DKV_STAGE, stream, q, ldq, k, ldk,
                      v, ldv, qt, dout, lddo, dot, lse, delta, dk, lddk, dv, lddv, H, S, S_pad, nk, B);

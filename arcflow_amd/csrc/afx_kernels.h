@@ -131,8 +131,15 @@ hipError_t launch_kv_prep(uint16_t* k, uint16_t* q, int64_t ldk, const float* wk
 hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv,
                                 uint16_t* vt_ws, uint16_t* o, int64_t ldo, int B, int H, int Hkv, int S, int head_dim, float scale,
                                 int causal, const float* bias, hipStream_t stream);
-// backward: see afx_attn_bwd.hip.  ws layout: Kt | Qt | dOt (each B*H*128*S_pad bf16) | delta (B*H*S_pad f32)
+// backward: see afx_attn_bwd.hip / afx_attn_bwd3.hip.  ws layout: Kt | Qt | dOt (each B*H*128*S_pad bf16) | delta (B*H*S_pad f32) | stats (2*B*H*S_pad f32)
+// (Qt / dOt are used by the round-4 dK / dV kernel only: AFX_ATTN_BWD_IMPL=2 and S <= 64)
 int64_t attn_bwd_ws_bytes(int B, int H, int S);
+int64_t attn_bwd3_stats_bytes(int B, int H, int S);
+hipError_t launch_attn_bwd_stats(const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo, const float* lse, float* stats, float* delta_old,
+                                 int B, int H, int S, hipStream_t stream);
+hipError_t launch_attn_bwd_dkv3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, const uint16_t* dout,
+                                int64_t lddo, const float* stats, uint16_t* dk, int64_t lddk, uint16_t* dv, int64_t lddv, int B, int H, int S,
+                                hipStream_t stream);
 hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
                                      int64_t ldv, const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo,
                                      const float* lse, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk,

@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generator of the instruction stream of the key-stationary dK / dV kernel (arcflow_amd/csrc/afx_attn_bwd3.hip, round 5).
+
+Same method as tools/gen_attn3.py (the forward): one wave per SIMD, every instruction of the loop its own `asm volatile` statement (source
+order = issue order), every wide operand ASM-OWNED (literal register names; `amdgpu_num_vgpr(64)` confines hipcc to v[0:63], arcflow_amd/build.py
+audits the ISA).  A wave owns 32 keys (lane = key); the queries stream by in HALVES of 32 (two per 64-query tile):
+
+    accumulator file   a[  0: 63]  dV^T accumulators  DVA[d]      = a[16 d ..+15]          (d = 32-column block of the head dim)
+                       a[ 64:127]  dK^T accumulators  DKA[d]      = a[64 + 16 d ..+15]
+                       a[128:159]  K fragments        KF[s]       = a[128 + 4 s ..+3]      (stationary B operands, s = 16-wide k-step of d)
+                       a[160:191]  V fragments        VF[s]       = a[160 + 4 s ..+3]
+                       a[192:255]  row fragments      RQ[s] / RO[s] = a[192 + 4 s ..] / a[224 + 4 s ..]   (Q / dO rows of the half: A operands of S, dP)
+    arch VGPRs         v[  0: 63]  hipcc's: LDS / DMA addresses, loop control
+                       v[ 64:127]  S / dP             SS[set] = v[64 + 32 set ..+15], DP[set] = v[80 + 32 set ..+15]   (set = half & 1)
+                       v[128:191]  transposed fragments TO[i] = v[128 + 4 i ..+3] (dO^T), TQ[i] = v[160 + 4 i ..+3] (Q^T), i = 4 ksub + d
+                       v[192:223]  P / dS words       PW[set][ksub] = v[192 + 16 set + 4 ksub ..+3], DW[set][ksub] = v[200 + 16 set + 4 ksub ..+3]
+                       v[224:255]  L (16) | delta (16) of the half whose softmax gradient runs
+
+One PHASE = 32 MFMAs = one half-step p of the software pipeline (J = p % 8 = the half's ring slot; set = p & 1):
+    MFMA   SD(p):   S(p) = Q(p) K^T, dP(p) = dO(p) V^T          (16, A = row fragments read in phase p - 1)
+           DV(p-2): dV^T += dO^T(p-2) P(p-2), dK^T += Q^T(p-2) dS(p-2)   (16, A = ds_read_b64_tr_b16 fragments read in this phase's first half)
+    VALU   SM(p-1): P = exp2(S c - L), dS = P (dP - delta), both rounded to bf16 words (80 instructions, in place in the S / dP registers)
+    LDS    32 transpose reads of half p - 2 (gaps 0-15), 16 row reads of half p + 1 + 8 L / delta reads of half p (gaps 16-31)
+    DMA    half p + 5 -> slot (J + 5) % 8: 4 pieces of the wave's tensor (waves 0, 1: Q rows 0-15 / 16-31, waves 2, 3: dO) + the 256-byte L | delta block
+Every phase issues the SAME sequence of LDS reads and DMA pieces, so the counted waits (lgkmcnt / vmcnt) hold in the peeled first and last
+phases too (which only drop MFMAs / VALU work whose inputs do not exist yet).
+
+LDS half-slot (16640 bytes): Q [4 d-blocks][32 rows][64 B] | dO (same) | L[32] | delta[32].  Inside a 64-byte row the 16-byte chunk c sits at
+c ^ ((row >> 2) & 3): a ds_read_b128 of 16 consecutive rows and a transpose read of 4 rows x 64 bytes both touch every bank once.
+
+Writes arcflow_amd/csrc/gen/b3_*.inc (committed; the build does not run this script).  Usage: python tools/gen_attn_bwd3.py
+"""
+import argparse
+import os
+
+SLOT = 16640
+X_DO = 8192
+STAT = 16384
+NSLOT = 8
+MFMA = 'v_mfma_f32_32x32x16_bf16'
+ABL = set()
+
+
+def rng(prefix, lo, n):
+    return f'{prefix}[{lo}:{lo + n - 1}]'
+
+
+def DVA(d):
+    return rng('a', 16 * d, 16)
+
+
+def DKA(d):
+    return rng('a', 64 + 16 * d, 16)
+
+
+def KF(s):
+    return rng('a', 128 + 4 * s, 4)
+
+
+def VF(s):
+    return rng('a', 160 + 4 * s, 4)
+
+
+def RQ(s):
+    return rng('a', 192 + 4 * s, 4)
+
+
+def RO(s):
+    return rng('a', 224 + 4 * s, 4)
+
+
+def SS(st):
+    return rng('v', 64 + 32 * st, 16)
+
+
+def DP(st):
+    return rng('v', 80 + 32 * st, 16)
+
+
+def SSx(st, r):
+    return f'v{64 + 32 * st + r}'
+
+
+def DPx(st, r):
+    return f'v{80 + 32 * st + r}'
+
+
+def T_lo(which, i):
+    """first register of transposed fragment i = 4 ksub + d: which 0 = dO^T (TO), 1 = Q^T (TQ)"""
+    return (128 if which == 0 else 160) + 4 * i
+
+
+def PW(st, ks):
+    return rng('v', 192 + 16 * st + 4 * ks, 4)
+
+
+def DW(st, ks):
+    return rng('v', 200 + 16 * st + 4 * ks, 4)
+
+
+def PWx(st, w):
+    return f'v{192 + 16 * st + w}'
+
+
+def DWx(st, w):
+    return f'v{200 + 16 * st + w}'
+
+
+def Lx(r):
+    return f'v{224 + r}'
+
+
+def Dx(r):
+    return f'v{240 + r}'
+
+
+def asm(text, outs='', ins='', clob=''):
+    s = f'asm volatile("{text}" : {outs} : {ins}'
+    if clob:
+        s += f' : {clob}'
+    return s + ');'
+
+
+def wait(text, own=False):
+    return asm(text, '', '', '"memory"' + (', "v255", "a255"' if own else ''))
+
+
+# ---- register bookkeeping of the LDS queue: which read (sequence number) last wrote a register ----------------------------------------
+class Lds:
+    """LDS reads return in order: a consumer of read q may go ahead once at most (issued - 1 - q) younger reads are outstanding.  lgkmcnt is a 4-bit
+    counter: counts above 15 are clamped (an over-wait, by then long satisfied: such reads were issued >= 8 MFMAs earlier)."""
+
+    def __init__(self):
+        self.issued = 0
+        self.writer = {}
+        self.done = -1
+
+    def read(self, regs):
+        for r in regs:
+            self.writer[r] = self.issued
+        self.issued += 1
+
+    def need(self, regs):
+        q = max((self.writer.get(r, -1) for r in regs), default=-1)
+        if q <= self.done:
+            return []
+        n_after = min(self.issued - 1 - q, 15)
+        self.done = self.issued - 1 - n_after
+        return [wait(f's_waitcnt lgkmcnt({n_after})')]
+
+    def new_phase(self):
+        self.done = -1           # nothing carried: every phase re-establishes what it needs (peeled phases emit fewer waits than the steady ones)
+
+
+def regs_of(prefix, lo, n):
+    return [f'{prefix}{i}' for i in range(lo, lo + n)]
+
+
+# ---- single instructions ---------------------------------------------------------------------------------------------------------------
+def sd(st, m):
+    """MFMA m = 0..15 of S = Q K^T (even) / dP = dO V^T (odd), k-step s = m >> 1"""
+    s = m >> 1
+    if m & 1:
+        return asm(f'{MFMA} {DP(st)}, {RO(s)}, {VF(s)}, {0 if s == 0 else DP(st)}'), regs_of('a', 224 + 4 * s, 4)
+    return asm(f'{MFMA} {SS(st)}, {RQ(s)}, {KF(s)}, {0 if s == 0 else SS(st)}'), regs_of('a', 192 + 4 * s, 4)
+
+
+def dv(st, n):
+    """MFMA n = 0..15 of dV^T += dO^T P (even) / dK^T += Q^T dS (odd): ksub = n >> 3, d = (n >> 1) & 3 (an accumulator comes back after 8 MFMAs)"""
+    ks, d, which = n >> 3, (n >> 1) & 3, n & 1
+    lo = T_lo(which, 4 * ks + d)
+    if which == 0:
+        return asm(f'{MFMA} {DVA(d)}, {rng("v", lo, 4)}, {PW(st, ks)}, {DVA(d)}'), regs_of('v', lo, 4)
+    return asm(f'{MFMA} {DKA(d)}, {rng("v", lo, 4)}, {DW(st, ks)}, {DKA(d)}'), regs_of('v', lo, 4)
+
+
+def ring(slot):
+    return 'h' if slot >= 4 else 'l'
+
+
+def read_row(lds, m, slot, extra=None):
+    """row fragment of next phase's SD MFMA m: tensor m & 1 (0 Q, 1 dO), k-step s = m >> 1: row ql, logical chunk 2 (s & 1) + hi of d-block s >> 1"""
+    s, tensor = m >> 1, m & 1
+    lo = (224 if tensor else 192) + 4 * s
+    off = tensor * X_DO + (s >> 1) * 2048
+    lds.read(regs_of('a', lo, 4))
+    if extra:
+        return asm(f'ds_read_b128 {rng("a", lo, 4)}, %0 offset:{off}', '', f'"v"(raddr{s & 1}l + {extra})')
+    return asm(f'ds_read_b128 {rng("a", lo, 4)}, %0 offset:{(slot & 3) * SLOT + off}', '', f'"v"(raddr{s & 1}{ring(slot)})')
+
+
+def read_tr(lds, k, slot, extra=None):
+    """transpose read k = 0..31: fragment of DV MFMA n = k >> 1, half rd = k & 1 (rows 16 ksub + 8 rd + 4 hi + 0..3 of the half)"""
+    n, rd = k >> 1, k & 1
+    ks, d, which = n >> 3, (n >> 1) & 3, n & 1
+    lo = T_lo(which, 4 * ks + d) + 2 * rd
+    off = (X_DO if which == 0 else 0) + d * 2048 + 16 * ks * 64          # (the + 8 rows of rd = 1 sit in taddr1*: the 16-bit offset field)
+    lds.read(regs_of('v', lo, 2))
+    if extra:
+        return asm(f'ds_read_b64_tr_b16 {rng("v", lo, 2)}, %0 offset:{off}', '', f'"v"(taddr{rd}l + {extra})')
+    return asm(f'ds_read_b64_tr_b16 {rng("v", lo, 2)}, %0 offset:{(slot & 3) * SLOT + off}', '', f'"v"(taddr{rd}{ring(slot)})')
+
+
+def read_stat(lds, which, g, slot):
+    """L (which 0) / delta (1) of queries 8 g + 4 hi + 0..3 of the half -> registers 4 g ..+3 of the block"""
+    lo = (224 if which == 0 else 240) + 4 * g
+    lds.read(regs_of('v', lo, 4))
+    return asm(f'ds_read_b128 {rng("v", lo, 4)}, %0 offset:{(slot & 3) * SLOT + which * 128 + 32 * g}', '', f'"v"(saddr{ring(slot)})')
+
+
+def dma(piece, slot):
+    # (s_add_u32 writes SCC: without the clobber hipcc keeps a loop-exit compare alive across the statement)
+    if piece < 4:
+        return asm(f's_add_u32 m0, %0, {slot * SLOT + piece * 2048}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %1, %2', '',
+                   f'"s"(wave_lds), "v"(xofs{piece}), "s"(xsrc)', '"memory", "scc"')
+    return asm(f's_add_u32 m0, %0, {slot * SLOT + STAT}\\n\\ts_nop 0\\n\\tglobal_load_lds_dword %1, %2', '', '"s"(lds0), "v"(sofs), "s"(ssrc)',
+               '"memory", "scc"')
+
+
+# ---- the softmax gradient of one half as an instruction list ----------------------------------------------------------------------------
+def sm_ops(st):
+    """(text, registers read that come from LDS, stage).  Stage k: A_k  S = S c - L;  C_k  dP = dP - delta;  B_(k-1)  S = exp2(S);  D_(k-3)  dP = S dP;
+    E  words of pairs (k - 4, k - 3).  A v_exp_f32 result is never read by the next instruction (trans -> VALU wait state)."""
+    ops = []
+    for k in range(16 + 3):
+        if k < 16:
+            ops.append((f'v_fma_f32 {SSx(st, k)}, {SSx(st, k)}, %0, -{Lx(k)}', [Lx(k)], k, True))
+            ops.append((f'v_sub_f32 {DPx(st, k)}, {DPx(st, k)}, {Dx(k)}', [Dx(k)], k, False))
+        if 0 <= k - 1 < 16:
+            ops.append((f'v_exp_f32 {SSx(st, k - 1)}, {SSx(st, k - 1)}', [], k, False))
+        if 0 <= k - 3 < 16:
+            i = k - 3
+            ops.append((f'v_mul_f32 {DPx(st, i)}, {SSx(st, i)}, {DPx(st, i)}', [], k, False))
+            if i & 1:
+                ops.append((f'v_cvt_pk_bf16_f32 {PWx(st, i >> 1)}, {SSx(st, i - 1)}, {SSx(st, i)}', [], k, False))
+                ops.append((f'v_cvt_pk_bf16_f32 {DWx(st, i >> 1)}, {DPx(st, i - 1)}, {DPx(st, i)}', [], k, False))
+    assert len(ops) == 80
+    if 'novalu' in ABL:
+        ops = []
+    return ops
+
+
+def emit_valu(lds, op):
+    text, lregs, _, uses_c = op
+    out = lds.need(lregs) if lregs else []
+    out.append(asm(text, '', '"s"(c)' if uses_c else ''))
+    return out
+
+
+# ---- one phase -------------------------------------------------------------------------------------------------------------------------------
+VALU_PER_GAP = 3
+
+
+def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
+    """half-step p with ring slot J = p % 8 (set = J & 1).  The C++ around it provides xsrc / ssrc / xofs0..3 (DMA of half p + 5)."""
+    st = J & 1
+    lds.new_phase()
+    out = [f'// ---- phase J = {J}: SD(p){"" if do_sd else " [off]"} | SM(p-1){"" if do_sm else " [off]"} | DV(p-2){"" if do_dv else " [off]"}']
+    # everything but the last three phases' DMA pieces has landed (half p + 1 was issued in phase p - 4); the barrier makes it everybody's pieces and
+    # says every wave is done with phase p - 1 (slot (J + 5) % 8 = half p - 3: last read there)
+    out.append(wait('s_waitcnt vmcnt(15)', own=True))
+    out.append(wait('s_barrier'))
+    sm = sm_ops(1 - st) if do_sm else []
+    # gap in which the last instruction of stage 4 g + 3 (the last reader of L / delta group g) is issued
+    pos, stage_gap = 0, {}
+    for gap in range(32):
+        for op in sm[pos:pos + VALU_PER_GAP]:
+            stage_gap[op[2]] = gap
+        pos += VALU_PER_GAP
+    free_after = [stage_gap.get(4 * g + 3, -1) for g in range(4)]          # group g's registers may be overwritten from the NEXT gap on
+    stat_plan = {}                                                          # gap -> [(which, g)]
+    gap = 16
+    for g in range(4):
+        for which in range(2):
+            gap = max(gap, free_after[g] + 1)
+            assert gap < 32, 'no room for the L / delta reads'
+            stat_plan.setdefault(gap, []).append((which, g))
+            gap += 1
+    dma_gaps = {17: 0, 20: 1, 23: 2, 26: 3, 29: 4}
+    k = 0
+    for gap in range(32):
+        if gap < 16:
+            if do_sd:
+                text, regs = sd(st, gap)
+                out += lds.need(regs)
+                out.append(text)
+            if 'nolds' not in ABL:
+                out.append(read_tr(lds, 2 * gap, (J + 6) % NSLOT))
+                out.append(read_tr(lds, 2 * gap + 1, (J + 6) % NSLOT))
+        else:
+            if do_dv:
+                text, regs = dv(st, gap - 16)
+                out += lds.need(regs)
+                out.append(text)
+            if 'nolds' not in ABL:
+                out.append(read_row(lds, gap - 16, (J + 1) % NSLOT))
+                for which, g in stat_plan.get(gap, []):
+                    out.append(read_stat(lds, which, g, J))
+            if gap in dma_gaps and 'nodma' not in ABL:
+                out.append(dma(dma_gaps[gap], (J + 5) % NSLOT))
+        for op in sm[k:k + VALU_PER_GAP]:
+            out += emit_valu(lds, op)
+        k += VALU_PER_GAP
+        if trace is not None and gap == 15:
+            out.append(f'B3_TR({trace})')
+    assert k >= len(sm)
+    return out
+
+
+# ---- blocks ------------------------------------------------------------------------------------------------------------------------------------
+def init():
+    out = ['// generated by tools/gen_attn_bwd3.py -- dV^T = dK^T = 0']
+    for lo in range(0, 128, 16):
+        out.append(asm('\\n\\t'.join(f'v_accvgpr_write_b32 a{lo + r}, 0' for r in range(16)), '', '', '"v255", "a255"' if lo == 0 else ''))
+    return out
+
+
+def kv_loads():
+    out = ['// generated by tools/gen_attn_bwd3.py -- the wave\'s K / V rows straight into the accumulator file (stationary B operands); waited for by hand']
+    for s in range(8):
+        out.append(asm(f'global_load_dwordx4 {KF(s)}, %0, off offset:{s * 32}', '', '"v"(kptr)', '"memory"'))
+        out.append(asm(f'global_load_dwordx4 {VF(s)}, %0, off offset:{s * 32}', '', '"v"(vptr)', '"memory"'))
+    return out
+
+
+def prologue_dma():
+    out = ['// generated by tools/gen_attn_bwd3.py -- halves 0..4 -> slots 0..4 (5 pieces each: the order the counted waits assume)']
+    for u in range(5):
+        out.append(f'{{ B3_SRC({u})')
+        out += [dma(i, u) for i in range(5)]
+        out.append('}')
+    return out
+
+
+def first_rows(lds):
+    out = ['// generated by tools/gen_attn_bwd3.py -- 16 K / V loads + 25 DMA pieces in flight: K, V and half 0 have landed when <= 20 remain']
+    out.append(wait('s_waitcnt vmcnt(20)', own=True))
+    out.append(wait('s_barrier'))
+    out += [read_row(lds, m, 0) for m in range(16)]
+    out.append(wait('s_waitcnt lgkmcnt(0)'))
+    return out
+
+
+def tail(lds, which):
+    """the two draining phases (runtime ring slot through `ts`, a byte offset added to the ring-0 addresses): not pipelined.
+    which 0: p = NH:     SM(NH - 1), DV(NH - 2)       which 1: p = NH + 1: DV(NH - 1)"""
+    out = [f'// generated by tools/gen_attn_bwd3.py -- draining phase {which} (set = {which}: NH is even)']
+    st = which                                   # p = NH + which, set = p & 1
+    out += [read_tr(lds, k, 0, 'ts') for k in range(32)]
+    if which == 0:
+        lds.new_phase()
+        for op in sm_ops(1 - st):
+            out += emit_valu(lds, op)
+    out.append(wait('s_waitcnt lgkmcnt(0)\\n\\ts_nop 3'))
+    out += [dv(st, n)[0] for n in range(16)]
+    return out
+
+
+def readout():
+    out = ['// generated by tools/gen_attn_bwd3.py -- epilogue: one [32 d][32 keys] accumulator tile -> 16 VGPR scalars ox[0..15]']
+    out.append('#define B3_DRAIN ' + asm('s_waitcnt vmcnt(0)\\n\\ts_nop 15\\n\\ts_nop 15', '', '', '"memory"'))
+    for name, base in (('V', 0), ('K', 64)):
+        for d in range(4):
+            lo = base + 16 * d
+            text = '\\n\\t'.join(f'v_accvgpr_read_b32 %{r}, a{lo + r}' for r in range(16))
+            outs = ', '.join(f'"=v"(ox[{r}])' for r in range(16))
+            out.append(f'#define B3_READ_{name}_{d} ' + asm(text, outs, ''))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn_bwd3.hip includes B3_GEN/..., default gen)')
+    ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu: timing experiments, WRONG results')
+    ap.add_argument('--valu-per-gap', type=int, default=3)
+    a = ap.parse_args()
+    ABL.update(x for x in a.ablate.split(',') if x)
+    global VALU_PER_GAP
+    VALU_PER_GAP = a.valu_per_gap
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'arcflow_amd', 'csrc', a.out)
+    os.makedirs(root, exist_ok=True)
+    files = {'b3_init.inc': init(), 'b3_kvload.inc': kv_loads(), 'b3_prologue_dma.inc': prologue_dma(), 'b3_readout.inc': readout()}
+    lds = Lds()
+    files['b3_first_rows.inc'] = first_rows(lds)
+    files['b3_p0.inc'] = ['// generated by tools/gen_attn_bwd3.py -- p = 0 (slot 0): SD(0) only'] + phase(lds, 0, True, False, False)
+    files['b3_p1.inc'] = ['// generated by tools/gen_attn_bwd3.py -- p = 1 (slot 1): SD(1), SM(0)'] + phase(lds, 1, True, True, False)
+    # steady state: the loop enters at J = 2 and walks 2, 3, ..., 7, 0, 1; every phase issues the same LDS sequence, so one running queue model serves
+    for J in (2, 3, 4, 5, 6, 7, 0, 1):
+        files[f'b3_body{J}.inc'] = [f'// generated by tools/gen_attn_bwd3.py -- steady-state phase, ring slot J = {J}'] + phase(lds, J, trace=J)
+    files['b3_tail0.inc'] = tail(lds, 0)
+    files['b3_tail1.inc'] = tail(lds, 1)
+    for f in os.listdir(root):
+        if f.startswith('b3_') and f not in files:
+            os.remove(os.path.join(root, f))
+    for name, lines in files.items():
+        with open(os.path.join(root, name), 'w') as f:
+            f.write('\n'.join(lines) + '\n')
+        print(name, len(lines), 'lines')
+
+
+if __name__ == '__main__':
+    main()
