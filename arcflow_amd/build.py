@@ -15,10 +15,10 @@ CSRC = os.path.join(HERE, 'csrc')
 LIBDIR = os.path.join(HERE, 'lib')
 LIBNAME = 'libarcflow_hip.so'
 SOURCES = ['afx_gemm.hip', 'afx_attn.hip', 'afx_attn3.hip', 'afx_attn_bwd.hip', 'afx_attn_bwd3.hip', 'afx_elementwise.hip', 'afx_train.hip', 'afx_vae.hip', 'afx_text.hip', 'afx_tn.hip', 'afx_engine.hip']
-HEADERS = ['afx_common.h', 'afx_kernels.h', 'afx_api_util.h', os.path.join('..', '..', 'include', 'arcflow_hip.h')]
+HEADERS = ['afx_common.h', 'afx_kernels.h', 'afx_api_util.h', 'afx_attn_bwd3_kernel.inc', os.path.join('..', '..', 'include', 'arcflow_hip.h')]
 HEADERS += [os.path.join('gen', f) for f in sorted(os.listdir(os.path.join(CSRC, 'gen'))) if f.endswith('.inc')]
 # sources whose kernels OWN registers by literal name (tools/gen_attn3.py): their ISA is audited after every build
-ASM_OWNED = {'afx_attn3.hip': ('attention_v3_kernel', 96), 'afx_attn_bwd3.hip': ('attn_bwd_dkv3_kernel', 64)}
+ASM_OWNED = {'afx_attn3.hip': ('attention_v3_kernel', 96), 'afx_attn_bwd3.hip': ('attn_bwd_dkv3_kernel', 60, 'attn_bwd_dq3_kernel', 'attn_bwd_fused3_kernel')}
 # kernels whose accumulators are written by inline-asm MFMAs the compiler cannot see into: a register spill there may store an accumulator straight
 # behind the MFMA that is still writing it (happened to gemm_kernel_v3f8 once its epilogue grew) -- they must not use scratch at all
 NO_SCRATCH = {'afx_gemm.hip': ['gemm_kernel_v3f8', 'gemm_kernel_v3ILi8ELi8ELb0ELi0E', 'gemm_kernel_v3ILi8ELi7ELb0ELi0E', 'gemm_kernel_v3ILi7ELi8ELb0ELi0E',
@@ -66,12 +66,14 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def audit_asm_owned(asm_path: str, kernel_substr: str, vgpr_limit: int = 96) -> None:
+def audit_asm_owned(asm_path: str, kernel_substr: str, vgpr_limit: int = 96, *more_kernels) -> None:
     """A kernel whose registers are asm-owned (literal names in the asm text: v[vgpr_limit:255] and the whole accumulator file) must
     contain no compiler-generated instruction that touches them and no scratch access: hipcc cannot know they are in use, and
     a wrong amdgpu_num_vgpr ceiling was exceeded once (silent corruption), and past the right one hipcc spills into accumulator registers.
     Raises on a violation."""
     import re
+    for other in more_kernels:
+        audit_asm_owned(asm_path, other, vgpr_limit)
     reg = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]|\b(a)\d+\b|\b(a)\[\d+:\d+\]')
     in_kernel = in_asm = False
     seen = False

@@ -500,7 +500,8 @@ int64_t attn_bwd_ws_bytes(int B, int H, int S) {
   return 3 * (int64_t)B * H * HD * S_pad * 2 + (int64_t)B * H * S_pad * 4 + attn_bwd3_stats_bytes(B, H, S);
 }
 
-// 3 (default): the generated one-wave-per-SIMD dK / dV kernel of afx_attn_bwd3.hip (no Q / dO transposes); 2: the round-4 kernel (A/B, AFX_ATTN_BWD_IMPL=2)
+// 3 (default): the generated one-wave-per-SIMD streams of afx_attn_bwd3.hip in ONE launch (no transposed copies at all); 4: the same as two launches;
+// 2: the round-4 kernels; 1: round-4 dQ + generated dK / dV   (A/B: AFX_ATTN_BWD_IMPL)
 static int attn_bwd_impl() {
   static const int impl = [] {
     const char* e = getenv("AFX_ATTN_BWD_IMPL");
@@ -520,10 +521,17 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
   uint16_t* dot = qt + tsz;
   float* delta = (float*)(dot + tsz);
   float* stats = delta + (int64_t)B * H * S_pad;
-  const bool v3 = attn_bwd_impl() != 2 && S_pad / 32 >= 4;
+  const int impl = S_pad / 32 >= 4 ? attn_bwd_impl() : 2;
+  const bool dkv3 = impl != 2, dq3 = impl == 3 || impl == 4;
   hipError_t e;
+  if (dq3) {           // L | delta side array, then the two generated kernels: nothing else
+    if ((e = launch_attn_bwd_stats(o, ldo, dout, lddo, lse, stats, nullptr, B, H, S, stream)) != hipSuccess) return e;
+    if (impl == 3) return launch_attn_bwd_fused3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dq, lddq, dk, lddk, dv, lddv, B, H, S, stream);
+    if ((e = launch_attn_bwd_dq3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dq, lddq, B, H, S, stream)) != hipSuccess) return e;
+    return launch_attn_bwd_dkv3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dk, lddk, dv, lddv, B, H, S, stream);
+  }
   if ((e = launch_v_transpose(k, ldk, kt, B, H, S, stream)) != hipSuccess) return e;
-  if (v3) {
+  if (dkv3) {
     if ((e = launch_attn_bwd_stats(o, ldo, dout, lddo, lse, stats, delta, B, H, S, stream)) != hipSuccess) return e;
   } else {
     if ((e = hipMemsetAsync(delta, 0, (size_t)B * H * S_pad * 4, stream)) != hipSuccess) return e;
@@ -545,7 +553,7 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
   const int nq = (S + DQ_WAVES * 32 - 1) / (DQ_WAVES * 32);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(8 * hpx * nq * B), dim3(DQ_THREADS), 2 * DQ_STAGE, stream, q, ldq, k, ldk, v,
                      ldv, kt, dout, lddo, lse, delta, dq, lddq, H, S, S_pad, nq, B);
-  if (v3) return launch_attn_bwd_dkv3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dk, lddk, dv, lddv, B, H, S, stream);
+  if (dkv3) return launch_attn_bwd_dkv3(q, ldq, k, ldk, v, ldv, dout, lddo, stats, dk, lddk, dv, lddv, B, H, S, stream);
   const int nk = (S + DKV_WAVES * 32 - 1) / (DKV_WAVES * 32);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(8 * hpx * nk * B), dim3(DKV_THREADS), 2 * DKV_STAGE, stream, q, ldq, k, ldk,
                      v, ldv, qt, dout, lddo, dot, lse, delta, dk, lddk, dv, lddv, H, S, S_pad, nk, B);

@@ -140,6 +140,11 @@ hipError_t launch_attn_bwd_stats(const uint16_t* o, int64_t ldo, const uint16_t*
 hipError_t launch_attn_bwd_dkv3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, const uint16_t* dout,
                                 int64_t lddo, const float* stats, uint16_t* dk, int64_t lddk, uint16_t* dv, int64_t lddv, int B, int H, int S,
                                 hipStream_t stream);
+hipError_t launch_attn_bwd_dq3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, const uint16_t* dout,
+                               int64_t lddo, const float* stats, uint16_t* dq, int64_t lddq, int B, int H, int S, hipStream_t stream);
+hipError_t launch_attn_bwd_fused3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, const uint16_t* dout,
+                                  int64_t lddo, const float* stats, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk, uint16_t* dv, int64_t lddv, int B,
+                                  int H, int S, hipStream_t stream);
 hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
                                      int64_t ldv, const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo,
                                      const float* lse, uint16_t* dq, int64_t lddq, uint16_t* dk, int64_t lddk,

@@ -183,7 +183,7 @@ def test_adamw_ema_sumsq_cast(ops):
     close(ops.cast_bf16(p).float(), p.cpu().bfloat16().float(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2)])
+@pytest.mark.parametrize('B,S,H', [(1, 64, 1), (2, 200, 2), (1, 333, 3), (1, 1024, 2), (2, 128, 1), (1, 97, 9), (1, 1500, 2), (1, 4608, 1)])
 def test_attention_backward(ops, B, S, H):
     g = torch.Generator().manual_seed(S + 1)
     q, k, v, do = (torch.randn(B, S, H, 128, generator=g).bfloat16() for _ in range(4))
@@ -204,6 +204,30 @@ def test_attention_backward(ops, B, S, H):
     assert rel(dv, vr.grad) < 1.5e-2, rel(dv, vr.grad)
     assert rel(dq, qr.grad) < 2e-2, rel(dq, qr.grad)
     assert rel(dk, kr.grad) < 2e-2, rel(dk, kr.grad)
+    for t in (dq, dk, dv):
+        assert torch.isfinite(t.float()).all()
+
+
+def test_attention_backward_strided_views_and_determinism(ops):
+    """The training trunk hands the backward row-strided views (q | k | v columns of one [rows, 3 H 128] stash, gradients into a second one); the generated
+    kernels (afx_attn_bwd3.hip) read them through LDS-DMA with the caller's strides.  Same numbers as the contiguous call, bit for bit, and twice the same
+    (no atomics anywhere in the backward)."""
+    B, S, H = 2, 333, 2
+    g = torch.Generator().manual_seed(11)
+    q, k, v, do = (torch.randn(B, S, H, 128, generator=g).bfloat16().cuda() for _ in range(4))
+    o, lse = ops.attention_fwd_lse(q, k, v)
+    ref = ops.attention_bwd(q, k, v, o.reshape(B, S, H, 128), do, lse)
+    D = H * 128
+    stash = torch.zeros(B * S, 3 * D + 64, dtype=torch.bfloat16, device='cuda')
+    stash[:, :D], stash[:, D:2 * D], stash[:, 2 * D:3 * D] = q.reshape(B * S, D), k.reshape(B * S, D), v.reshape(B * S, D)
+    gbuf = torch.full((B * S, 3 * D), 7.0, dtype=torch.bfloat16, device='cuda')
+    dov = torch.zeros(B * S, D + 8, dtype=torch.bfloat16, device='cuda')
+    dov[:, :D] = do.reshape(B * S, D)
+    for _ in range(2):
+        ops.attention_bwd_2d(stash[:, :D], stash[:, D:2 * D], stash[:, 2 * D:3 * D], o.reshape(B * S, D), dov[:, :D], lse, gbuf[:, :D], gbuf[:, D:2 * D],
+                             gbuf[:, 2 * D:], B, S, H)
+        for i, r in enumerate(ref):
+            assert torch.equal(gbuf[:, i * D:(i + 1) * D], r.reshape(B * S, D)), i
 
 
 def test_elementwise_backward_kernels(ops):

@@ -2,7 +2,7 @@
 """Generator of the instruction stream of the key-stationary dK / dV kernel (arcflow_amd/csrc/afx_attn_bwd3.hip, round 5).
 
 Same method as tools/gen_attn3.py (the forward): one wave per SIMD, every instruction of the loop its own `asm volatile` statement (source
-order = issue order), every wide operand ASM-OWNED (literal register names; `amdgpu_num_vgpr(64)` confines hipcc to v[0:63], arcflow_amd/build.py
+order = issue order), every wide operand ASM-OWNED (literal register names; `amdgpu_num_vgpr(60)` confines hipcc to v[0:59], arcflow_amd/build.py
 audits the ISA).  A wave owns 32 keys (lane = key); the queries stream by in HALVES of 32 (two per 64-query tile):
 
     accumulator file   a[  0: 63]  dV^T accumulators  DVA[d]      = a[16 d ..+15]          (d = 32-column block of the head dim)
@@ -10,7 +10,7 @@ audits the ISA).  A wave owns 32 keys (lane = key); the queries stream by in HAL
                        a[128:159]  K fragments        KF[s]       = a[128 + 4 s ..+3]      (stationary B operands, s = 16-wide k-step of d)
                        a[160:191]  V fragments        VF[s]       = a[160 + 4 s ..+3]
                        a[192:255]  row fragments      RQ[s] / RO[s] = a[192 + 4 s ..] / a[224 + 4 s ..]   (Q / dO rows of the half: A operands of S, dP)
-    arch VGPRs         v[  0: 63]  hipcc's: LDS / DMA addresses, loop control
+    arch VGPRs         v[  0: 59]  hipcc's: LDS addresses, loop control          v[60:63]  per-lane source offsets of the four DMA pieces (B3_SETX)
                        v[ 64:127]  S / dP             SS[set] = v[64 + 32 set ..+15], DP[set] = v[80 + 32 set ..+15]   (set = half & 1)
                        v[128:191]  transposed fragments TO[i] = v[128 + 4 i ..+3] (dO^T), TQ[i] = v[160 + 4 i ..+3] (Q^T), i = 4 ksub + d
                        v[192:223]  P / dS words       PW[set][ksub] = v[192 + 16 set + 4 ksub ..+3], DW[set][ksub] = v[200 + 16 set + 4 ksub ..+3]
@@ -28,12 +28,18 @@ phases too (which only drop MFMAs / VALU work whose inputs do not exist yet).
 LDS half-slot (16640 bytes): Q [4 d-blocks][32 rows][64 B] | dO (same) | L[32] | delta[32].  Inside a 64-byte row the 16-byte chunk c sits at
 c ^ ((row >> 2) & 3): a ds_read_b128 of 16 consecutive rows and a transpose read of 4 rows x 64 bytes both touch every bank once.
 
-Writes arcflow_amd/csrc/gen/b3_*.inc (committed; the build does not run this script).  Usage: python tools/gen_attn_bwd3.py
+--mode dq: the QUERY-stationary dQ kernel is the same stream with the tensors' roles swapped (lane = query; K / V halves stream by):
+    SD(p): S^T = K Q^T, dP^T = V dO^T (A = K / V rows, B = the wave's Q / dO rows, stationary in a[128:191])
+    SM(p-1): dS^T = P^T (dP^T - delta) only (L and delta are per LANE: v224 / v240, loaded once)       DV(p-2): dQ^T += K^T dS^T (8 MFMAs, A = transpose reads of the K half)
+24 MFMAs, 72 VALU, 32 LDS reads and 4 DMA pieces per phase; half-slot = K | V = 16384 bytes; files q3_*.inc.
+
+Writes arcflow_amd/csrc/gen/b3_*.inc / q3_*.inc (committed; the build does not run this script).  Usage: python tools/gen_attn_bwd3.py [--mode dq]
 """
 import argparse
 import os
 
 SLOT = 16640
+MODE = 'dkv'            # 'dq': see the header
 X_DO = 8192
 STAT = 16384
 NSLOT = 8
@@ -167,6 +173,10 @@ def sd(st, m):
 
 def dv(st, n):
     """MFMA n = 0..15 of dV^T += dO^T P (even) / dK^T += Q^T dS (odd): ksub = n >> 3, d = (n >> 1) & 3 (an accumulator comes back after 8 MFMAs)"""
+    if MODE == 'dq':         # n = 0..7: dQ^T[d] += K^T(ks, d) dS^T(ks)
+        ks, d = n >> 2, n & 3
+        lo = T_lo(1, 4 * ks + d)
+        return asm(f'{MFMA} {DVA(d)}, {rng("v", lo, 4)}, {DW(st, ks)}, {DVA(d)}'), regs_of('v', lo, 4)
     ks, d, which = n >> 3, (n >> 1) & 3, n & 1
     lo = T_lo(which, 4 * ks + d)
     if which == 0:
@@ -192,7 +202,10 @@ def read_row(lds, m, slot, extra=None):
 def read_tr(lds, k, slot, extra=None):
     """transpose read k = 0..31: fragment of DV MFMA n = k >> 1, half rd = k & 1 (rows 16 ksub + 8 rd + 4 hi + 0..3 of the half)"""
     n, rd = k >> 1, k & 1
-    ks, d, which = n >> 3, (n >> 1) & 3, n & 1
+    if MODE == 'dq':
+        ks, d, which = n >> 2, n & 3, 1          # K^T fragments: the K half sits first in the slot (as Q in the dK / dV kernel)
+    else:
+        ks, d, which = n >> 3, (n >> 1) & 3, n & 1
     lo = T_lo(which, 4 * ks + d) + 2 * rd
     off = (X_DO if which == 0 else 0) + d * 2048 + 16 * ks * 64          # (the + 8 rows of rd = 1 sit in taddr1*: the 16-bit offset field)
     lds.read(regs_of('v', lo, 2))
@@ -210,9 +223,10 @@ def read_stat(lds, which, g, slot):
 
 def dma(piece, slot):
     # (s_add_u32 writes SCC: without the clobber hipcc keeps a loop-exit compare alive across the statement)
-    if piece < 4:
-        return asm(f's_add_u32 m0, %0, {slot * SLOT + piece * 2048}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 %1, %2', '',
-                   f'"s"(wave_lds), "v"(xofs{piece}), "s"(xsrc)', '"memory", "scc"')
+    if piece < 4 or MODE == 'dq':
+        # (the per-lane source offsets of the four pieces are asm-owned too: v60..v63, set by B3_SETX -- as C++ values hipcc copied the set every phase)
+        return asm(f's_add_u32 m0, %0, {slot * SLOT + piece * 2048}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 v{60 + piece}, %1', '',
+                   '"s"(wave_lds), "s"(xsrc)', '"memory", "scc"')
     return asm(f's_add_u32 m0, %0, {slot * SLOT + STAT}\\n\\ts_nop 0\\n\\tglobal_load_lds_dword %1, %2', '', '"s"(lds0), "v"(sofs), "s"(ssrc)',
                '"memory", "scc"')
 
@@ -222,19 +236,21 @@ def sm_ops(st):
     """(text, registers read that come from LDS, stage).  Stage k: A_k  S = S c - L;  C_k  dP = dP - delta;  B_(k-1)  S = exp2(S);  D_(k-3)  dP = S dP;
     E  words of pairs (k - 4, k - 3).  A v_exp_f32 result is never read by the next instruction (trans -> VALU wait state)."""
     ops = []
+    dq = MODE == 'dq'
     for k in range(16 + 3):
         if k < 16:
-            ops.append((f'v_fma_f32 {SSx(st, k)}, {SSx(st, k)}, %0, -{Lx(k)}', [Lx(k)], k, True))
-            ops.append((f'v_sub_f32 {DPx(st, k)}, {DPx(st, k)}, {Dx(k)}', [Dx(k)], k, False))
+            ops.append((f'v_fma_f32 {SSx(st, k)}, {SSx(st, k)}, %0, -{Lx(0 if dq else k)}', [] if dq else [Lx(k)], k, True))
+            ops.append((f'v_sub_f32 {DPx(st, k)}, {DPx(st, k)}, {Dx(0 if dq else k)}', [] if dq else [Dx(k)], k, False))
         if 0 <= k - 1 < 16:
             ops.append((f'v_exp_f32 {SSx(st, k - 1)}, {SSx(st, k - 1)}', [], k, False))
         if 0 <= k - 3 < 16:
             i = k - 3
             ops.append((f'v_mul_f32 {DPx(st, i)}, {SSx(st, i)}, {DPx(st, i)}', [], k, False))
             if i & 1:
-                ops.append((f'v_cvt_pk_bf16_f32 {PWx(st, i >> 1)}, {SSx(st, i - 1)}, {SSx(st, i)}', [], k, False))
+                if not dq:
+                    ops.append((f'v_cvt_pk_bf16_f32 {PWx(st, i >> 1)}, {SSx(st, i - 1)}, {SSx(st, i)}', [], k, False))
                 ops.append((f'v_cvt_pk_bf16_f32 {DWx(st, i >> 1)}, {DPx(st, i - 1)}, {DPx(st, i)}', [], k, False))
-    assert len(ops) == 80
+    assert len(ops) == (72 if dq else 80)
     if 'novalu' in ABL:
         ops = []
     return ops
@@ -251,90 +267,118 @@ def emit_valu(lds, op):
 VALU_PER_GAP = 3
 
 
+def slot_bytes():
+    return 16384 if MODE == 'dq' else SLOT
+
+
+def pieces():
+    return 4 if MODE == 'dq' else 5
+
+
 def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
     """half-step p with ring slot J = p % 8 (set = J & 1).  The C++ around it provides xsrc / ssrc / xofs0..3 (DMA of half p + 5)."""
     st = J & 1
+    dq = MODE == 'dq'
+    ngap = 24 if dq else 32
     lds.new_phase()
     out = [f'// ---- phase J = {J}: SD(p){"" if do_sd else " [off]"} | SM(p-1){"" if do_sm else " [off]"} | DV(p-2){"" if do_dv else " [off]"}']
     # everything but the last three phases' DMA pieces has landed (half p + 1 was issued in phase p - 4); the barrier makes it everybody's pieces and
     # says every wave is done with phase p - 1 (slot (J + 5) % 8 = half p - 3: last read there)
-    out.append(wait('s_waitcnt vmcnt(15)', own=True))
+    if trace is not None:
+        out.append(f'B3_TR({trace}, 0)')
+    out.append(wait(f's_waitcnt vmcnt({3 * pieces()})', own=True))
     out.append(wait('s_barrier'))
+    if trace is not None:
+        out.append(f'B3_TR({trace}, 1)')
+    if dq and do_sm:
+        # ragged key range: the scores of the keys past S (clamped copies of the last K row) -> -inf before the half's softmax gradient reads them (cold)
+        out.append(f'if (__builtin_expect(ragged && p - 1 >= NH - 2, 0)) {{ const int kb_ = 32 * (p - 1); B3_MASK_S{1 - st} }}')
     sm = sm_ops(1 - st) if do_sm else []
-    # gap in which the last instruction of stage 4 g + 3 (the last reader of L / delta group g) is issued
-    pos, stage_gap = 0, {}
-    for gap in range(32):
-        for op in sm[pos:pos + VALU_PER_GAP]:
-            stage_gap[op[2]] = gap
-        pos += VALU_PER_GAP
-    free_after = [stage_gap.get(4 * g + 3, -1) for g in range(4)]          # group g's registers may be overwritten from the NEXT gap on
-    stat_plan = {}                                                          # gap -> [(which, g)]
-    gap = 16
-    for g in range(4):
-        for which in range(2):
-            gap = max(gap, free_after[g] + 1)
-            assert gap < 32, 'no room for the L / delta reads'
-            stat_plan.setdefault(gap, []).append((which, g))
-            gap += 1
-    dma_gaps = {17: 0, 20: 1, 23: 2, 26: 3, 29: 4}
+    mem = {g: [] for g in range(ngap)}                                       # gap -> memory instructions (callables: they register with the queue model in issue order)
+    if dq:
+        for g in range(16):                                                 # 16 transpose reads of K(p - 2); row read m of half p + 1 two gaps behind the MFMA that read the old fragment
+            mem[g].append(lambda g=g: read_tr(lds, g, (J + 6) % NSLOT))
+        for m in range(16):
+            mem[m + 2].append(lambda m=m: read_row(lds, m, (J + 1) % NSLOT))
+        dma_gaps = {17: 0, 19: 1, 21: 2, 23: 3}
+    else:
+        # gap in which the last instruction of stage 4 g + 3 (the last reader of L / delta group g) is issued
+        pos, stage_gap = 0, {}
+        for gap in range(ngap):
+            for op in sm[pos:pos + VALU_PER_GAP]:
+                stage_gap[op[2]] = gap
+            pos += VALU_PER_GAP
+        free_after = [stage_gap.get(4 * g + 3, -1) for g in range(4)]      # group g's registers may be overwritten from the NEXT gap on
+        for g in range(16):
+            mem[g].append(lambda g=g: read_tr(lds, 2 * g, (J + 6) % NSLOT))
+            mem[g].append(lambda g=g: read_tr(lds, 2 * g + 1, (J + 6) % NSLOT))
+            mem[16 + g].append(lambda g=g: read_row(lds, g, (J + 1) % NSLOT))
+        gap = 16
+        for g in range(4):
+            for which in range(2):
+                gap = max(gap, free_after[g] + 1)
+                assert gap < ngap, 'no room for the L / delta reads'
+                mem[gap].append(lambda which=which, g=g: read_stat(lds, which, g, J))
+                gap += 1
+        dma_gaps = {17: 0, 20: 1, 23: 2, 26: 3, 29: 4}
     k = 0
-    for gap in range(32):
+    for gap in range(ngap):
         if gap < 16:
             if do_sd:
                 text, regs = sd(st, gap)
                 out += lds.need(regs)
                 out.append(text)
-            if 'nolds' not in ABL:
-                out.append(read_tr(lds, 2 * gap, (J + 6) % NSLOT))
-                out.append(read_tr(lds, 2 * gap + 1, (J + 6) % NSLOT))
-        else:
-            if do_dv:
-                text, regs = dv(st, gap - 16)
-                out += lds.need(regs)
-                out.append(text)
-            if 'nolds' not in ABL:
-                out.append(read_row(lds, gap - 16, (J + 1) % NSLOT))
-                for which, g in stat_plan.get(gap, []):
-                    out.append(read_stat(lds, which, g, J))
-            if gap in dma_gaps and 'nodma' not in ABL:
-                out.append(dma(dma_gaps[gap], (J + 5) % NSLOT))
+        elif do_dv:
+            text, regs = dv(st, gap - 16)
+            out += lds.need(regs)
+            out.append(text)
+        if 'nolds' not in ABL:
+            out += [f() for f in mem[gap]]
+        if gap in dma_gaps and 'nodma' not in ABL:
+            out.append(dma(dma_gaps[gap], (J + 5) % NSLOT))
         for op in sm[k:k + VALU_PER_GAP]:
             out += emit_valu(lds, op)
         k += VALU_PER_GAP
         if trace is not None and gap == 15:
-            out.append(f'B3_TR({trace})')
+            out.append(f'B3_TR({trace}, 2)')
     assert k >= len(sm)
     return out
 
 
 # ---- blocks ------------------------------------------------------------------------------------------------------------------------------------
+HDR = '// generated by tools/gen_attn_bwd3.py'
+
+
 def init():
-    out = ['// generated by tools/gen_attn_bwd3.py -- dV^T = dK^T = 0']
-    for lo in range(0, 128, 16):
+    out = [f'{HDR} -- accumulators = 0']
+    for lo in range(0, 64 if MODE == 'dq' else 128, 16):
         out.append(asm('\\n\\t'.join(f'v_accvgpr_write_b32 a{lo + r}, 0' for r in range(16)), '', '', '"v255", "a255"' if lo == 0 else ''))
     return out
 
 
 def kv_loads():
-    out = ['// generated by tools/gen_attn_bwd3.py -- the wave\'s K / V rows straight into the accumulator file (stationary B operands); waited for by hand']
+    out = [f'{HDR} -- the wave\'s stationary rows (K / V; dq mode: Q / dO) straight into the accumulator file (B operands); waited for by hand']
     for s in range(8):
         out.append(asm(f'global_load_dwordx4 {KF(s)}, %0, off offset:{s * 32}', '', '"v"(kptr)', '"memory"'))
         out.append(asm(f'global_load_dwordx4 {VF(s)}, %0, off offset:{s * 32}', '', '"v"(vptr)', '"memory"'))
+    if MODE == 'dq':         # L and delta of the lane's query (padded side array: +inf | 0 past S)
+        out.append(asm(f'global_load_dword {Lx(0)}, %0, off', '', '"v"(lptr)', '"memory"'))
+        out.append(asm(f'global_load_dword {Dx(0)}, %0, off offset:128', '', '"v"(lptr)', '"memory"'))
     return out
 
 
 def prologue_dma():
-    out = ['// generated by tools/gen_attn_bwd3.py -- halves 0..4 -> slots 0..4 (5 pieces each: the order the counted waits assume)']
+    out = [f'{HDR} -- halves 0..4 -> slots 0..4 ({pieces()} pieces each: the order the counted waits assume)']
     for u in range(5):
-        out.append(f'{{ B3_SRC({u})')
-        out += [dma(i, u) for i in range(5)]
+        out.append(f'{{ B3_SRC({u}) B3_SETX(xofs0, xofs1, xofs2, xofs3)')
+        out += [dma(i, u) for i in range(pieces())]
         out.append('}')
     return out
 
 
 def first_rows(lds):
-    out = ['// generated by tools/gen_attn_bwd3.py -- 16 K / V loads + 25 DMA pieces in flight: K, V and half 0 have landed when <= 20 remain']
-    out.append(wait('s_waitcnt vmcnt(20)', own=True))
+    out = [f'{HDR} -- the stationary rows\' loads + 5 halves of DMA pieces in flight: everything up to half 0 has landed when only halves 1..4 remain']
+    out.append(wait(f's_waitcnt vmcnt({4 * pieces()})', own=True))
     out.append(wait('s_barrier'))
     out += [read_row(lds, m, 0) for m in range(16)]
     out.append(wait('s_waitcnt lgkmcnt(0)'))
@@ -344,53 +388,72 @@ def first_rows(lds):
 def tail(lds, which):
     """the two draining phases (runtime ring slot through `ts`, a byte offset added to the ring-0 addresses): not pipelined.
     which 0: p = NH:     SM(NH - 1), DV(NH - 2)       which 1: p = NH + 1: DV(NH - 1)"""
-    out = [f'// generated by tools/gen_attn_bwd3.py -- draining phase {which} (set = {which}: NH is even)']
+    out = [f'{HDR} -- draining phase {which} (set = {which}: NH is even)']
     st = which                                   # p = NH + which, set = p & 1
-    out += [read_tr(lds, k, 0, 'ts') for k in range(32)]
+    out += [read_tr(lds, k, 0, 'ts') for k in range(16 if MODE == 'dq' else 32)]
     if which == 0:
         lds.new_phase()
+        if MODE == 'dq':
+            out.append(f'if (ragged) {{ const int kb_ = 32 * (NH - 1); B3_MASK_S{1 - st} }}')
         for op in sm_ops(1 - st):
             out += emit_valu(lds, op)
     out.append(wait('s_waitcnt lgkmcnt(0)\\n\\ts_nop 3'))
-    out += [dv(st, n)[0] for n in range(16)]
+    out += [dv(st, n)[0] for n in range(8 if MODE == 'dq' else 16)]
     return out
 
 
+def mask_ops(st):
+    """dq mode, ragged key range (cold): S^T register r of a lane holds key 32 half + (r & 3) + 8 (r >> 2) + 4 hi (the MFMA D layout); kb_ = 32 half."""
+    lines = [f'#define B3_MASK_S{st} \\']
+    for r in range(16):
+        key = (r & 3) + 8 * (r >> 2)
+        lines.append(f'  {{ const float pen_ = kb_ + {key} + 4 * hi >= S ? -INFINITY : 0.f; asm volatile("v_add_f32 {SSx(st, r)}, {SSx(st, r)}, %0" : : "v"(pen_)); }} \\')
+    lines.append('  asm volatile("s_nop 1");')
+    return lines
+
+
 def readout():
-    out = ['// generated by tools/gen_attn_bwd3.py -- epilogue: one [32 d][32 keys] accumulator tile -> 16 VGPR scalars ox[0..15]']
-    out.append('#define B3_DRAIN ' + asm('s_waitcnt vmcnt(0)\\n\\ts_nop 15\\n\\ts_nop 15', '', '', '"memory"'))
-    for name, base in (('V', 0), ('K', 64)):
+    out = [f'{HDR} -- epilogue: one [32 d][32 lanes] accumulator tile -> 16 VGPR scalars ox[0..15]']
+    pre = 'Q3' if MODE == 'dq' else 'B3'
+    out.append(f'#define {pre}_DRAIN ' + asm('s_waitcnt vmcnt(0)\\n\\ts_nop 15\\n\\ts_nop 15', '', '', '"memory"'))
+    for name, base in ((('Q', 0),) if MODE == 'dq' else (('V', 0), ('K', 64))):
         for d in range(4):
             lo = base + 16 * d
             text = '\\n\\t'.join(f'v_accvgpr_read_b32 %{r}, a{lo + r}' for r in range(16))
             outs = ', '.join(f'"=v"(ox[{r}])' for r in range(16))
-            out.append(f'#define B3_READ_{name}_{d} ' + asm(text, outs, ''))
+            out.append(f'#define {pre}_READ_{name}_{d} ' + asm(text, outs, ''))
     return out
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--mode', default='dkv', choices=['dkv', 'dq'])
     ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn_bwd3.hip includes B3_GEN/..., default gen)')
     ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu: timing experiments, WRONG results')
     ap.add_argument('--valu-per-gap', type=int, default=3)
     a = ap.parse_args()
     ABL.update(x for x in a.ablate.split(',') if x)
-    global VALU_PER_GAP
+    global VALU_PER_GAP, MODE, SLOT
     VALU_PER_GAP = a.valu_per_gap
+    MODE = a.mode
+    SLOT = slot_bytes()
+    px = 'q3' if MODE == 'dq' else 'b3'
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'arcflow_amd', 'csrc', a.out)
     os.makedirs(root, exist_ok=True)
-    files = {'b3_init.inc': init(), 'b3_kvload.inc': kv_loads(), 'b3_prologue_dma.inc': prologue_dma(), 'b3_readout.inc': readout()}
+    files = {f'{px}_init.inc': init(), f'{px}_kvload.inc': kv_loads(), f'{px}_prologue_dma.inc': prologue_dma(), f'{px}_readout.inc': readout()}
+    if MODE == 'dq':
+        files[f'{px}_mask.inc'] = mask_ops(0) + mask_ops(1)
     lds = Lds()
-    files['b3_first_rows.inc'] = first_rows(lds)
-    files['b3_p0.inc'] = ['// generated by tools/gen_attn_bwd3.py -- p = 0 (slot 0): SD(0) only'] + phase(lds, 0, True, False, False)
-    files['b3_p1.inc'] = ['// generated by tools/gen_attn_bwd3.py -- p = 1 (slot 1): SD(1), SM(0)'] + phase(lds, 1, True, True, False)
+    files[f'{px}_first_rows.inc'] = first_rows(lds)
+    files[f'{px}_p0.inc'] = [f'{HDR} -- p = 0 (slot 0): SD(0) only'] + phase(lds, 0, True, False, False)
+    files[f'{px}_p1.inc'] = [f'{HDR} -- p = 1 (slot 1): SD(1), SM(0)'] + phase(lds, 1, True, True, False)
     # steady state: the loop enters at J = 2 and walks 2, 3, ..., 7, 0, 1; every phase issues the same LDS sequence, so one running queue model serves
     for J in (2, 3, 4, 5, 6, 7, 0, 1):
-        files[f'b3_body{J}.inc'] = [f'// generated by tools/gen_attn_bwd3.py -- steady-state phase, ring slot J = {J}'] + phase(lds, J, trace=J)
-    files['b3_tail0.inc'] = tail(lds, 0)
-    files['b3_tail1.inc'] = tail(lds, 1)
+        files[f'{px}_body{J}.inc'] = [f'{HDR} -- steady-state phase, ring slot J = {J}'] + phase(lds, J, trace=J)
+    files[f'{px}_tail0.inc'] = tail(lds, 0)
+    files[f'{px}_tail1.inc'] = tail(lds, 1)
     for f in os.listdir(root):
-        if f.startswith('b3_') and f not in files:
+        if f.startswith(px + '_') and f not in files:
             os.remove(os.path.join(root, f))
     for name, lines in files.items():
         with open(os.path.join(root, name), 'w') as f:
