@@ -13,8 +13,8 @@
 //     same read).  Half the LDS-DMA pieces and half the L2 traffic per tile, and the three transpose passes per call are gone.
 //   * the streams are GENERATED (tools/gen_attn_bwd3.py -> gen/b3_*.inc, gen/q3_*.inc, committed): every instruction its own asm statement, every wide
 //     operand asm-owned (register map in the generator's header), hipcc confined to v[0:63] by amdgpu_num_vgpr(64), ISA audited by arcflow_amd/build.py.
-//     Per 32 MFMAs the dK / dV wave issues 80 VALU instructions (the round-4 kernel: ~245, two thirds of them address arithmetic, accumulator-file moves and
-//     register shuffles the compiler added), 56 LDS reads and 5 DMA pieces; the dQ wave 72 / 32 / 4 per 24 MFMAs.
+//     Per 32 MFMAs the dK / dV wave issues 64 VALU instructions (the round-4 kernel: ~245, two thirds of them address arithmetic, accumulator-file moves and
+//     register shuffles the compiler added), 56 LDS reads and 5 DMA pieces; the dQ wave 56 / 32 / 4 per 24 MFMAs.
 //   * software pipeline over HALVES of 32 streamed rows (phase p: S / dP of half p | softmax gradient of half p - 1 | accumulating products of half p - 2),
 //     an 8-slot LDS ring of half tiles fed three phases ahead, one counted `s_waitcnt vmcnt` + barrier per phase.
 //   * L and delta come from ONE padded side array (attn_bwd_stats_kernel below: rows past S carry L = +inf, delta = 0, so that the clamped copies of the
@@ -53,7 +53,7 @@ AFX_DEV uint64_t uniform_u64(uint64_t v) {
 __device__ unsigned g_bwd3_trace[2 * 2 * 4 * 32];
 #endif
 
-// stats[(b H + h)][half u][64] = L of the half's 32 queries | their delta = sum_d dO O; rows past S: +inf | 0.  One 16-lane group per (row, head).
+// stats[(b H + h)][half u][64] = L of the half's 32 queries | MINUS their delta = -sum_d dO O (the dP MFMA chains start from it); rows past S: +inf | 0.  One 16-lane group per (row, head).
 __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const bf16_t* __restrict__ o, int64_t ldo, const bf16_t* __restrict__ dout, int64_t lddo,
                                                             const float* __restrict__ lse, float* __restrict__ stats, float* __restrict__ delta_old,
                                                             int H, int S, int S_pad, int64_t total) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void attn_bwd_stats_kernel(const bf16_t* __res
   for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   if (c == 0) {
     dst[0] = lse[(bb * H + h) * S_pad + ss];
-    dst[32] = s;
+    dst[32] = -s;
     if (delta_old != nullptr) delta_old[(bb * H + h) * S_pad + ss] = s;
   }
 }

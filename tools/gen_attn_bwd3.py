@@ -19,8 +19,9 @@ audits the ISA).  A wave owns 32 keys (lane = key); the queries stream by in HAL
 One PHASE = 32 MFMAs = one half-step p of the software pipeline (J = p % 8 = the half's ring slot; set = p & 1):
     MFMA   SD(p):   S(p) = Q(p) K^T, dP(p) = dO(p) V^T          (16, A = row fragments read in phase p - 1)
            DV(p-2): dV^T += dO^T(p-2) P(p-2), dK^T += Q^T(p-2) dS(p-2)   (16, A = ds_read_b64_tr_b16 fragments read in this phase's first half)
-    VALU   SM(p-1): P = exp2(S c - L), dS = P (dP - delta), both rounded to bf16 words (80 instructions, in place in the S / dP registers)
-    LDS    32 transpose reads of half p - 2 (gaps 0-15), 16 row reads of half p + 1 + 8 L / delta reads of half p (gaps 16-31)
+    VALU   SM(p-1): P = exp2(S c - L), dS = P dP', both rounded to bf16 words (64 instructions, in place in the S / dP registers); dP' = dP - delta comes out of
+                    the MFMA chain itself: the chain's C operand is the half's -delta, read from LDS straight into the accumulator's registers
+    LDS    32 transpose reads of half p - 2 (gaps 0-15), 16 row reads of half p + 1, 4 L reads of half p, 4 -delta reads of half p + 1 (gaps 16-31)
     DMA    half p + 5 -> slot (J + 5) % 8: 4 pieces of the wave's tensor (waves 0, 1: Q rows 0-15 / 16-31, waves 2, 3: dO) + the 256-byte L | delta block
 Every phase issues the SAME sequence of LDS reads and DMA pieces, so the counted waits (lgkmcnt / vmcnt) hold in the peeled first and last
 phases too (which only drop MFMAs / VALU work whose inputs do not exist yet).
@@ -30,8 +31,8 @@ c ^ ((row >> 2) & 3): a ds_read_b128 of 16 consecutive rows and a transpose read
 
 --mode dq: the QUERY-stationary dQ kernel is the same stream with the tensors' roles swapped (lane = query; K / V halves stream by):
     SD(p): S^T = K Q^T, dP^T = V dO^T (A = K / V rows, B = the wave's Q / dO rows, stationary in a[128:191])
-    SM(p-1): dS^T = P^T (dP^T - delta) only (L and delta are per LANE: v224 / v240, loaded once)       DV(p-2): dQ^T += K^T dS^T (8 MFMAs, A = transpose reads of the K half)
-24 MFMAs, 72 VALU, 32 LDS reads and 4 DMA pieces per phase; half-slot = K | V = 16384 bytes; files q3_*.inc.
+    SM(p-1): dS^T = P^T dP'^T only (L and -delta are per LANE: v224, and v[144:159] = 16 copies of -delta as the dP^T chain's C operand)       DV(p-2): dQ^T += K^T dS^T (8 MFMAs, A = transpose reads of the K half)
+24 MFMAs, 56 VALU, 32 LDS reads and 4 DMA pieces per phase; half-slot = K | V = 16384 bytes; files q3_*.inc.
 
 Writes arcflow_amd/csrc/gen/b3_*.inc / q3_*.inc (committed; the build does not run this script).  Usage: python tools/gen_attn_bwd3.py [--mode dq]
 """
@@ -167,7 +168,11 @@ def sd(st, m):
     """MFMA m = 0..15 of S = Q K^T (even) / dP = dO V^T (odd), k-step s = m >> 1"""
     s = m >> 1
     if m & 1:
-        return asm(f'{MFMA} {DP(st)}, {RO(s)}, {VF(s)}, {0 if s == 0 else DP(st)}'), regs_of('a', 224 + 4 * s, 4)
+        # the dP chain starts from -delta instead of 0 (dP - delta for free): the dQ stream keeps the lane's -delta in a constant 16-register block,
+        # the dK / dV stream reads the half's -delta straight into the accumulator's registers (read_negdelta)
+        c0 = NEGD if MODE == 'dq' else DP(st)
+        regs = regs_of('a', 224 + 4 * s, 4) + (regs_of('v', 80 + 32 * st, 16) if s == 0 and MODE != 'dq' else [])
+        return asm(f'{MFMA} {DP(st)}, {RO(s)}, {VF(s)}, {c0 if s == 0 else DP(st)}'), regs
     return asm(f'{MFMA} {SS(st)}, {RQ(s)}, {KF(s)}, {0 if s == 0 else SS(st)}'), regs_of('a', 192 + 4 * s, 4)
 
 
@@ -182,6 +187,9 @@ def dv(st, n):
     if which == 0:
         return asm(f'{MFMA} {DVA(d)}, {rng("v", lo, 4)}, {PW(st, ks)}, {DVA(d)}'), regs_of('v', lo, 4)
     return asm(f'{MFMA} {DKA(d)}, {rng("v", lo, 4)}, {DW(st, ks)}, {DKA(d)}'), regs_of('v', lo, 4)
+
+
+NEGD = 'v[144:159]'       # dq mode: 16 copies of the lane's -delta (C operand of the first dP^T MFMA of every half)
 
 
 def ring(slot):
@@ -221,6 +229,13 @@ def read_stat(lds, which, g, slot):
     return asm(f'ds_read_b128 {rng("v", lo, 4)}, %0 offset:{(slot & 3) * SLOT + which * 128 + 32 * g}', '', f'"v"(saddr{ring(slot)})')
 
 
+def read_negdelta(lds, g, slot, st):
+    """-delta of queries 8 g + 4 hi + 0..3 of the half in `slot` -> registers 4 g ..+3 of the dP accumulator of set st (its MFMA chain starts from them)"""
+    lo = 80 + 32 * st + 4 * g
+    lds.read(regs_of('v', lo, 4))
+    return asm(f'ds_read_b128 {rng("v", lo, 4)}, %0 offset:{(slot & 3) * SLOT + 128 + 32 * g}', '', f'"v"(saddr{ring(slot)})')
+
+
 def dma(piece, slot):
     # (s_add_u32 writes SCC: without the clobber hipcc keeps a loop-exit compare alive across the statement)
     if piece < 4 or MODE == 'dq':
@@ -233,14 +248,13 @@ def dma(piece, slot):
 
 # ---- the softmax gradient of one half as an instruction list ----------------------------------------------------------------------------
 def sm_ops(st):
-    """(text, registers read that come from LDS, stage).  Stage k: A_k  S = S c - L;  C_k  dP = dP - delta;  B_(k-1)  S = exp2(S);  D_(k-3)  dP = S dP;
+    """(text, registers read that come from LDS, stage).  Stage k: A_k  S = S c - L;  B_(k-1)  S = exp2(S);  D_(k-3)  dP = S dP  (dP arrives as dP - delta: see sd());
     E  words of pairs (k - 4, k - 3).  A v_exp_f32 result is never read by the next instruction (trans -> VALU wait state)."""
     ops = []
     dq = MODE == 'dq'
     for k in range(16 + 3):
         if k < 16:
             ops.append((f'v_fma_f32 {SSx(st, k)}, {SSx(st, k)}, %0, -{Lx(0 if dq else k)}', [] if dq else [Lx(k)], k, True))
-            ops.append((f'v_sub_f32 {DPx(st, k)}, {DPx(st, k)}, {Dx(0 if dq else k)}', [] if dq else [Dx(k)], k, False))
         if 0 <= k - 1 < 16:
             ops.append((f'v_exp_f32 {SSx(st, k - 1)}, {SSx(st, k - 1)}', [], k, False))
         if 0 <= k - 3 < 16:
@@ -250,7 +264,7 @@ def sm_ops(st):
                 if not dq:
                     ops.append((f'v_cvt_pk_bf16_f32 {PWx(st, i >> 1)}, {SSx(st, i - 1)}, {SSx(st, i)}', [], k, False))
                 ops.append((f'v_cvt_pk_bf16_f32 {DWx(st, i >> 1)}, {DPx(st, i - 1)}, {DPx(st, i)}', [], k, False))
-    assert len(ops) == (72 if dq else 80)
+    assert len(ops) == (56 if dq else 64)
     if 'novalu' in ABL:
         ops = []
     return ops
@@ -265,6 +279,7 @@ def emit_valu(lds, op):
 
 # ---- one phase -------------------------------------------------------------------------------------------------------------------------------
 VALU_PER_GAP = 3
+DMA_GAPS = None           # --dma-gaps: the MFMA gaps that carry the phase's DMA pieces
 
 
 def slot_bytes():
@@ -300,13 +315,14 @@ def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
             mem[g].append(lambda g=g: read_tr(lds, g, (J + 6) % NSLOT))
         for m in range(16):
             mem[m + 2].append(lambda m=m: read_row(lds, m, (J + 1) % NSLOT))
-        dma_gaps = {17: 0, 19: 1, 21: 2, 23: 3}
+        dma_gaps = dict(zip(DMA_GAPS or (17, 19, 21, 23), range(4)))
     else:
-        # gap in which the last instruction of stage 4 g + 3 (the last reader of L / delta group g) is issued
-        pos, stage_gap = 0, {}
+        # gap in which the last instruction of stage 4 g + 3 (the last reader of L group g) is issued; the softmax gradient's last instruction
+        pos, stage_gap, last_gap = 0, {}, -1
         for gap in range(ngap):
             for op in sm[pos:pos + VALU_PER_GAP]:
                 stage_gap[op[2]] = gap
+                last_gap = gap
             pos += VALU_PER_GAP
         free_after = [stage_gap.get(4 * g + 3, -1) for g in range(4)]      # group g's registers may be overwritten from the NEXT gap on
         for g in range(16):
@@ -314,13 +330,17 @@ def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
             mem[g].append(lambda g=g: read_tr(lds, 2 * g + 1, (J + 6) % NSLOT))
             mem[16 + g].append(lambda g=g: read_row(lds, g, (J + 1) % NSLOT))
         gap = 16
+        for g in range(4):                                                  # L of half p -> v[224:239] (SM(p) runs in the next phase)
+            gap = max(gap, free_after[g] + 1)
+            assert gap < ngap, 'no room for the L reads'
+            mem[gap].append(lambda g=g: read_stat(lds, 0, g, J))
+            gap += 1
+        # -delta of half p + 1 -> the dP accumulator of set 1 - st, once SM(p - 1) is done with it (the first dP MFMA of the next phase starts from it)
+        gap = max(ngap - 4, last_gap + 1)
+        assert gap + 3 < ngap, 'no room for the -delta reads'
         for g in range(4):
-            for which in range(2):
-                gap = max(gap, free_after[g] + 1)
-                assert gap < ngap, 'no room for the L / delta reads'
-                mem[gap].append(lambda which=which, g=g: read_stat(lds, which, g, J))
-                gap += 1
-        dma_gaps = {17: 0, 20: 1, 23: 2, 26: 3, 29: 4}
+            mem[gap + g].append(lambda g=g: read_negdelta(lds, g, (J + 1) % NSLOT, 1 - st))
+        dma_gaps = dict(zip(DMA_GAPS or (17, 20, 23, 26, 29), range(5)))
     k = 0
     for gap in range(ngap):
         if gap < 16:
@@ -381,6 +401,10 @@ def first_rows(lds):
     out.append(wait(f's_waitcnt vmcnt({4 * pieces()})', own=True))
     out.append(wait('s_barrier'))
     out += [read_row(lds, m, 0) for m in range(16)]
+    if MODE == 'dq':
+        out.append(asm('\\n\\t'.join(f'v_mov_b32 v{144 + r}, {Dx(0)}' for r in range(16))))       # the constant -delta block (stats hold -delta)
+    else:
+        out += [read_negdelta(lds, g, 0, 0) for g in range(4)]
     out.append(wait('s_waitcnt lgkmcnt(0)'))
     return out
 
@@ -431,9 +455,11 @@ def main():
     ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn_bwd3.hip includes B3_GEN/..., default gen)')
     ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu: timing experiments, WRONG results')
     ap.add_argument('--valu-per-gap', type=int, default=3)
+    ap.add_argument('--dma-gaps', default='', help='comma list: the MFMA gaps of a phase that carry its DMA pieces (5 for dkv, 4 for dq)')
     a = ap.parse_args()
     ABL.update(x for x in a.ablate.split(',') if x)
-    global VALU_PER_GAP, MODE, SLOT
+    global VALU_PER_GAP, MODE, SLOT, DMA_GAPS
+    DMA_GAPS = tuple(int(x) for x in a.dma_gaps.split(',')) if a.dma_gaps else None
     VALU_PER_GAP = a.valu_per_gap
     MODE = a.mode
     SLOT = slot_bytes()
