@@ -242,6 +242,10 @@ def dma(piece, slot):
         # (the per-lane source offsets of the four pieces are asm-owned too: v60..v63, set by B3_SETX -- as C++ values hipcc copied the set every phase)
         return asm(f's_add_u32 m0, %0, {slot * SLOT + piece * 2048}\\n\\ts_nop 0\\n\\tglobal_load_lds_dwordx4 v{60 + piece}, %1', '',
                    '"s"(wave_lds), "s"(xsrc)', '"memory", "scc"')
+    if STAT1:
+        # --stat-one-wave: the 256-byte L | -delta block is one DMA instruction: wave (slot & 3) alone issues it (EXEC = 0 in the other three: the instruction is a no-op there)
+        return asm(f's_add_u32 m0, %0, {slot * SLOT + STAT}\\n\\ts_cmp_eq_u32 %3, {slot & 3}\\n\\ts_cselect_b64 exec, -1, 0\\n\\tglobal_load_lds_dword %1, %2\\n\\ts_mov_b64 exec, -1', '',
+                   '"s"(lds0), "v"(sofs), "s"(ssrc), "s"(wave)', '"memory", "scc"')
     return asm(f's_add_u32 m0, %0, {slot * SLOT + STAT}\\n\\ts_nop 0\\n\\tglobal_load_lds_dword %1, %2', '', '"s"(lds0), "v"(sofs), "s"(ssrc)',
                '"memory", "scc"')
 
@@ -280,6 +284,12 @@ def emit_valu(lds, op):
 # ---- one phase -------------------------------------------------------------------------------------------------------------------------------
 VALU_PER_GAP = 3
 DMA_GAPS = None           # --dma-gaps: the MFMA gaps that carry the phase's DMA pieces
+STAT1 = False             # --stat-one-wave: see dma()
+BAR2 = False              # --barrier-every 2: wait + barrier at even phases only; a phase then fetches half p + 4 (see phase())
+
+
+def lead():
+    return 4 if BAR2 else 5
 
 
 def slot_bytes():
@@ -288,6 +298,12 @@ def slot_bytes():
 
 def pieces():
     return 4 if MODE == 'dq' else 5
+
+
+def vm_pieces():
+    """pieces per phase the counted vmcnt waits may assume outstanding: with --stat-one-wave a wave issues 4 or 5 (or, if the hardware does not count an EXEC = 0
+    instruction, 4): waiting down to 4 per phase is safe in every case"""
+    return 4 if STAT1 else pieces()
 
 
 def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
@@ -301,8 +317,16 @@ def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
     # says every wave is done with phase p - 1 (slot (J + 5) % 8 = half p - 3: last read there)
     if trace is not None:
         out.append(f'B3_TR({trace}, 0)')
-    out.append(wait(f's_waitcnt vmcnt({3 * pieces()})', own=True))
-    out.append(wait('s_barrier'))
+    if not BAR2:
+        out.append(wait(f's_waitcnt vmcnt({3 * vm_pieces()})', own=True))
+        out.append(wait('s_barrier'))
+    elif J % 2 == 0:
+        # --barrier-every 2: at an even phase p only the pieces of phase p - 1 (half p + 3) may be in flight: halves <= p + 2 have landed, which is what phases p and
+        # p + 1 read; phase u fetches half u + 4 into the slot of half u - 4, whose last (transpose) reads were issued in phase u - 2 -- before this barrier or the last one
+        out.append(wait(f's_waitcnt vmcnt({vm_pieces()})', own=True))
+        out.append(wait('s_barrier'))
+    else:
+        out.append(wait('s_nop 0', own=True))
     if trace is not None:
         out.append(f'B3_TR({trace}, 1)')
     if dq and do_sm:
@@ -355,7 +379,7 @@ def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
         if 'nolds' not in ABL:
             out += [f() for f in mem[gap]]
         if gap in dma_gaps and 'nodma' not in ABL:
-            out.append(dma(dma_gaps[gap], (J + 5) % NSLOT))
+            out.append(dma(dma_gaps[gap], (J + lead()) % NSLOT))
         for op in sm[k:k + VALU_PER_GAP]:
             out += emit_valu(lds, op)
         k += VALU_PER_GAP
@@ -370,7 +394,7 @@ HDR = '// generated by tools/gen_attn_bwd3.py'
 
 
 def init():
-    out = [f'{HDR} -- accumulators = 0']
+    out = [f'{HDR} -- accumulators = 0; B3_LEAD: a phase fetches the half that many phases ahead', '#undef B3_LEAD', f'#define B3_LEAD {lead()}']
     for lo in range(0, 64 if MODE == 'dq' else 128, 16):
         out.append(asm('\\n\\t'.join(f'v_accvgpr_write_b32 a{lo + r}, 0' for r in range(16)), '', '', '"v255", "a255"' if lo == 0 else ''))
     return out
@@ -388,8 +412,8 @@ def kv_loads():
 
 
 def prologue_dma():
-    out = [f'{HDR} -- halves 0..4 -> slots 0..4 ({pieces()} pieces each: the order the counted waits assume)']
-    for u in range(5):
+    out = [f'{HDR} -- halves 0..{lead() - 1} -> slots 0..{lead() - 1} ({pieces()} pieces each: the order the counted waits assume)']
+    for u in range(lead()):
         out.append(f'{{ B3_SRC({u}) B3_SETX(xofs0, xofs1, xofs2, xofs3)')
         out += [dma(i, u) for i in range(pieces())]
         out.append('}')
@@ -398,7 +422,7 @@ def prologue_dma():
 
 def first_rows(lds):
     out = [f'{HDR} -- the stationary rows\' loads + 5 halves of DMA pieces in flight: everything up to half 0 has landed when only halves 1..4 remain']
-    out.append(wait(f's_waitcnt vmcnt({4 * pieces()})', own=True))
+    out.append(wait(f's_waitcnt vmcnt({(lead() - 1) * vm_pieces()})', own=True))
     out.append(wait('s_barrier'))
     out += [read_row(lds, m, 0) for m in range(16)]
     if MODE == 'dq':
@@ -455,10 +479,14 @@ def main():
     ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn_bwd3.hip includes B3_GEN/..., default gen)')
     ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu: timing experiments, WRONG results')
     ap.add_argument('--valu-per-gap', type=int, default=3)
+    ap.add_argument('--barrier-every', type=int, default=1, choices=[1, 2])
+    ap.add_argument('--stat-one-wave', action='store_true')
     ap.add_argument('--dma-gaps', default='', help='comma list: the MFMA gaps of a phase that carry its DMA pieces (5 for dkv, 4 for dq)')
     a = ap.parse_args()
     ABL.update(x for x in a.ablate.split(',') if x)
-    global VALU_PER_GAP, MODE, SLOT, DMA_GAPS
+    global VALU_PER_GAP, MODE, SLOT, DMA_GAPS, BAR2, STAT1
+    STAT1 = a.stat_one_wave
+    BAR2 = a.barrier_every == 2
     DMA_GAPS = tuple(int(x) for x in a.dma_gaps.split(',')) if a.dma_gaps else None
     VALU_PER_GAP = a.valu_per_gap
     MODE = a.mode
