@@ -1964,6 +1964,12 @@ static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
   if constexpr (!CONV) {
     if (gemm_persist() == 1 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 1>(batch, slots, stream);
     if (gemm_persist() == 2 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
+  } else {
+    // the VAE's convolutions: thousands of tiles with 18-72 K-tiles each (K = taps x channel chunks): the per-tile prologue is a large share of a tile, which
+    // is the case the persistent walk was built for (AFX_CONV_PERSIST=1|2: next tile's first DMA batches in front of / behind the epilogue; round 5 A/B)
+    static const int cp = [] { const char* e = getenv("AFX_CONV_PERSIST"); return e ? atoi(e) : 0; }();
+    if (cp == 1 && total > 2 * slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 1>(batch, slots, stream);
+    if (cp == 2 && total > 2 * slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
   }
   return launch_v3_impl<MI, NJ, CONV, 0>(batch, total, stream);
 }
