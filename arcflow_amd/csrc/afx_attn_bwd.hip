@@ -521,7 +521,7 @@ hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint1
   uint16_t* dot = qt + tsz;
   float* delta = (float*)(dot + tsz);
   float* stats = delta + (int64_t)B * H * S_pad;
-  const int impl = S_pad / 32 >= 4 ? attn_bwd_impl() : 2;
+  const int impl = attn_bwd3_eligible(q, k, v, dout, ldq, ldk, ldv, lddo, S) ? attn_bwd_impl() : 2;
   const bool dkv3 = impl != 2, dq3 = impl == 3 || impl == 4;
   hipError_t e;
   if (dq3) {           // L | delta side array, then the two generated kernels: nothing else

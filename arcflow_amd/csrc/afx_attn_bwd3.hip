@@ -144,6 +144,12 @@ hipError_t launch_attn_bwd_stats(const uint16_t* o, int64_t ldo, const uint16_t*
   return hipGetLastError();
 }
 
+bool attn_bwd3_eligible(const void* q, const void* k, const void* v, const void* dout, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int S) {
+  if (attn_spad(S) / 32 < 4) return false;                   // S <= 64: the round-4 kernels
+  if ((ldq | ldk | ldv | lddo) % 8) return false;             // 16-byte LDS-DMA pieces / fragment loads: row strides and base pointers
+  return ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+}
+
 static bool bwd3_args_ok(const void* a, const void* b, const void* c, const void* d, int64_t l0, int64_t l1, int64_t l2, int64_t l3, int S) {
   if (attn_spad(S) / 32 < 4) return false;                   // (the caller keeps the round-4 kernels for S <= 64)
   // 16-byte LDS-DMA / global loads: row strides and base pointers

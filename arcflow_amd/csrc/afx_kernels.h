@@ -135,6 +135,8 @@ hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* 
 // (Qt / dOt are used by the round-4 dK / dV kernel only: AFX_ATTN_BWD_IMPL=2 and S <= 64)
 int64_t attn_bwd_ws_bytes(int B, int H, int S);
 int64_t attn_bwd3_stats_bytes(int B, int H, int S);
+// the generated streams take the call (S > 64, row strides multiples of 8 elements, 16-byte aligned bases); otherwise the round-4 kernels do
+bool attn_bwd3_eligible(const void* q, const void* k, const void* v, const void* dout, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int S);
 hipError_t launch_attn_bwd_stats(const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo, const float* lse, float* stats, float* delta_old,
                                  int B, int H, int S, hipStream_t stream);
 hipError_t launch_attn_bwd_dkv3(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v, int64_t ldv, const uint16_t* dout,
