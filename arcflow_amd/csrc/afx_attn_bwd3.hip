@@ -12,7 +12,7 @@
 //     8 consecutive rows of one head-dim column per lane -- are gathered by ds_read_b64_tr_b16 (pinned by tools/tr_probe.hip; afx_tn.hip uses the
 //     same read).  Half the LDS-DMA pieces and half the L2 traffic per tile, and the three transpose passes per call are gone.
 //   * the streams are GENERATED (tools/gen_attn_bwd3.py -> gen/b3_*.inc, gen/q3_*.inc, committed): every instruction its own asm statement, every wide
-//     operand asm-owned (register map in the generator's header), hipcc confined to v[0:63] by amdgpu_num_vgpr(64), ISA audited by arcflow_amd/build.py.
+//     operand asm-owned (register map in the generator's header), hipcc confined to v[0:59] by amdgpu_num_vgpr(60), ISA audited by arcflow_amd/build.py.
 //     Per 32 MFMAs the dK / dV wave issues 64 VALU instructions (the round-4 kernel: ~245, two thirds of them address arithmetic, accumulator-file moves and
 //     register shuffles the compiler added), 56 LDS reads and 5 DMA pieces; the dQ wave 56 / 32 / 4 per 24 MFMAs.
 //   * software pipeline over HALVES of 32 streamed rows (phase p: S / dP of half p | softmax gradient of half p - 1 | accumulating products of half p - 2),

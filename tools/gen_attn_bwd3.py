@@ -307,7 +307,7 @@ def vm_pieces():
 
 
 def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
-    """half-step p with ring slot J = p % 8 (set = J & 1).  The C++ around it provides xsrc / ssrc / xofs0..3 (DMA of half p + 5)."""
+    """half-step p with ring slot J = p % 8 (set = J & 1).  The C++ around it provides xsrc / ssrc (DMA of half p + lead(); the per-lane offsets are v60..v63)."""
     st = J & 1
     dq = MODE == 'dq'
     ngap = 24 if dq else 32
