@@ -502,13 +502,14 @@ int64_t attn_bwd_ws_bytes(int B, int H, int S) {
 
 // 3 (default): the generated one-wave-per-SIMD streams of afx_attn_bwd3.hip in ONE launch (no transposed copies at all); 4: the same as two launches;
 // 2: the round-4 kernels; 1: round-4 dQ + generated dK / dV   (A/B: AFX_ATTN_BWD_IMPL)
-static int attn_bwd_impl() {
-  static const int impl = [] {
+static int& attn_bwd_impl() {
+  static int impl = [] {
     const char* e = getenv("AFX_ATTN_BWD_IMPL");
     return e != nullptr ? atoi(e) : 3;
   }();
   return impl;
 }
+void attn_bwd_set_impl(int impl) { attn_bwd_impl() = (impl >= 1 && impl <= 4) ? impl : 3; }
 
 hipError_t launch_attention_backward(const uint16_t* q, int64_t ldq, const uint16_t* k, int64_t ldk, const uint16_t* v,
                                      int64_t ldv, const uint16_t* o, int64_t ldo, const uint16_t* dout, int64_t lddo,

@@ -1037,6 +1037,10 @@ int afx_attn_set_impl(int32_t impl) {
   attn_set_impl(impl);
   return 0;
 }
+int afx_attn_bwd_set_impl(int32_t impl) {
+  attn_bwd_set_impl(impl);
+  return 0;
+}
 
 static int linear_impl(const void* A, int64_t lda, const void* W, int64_t ldw, const void* bias, void* C, int64_t ldc,
                        int32_t M, int32_t N, int32_t K, int32_t epi, int32_t gelu_col0, const float* gate,

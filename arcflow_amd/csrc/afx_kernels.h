@@ -134,6 +134,7 @@ hipError_t launch_attention_ext(const uint16_t* q, int64_t ldq, const uint16_t* 
 // backward: see afx_attn_bwd.hip / afx_attn_bwd3.hip.  ws layout: Kt | Qt | dOt (each B*H*128*S_pad bf16) | delta (B*H*S_pad f32) | stats (2*B*H*S_pad f32)
 // (Qt / dOt are used by the round-4 dK / dV kernel only: AFX_ATTN_BWD_IMPL=2 and S <= 64)
 int64_t attn_bwd_ws_bytes(int B, int H, int S);
+void attn_bwd_set_impl(int impl);           // 3 (default) / 4 / 1 / 2: see afx_attn_bwd.hip (A/B runs, parity tests)
 int64_t attn_bwd3_stats_bytes(int B, int H, int S);
 // the generated streams take the call (S > 64, row strides multiples of 8 elements, 16-byte aligned bases); otherwise the round-4 kernels do
 bool attn_bwd3_eligible(const void* q, const void* k, const void* v, const void* dout, int64_t ldq, int64_t ldk, int64_t ldv, int64_t lddo, int S);

@@ -72,6 +72,12 @@ def set_attn_impl(impl: int = 0) -> None:
     _lib.check(_lib.load().afx_attn_set_impl(impl))
 
 
+def set_attn_bwd_impl(impl: int = 3) -> None:
+    """Kernel generation of ``attention_bwd`` (``afx_attn_bwd_set_impl``): 3 = generated dK / dV + dQ streams in one launch (default), 4 = as two launches,
+    1 = generated dK / dV + round-4 dQ, 2 = the round-4 kernels."""
+    _lib.check(_lib.load().afx_attn_bwd_set_impl(impl))
+
+
 def stream_k_workspace(device='cuda') -> torch.Tensor:
     """Zero-initialised workspace for ``linear(..., sk_ws=)`` (hand-off flags + fp32 accumulator slabs of the stream-K tail)."""
     lib = _lib.load()

@@ -450,6 +450,10 @@ int afx_attention_to_mx8(const void* q, int64_t ldq, const void* k, int64_t ldk,
 int afx_attention_fwd_lse_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o,
                                int64_t ldo, float* lse, void* vt_ws, int32_t batch, int32_t heads, int32_t S, void* stream);
 int64_t afx_attention_bwd_ws_bytes(int32_t batch, int32_t heads, int32_t S);
+/* Kernel generation of afx_attention_bwd_bf16 (reference: the FlashAttention-2 backward SDPA runs under arcflux.py:181-189): 3 (default) = the generated
+ * one-wave-per-SIMD dK / dV and dQ streams in one launch (csrc/afx_attn_bwd3.hip; S > 64, row strides multiples of 8), 4 = the same as two launches,
+ * 1 = generated dK / dV + round-4 dQ, 2 = the round-4 kernels (also what S <= 64 runs).  For A/B runs and the parity tests.  Returns 0. */
+int afx_attn_bwd_set_impl(int32_t impl);
 int afx_attention_bwd_bf16(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* o,
                            int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* dq, int64_t lddq, void* dk,
                            int64_t lddk, void* dv, int64_t lddv, void* ws, int32_t batch, int32_t heads, int32_t S,

@@ -208,6 +208,28 @@ def test_attention_backward(ops, B, S, H):
         assert torch.isfinite(t.float()).all()
 
 
+@pytest.mark.parametrize('S,H', [(4608, 24), (4224, 24), (4133, 5)])
+def test_attention_backward_generations_agree_at_the_production_shapes(ops, S, H):
+    """FLUX (4096 + 512 tokens) and Qwen-Image (4096 + 128) shapes, 24 heads, and a ragged one: the generated streams (one launch / two launches / dK-dV only)
+    against the round-4 kernels -- the same mathematics and the same bf16 rounding points (P and dS rounded to bf16 before the accumulating products), so the
+    results differ by summation order only."""
+    g = torch.Generator(device='cuda').manual_seed(S)
+    q, k, v, do = (torch.randn(1, S, H, 128, generator=g, device='cuda').bfloat16() for _ in range(4))
+    o, lse = ops.attention_fwd_lse(q, k, v)
+    try:
+        ops.set_attn_bwd_impl(2)
+        ref = ops.attention_bwd(q, k, v, o.reshape(1, S, H, 128), do, lse)
+        for impl in (3, 4, 1):
+            ops.set_attn_bwd_impl(impl)
+            got = ops.attention_bwd(q, k, v, o.reshape(1, S, H, 128), do, lse)
+            for name, a, b in zip(('dq', 'dk', 'dv'), got, ref):
+                assert torch.isfinite(a.float()).all()
+                err = ((a.float() - b.float()).norm() / b.float().norm()).item()
+                assert err < 6e-3, (impl, name, err)
+    finally:
+        ops.set_attn_bwd_impl(3)
+
+
 def test_attention_backward_strided_views_and_determinism(ops):
     """The training trunk hands the backward row-strided views (q | k | v columns of one [rows, 3 H 128] stash, gradients into a second one); the generated
     kernels (afx_attn_bwd3.hip) read them through LDS-DMA with the caller's strides.  Same numbers as the contiguous call, bit for bit, and twice the same
