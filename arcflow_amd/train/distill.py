@@ -25,6 +25,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from .. import ops
@@ -253,18 +255,29 @@ class ArcFlowDistiller:
             g = self.cfg.teacher_guidance
         return torch.full((B,), g, device=self.device)
 
-    def _teacher_u(self, x, sigma, cond):
+    def _teacher_prepare(self, sigmas, cond, N: int, T: int) -> bool:
+        """AdaLN modulation vectors of the teacher's next forwards -- `sigmas` [k, B], k x B <= 8 -- in ONE pass over the stacked modulation matrix
+        (``afx_mmdit_prepare_steps``, the inference loop's mechanism: 6.5 GB of weight streaming per FLUX forward, 8 right-hand sides cost what one does).
+        The reference re-evaluates `norm1.linear(silu(temb))` in every block of every teacher call (arcflux.py:160-230); the numbers are bit-identical
+        (tests/test_hip_engine.py::test_prepared_steps_are_bit_identical_to_the_plain_forward)."""
+        B = sigmas.shape[1]
+        return self.teacher.prepare_steps(sigmas, cond.get('pooled'), self._guid(B, teacher=True), B, N, T)
+
+    def _teacher_u(self, x, sigma, cond, prepared_step=None):
         """Teacher velocity (GaussianFlow.forward_u, gaussian_flow.py:224-254).  True CFG: the reference runs ONE forward on a 2B batch [negative; positive];
-        here the two halves are two forwards of B samples each (per-sample results are identical, the engine's micro-batch holds at most 4 samples)."""
+        here the two halves are two forwards of B samples each (per-sample results are identical, the engine's micro-batch holds at most 4 samples).
+        prepared_step: this call's row block of the last _teacher_prepare()."""
         xb = x.to(torch.bfloat16)
         g = self._guid(x.shape[0], teacher=True)
         if self.cfg.teacher_guidance_scale != 1.0 and 'negative_prompt_embeds' not in cond:
             raise ValueError('teacher_guidance_scale > 1 (true CFG) needs cond["negative_prompt_embeds"] '
                              '(reference: negative_prompt_embeds_path, lakonlab/datasets/image_prompts.py:158-163)')
-        pos = self.teacher(xb, sigma, cond['prompt_embeds'], cond.get('pooled'), g, cond['hp'], cond['wp']).float()
+        pos = self.teacher(xb, sigma, cond['prompt_embeds'], cond.get('pooled'), g, cond['hp'], cond['wp'], prepared_step=prepared_step).float()
         if self.cfg.teacher_guidance_scale == 1.0:
             return pos
-        neg = self.teacher(xb, sigma, cond['negative_prompt_embeds'], cond.get('negative_pooled'), g, cond['hp'], cond['wp']).float()
+        # the negative pass may reuse the prepared vectors when the conditioning does not see the prompt (Qwen-Image: timestep only; FLUX adds the pooled CLIP vector)
+        neg_prep = prepared_step if cond.get('pooled') is None and cond.get('negative_pooled') is None else None
+        neg = self.teacher(xb, sigma, cond['negative_prompt_embeds'], cond.get('negative_pooled'), g, cond['hp'], cond['wp'], prepared_step=neg_prep).float()
         return ops.cfg_combine(pos, neg, self.cfg.teacher_guidance_scale)
 
     def student_forward_unmerged(self, x_src, sigma_src, cond, p_drop: float = 0.0, seed: int = 0):
@@ -362,12 +375,23 @@ class ArcFlowDistiller:
         coef = c.loss_scale / (n * batch_total * N * ch) * segment          # mean over the 4B stacked states x segment weight
         x, raw, sigma = x_src, raw_src, sigma_src
         one = torch.ones(B, device=dev)
+        # the teacher's timesteps depend on the interval draws only, not on the roll-out: the modulation vectors of the next `chunk` teacher states come out of
+        # one pass over the stacked modulation matrix instead of one pass per forward (ARCFLOW_TRAIN_PREP_MOD=0: per forward, for A/B runs)
+        sig_a_all, raw_t = [], raw_src
+        for i in range(n):
+            raw_t = (raw_t - s_iv[:, i]).clamp(min=0)
+            sig_a_all.append(warp(raw_t, c.shift))
+            raw_t = (raw_t - t_iv[:, i]).clamp(min=0)
+        chunk = min(max(8 // B, 1), n) if os.environ.get('ARCFLOW_TRAIN_PREP_MOD', '1') != '0' else 0
+        prepared = False
         for i in range(n):
             raw_a = (raw - s_iv[:, i]).clamp(min=0)
             raw_b = (raw_a - t_iv[:, i]).clamp(min=0)
             sigma_a = warp(raw_a, c.shift)
             x_a = ops.arcflow_step_dropout(x, means, logw, logg, sigma_src, sigma, sigma_a, drop, c.eps)
-            tgt = self._teacher_u(x_a, sigma_a, cond)
+            if chunk > 1 and i % chunk == 0:
+                prepared = self._teacher_prepare(torch.stack(sig_a_all[i:i + chunk]), cond, N, T)
+            tgt = self._teacher_u(x_a, sigma_a, cond, prepared_step=(i % chunk) if (chunk > 1 and prepared) else None)
             # predicted mean velocity of the full policy over [raw_e, raw_a] (policy_average_u_momentum)
             raw_e = raw_b - window
             short = (torch.round((raw_a - raw_e) * c.total_substeps) < 2).float()

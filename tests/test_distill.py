@@ -315,6 +315,40 @@ def test_two_rank_train_step_equals_single_process_batch(tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('B', [1, 2, 4])
+def test_teacher_modulation_prepared_per_chunk_equals_per_forward(B, monkeypatch):
+    """The teacher's timesteps of a segment are known before its roll-out: their AdaLN modulation vectors come out of one pass over the stacked modulation matrix
+    per chunk of states (8 / B states) instead of one pass per teacher forward.  Same kernels, same numbers (the engine-level test pins bit-identity: test_hip_engine.py): the
+    iteration equals ARCFLOW_TRAIN_PREP_MOD=0 (B = 4: chunks of 2 states, B = 2: one chunk of 4, B = 1: one chunk of 4 of the 8 rows)."""
+    from arcflow_amd.train import ArcFlowDistiller, DistillConfig
+    cfg, w = _setup()
+    hp, wp, T = 8, 8, 12
+    g = torch.Generator().manual_seed(41 + B)
+    pe = (torch.randn(B, T, 128, generator=g) * 0.5).bfloat16().cuda()
+    pooled = (torch.randn(B, 64, generator=g) * 0.5).bfloat16().cuda()
+    x0 = torch.randn(B, hp * wp, 64, generator=g).cuda()
+    draws = [(torch.rand(B, 16, generator=g), torch.rand(B, 4, generator=g), torch.rand(B, 3, generator=g)) for _ in range(2)]
+    dc = DistillConfig(num_decay_iters=4, warmup_iters=0, grad_clip_begin_iter=10 ** 9, ema_start_iter=0)
+    eng = dict(num_double=1, num_single=1, heads=2, joint_dim=128, pooled_dim=64)
+    res = []
+    for mode in ('1', '0'):
+        monkeypatch.setenv('ARCFLOW_TRAIN_PREP_MOD', mode)
+        d = ArcFlowDistiller('flux', eng, w, dc)
+        d.iteration = 1
+        calls = []
+        orig = d.teacher.prepare_steps
+        d.teacher.prepare_steps = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        info = d.train_step(dict(prompt_embeds=pe, pooled=pooled, hp=hp, wp=wp), B, x_init=x0, draws=draws)
+        torch.cuda.synchronize()
+        res.append((info['loss'], d.grad.clone(), d.params.clone(), len(calls)))
+    assert res[0][3] == (4 if B == 4 else 2) and res[1][3] == 0          # two segments x (4 states / chunk) passes, none with the switch off
+    # (the loss scalar and two of the gradient reductions are summed with float atomics: equal up to their order, run to run as well)
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * abs(res[1][0])
+    assert ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item() < 1e-6
+    assert ((res[0][2] - res[1][2]).norm() / res[1][2].norm()).item() < 1e-7
+
+
+@pytest.mark.gpu
 def test_micro_batched_step_equals_one_batch():
     """more than 4 samples per GPU run as micro-batches of <= 4 and must give the gradient of the whole
     batch (mean over ALL samples), not of the last chunk."""
