@@ -19,6 +19,11 @@
 //     an 8-slot LDS ring of half tiles fed three phases ahead, one counted `s_waitcnt vmcnt` + barrier per phase.
 //   * L and delta come from ONE padded side array (attn_bwd_stats_kernel below: rows past S carry L = +inf, delta = 0, so that the clamped copies of the
 //     last row that fill a ragged query tile contribute exactly zero: no mask in the dK / dV loop; the dQ kernel masks the last tile's keys on a cold path).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
 #include <hip/hip_runtime.h>
 
 #include "afx_common.h"
@@ -118,15 +123,23 @@ B3_KATTR void attn_bwd_dq3_kernel(const bf16_t* __restrict__ q, int64_t ldq, con
   dq3_body(q, ldq, dout, lddo, k, ldk, v, ldv, stats, dq, lddq, nullptr, 0, H, S, S_pad, nblk, B, (int)blockIdx.x);
 }
 // ONE launch for both (the default): the two grids are 3.375 rounds of one work-group per CU each at S = 4608 / H = 24 and a launch costs ceil(rounds)
-// (DESIGN 4.0); back to back in one in-order grid the dQ work-groups start on the compute units the dK / dV grid's last round leaves idle
-// (6.75 rounds -> 7 instead of 4 + 4).  The longer dK / dV work-groups go first.
+// (DESIGN 4.0); in one in-order grid the dQ work-groups start on the compute units the dK / dV grid's last round leaves idle (6.75 rounds -> 7 instead
+// of 4 + 4).  Order inside an XCD's queue (slot = blockIdx / 8): ord_a dK / dV work-groups, ord_mid dQ ones, the other dK / dV ones, the other dQ ones --
+// launch_attn_bwd_fused3 picks (ord_a, ord_mid) by simulating the in-order dispatch with the two streams' measured cost ratio.
 B3_KATTR void attn_bwd_fused3_kernel(const bf16_t* __restrict__ q, int64_t ldq, const bf16_t* __restrict__ k, int64_t ldk, const bf16_t* __restrict__ v, int64_t ldv,
                                      const bf16_t* __restrict__ dout, int64_t lddo, const float* __restrict__ stats, bf16_t* __restrict__ dq, int64_t lddq,
                                      bf16_t* __restrict__ dk, int64_t lddk, bf16_t* __restrict__ dv, int64_t lddv, int H, int S, int S_pad, int nblk, int B,
-                                     int n_dkv) {
-  const int bid = (int)blockIdx.x;
-  if (bid < n_dkv) dkv3_body(k, ldk, v, ldv, q, ldq, dout, lddo, stats, dk, lddk, dv, lddv, H, S, S_pad, nblk, B, bid);
-  else dq3_body(q, ldq, dout, lddo, k, ldk, v, ldv, stats, dq, lddq, nullptr, 0, H, S, S_pad, nblk, B, bid - n_dkv);
+                                     int per_xcd, int ord_a, int ord_mid) {
+  const int xcd = (int)blockIdx.x & 7, s = (int)blockIdx.x >> 3;
+  int idx;
+  bool is_dq;
+  if (s < ord_a) { is_dq = false; idx = s; }
+  else if (s < ord_a + ord_mid) { is_dq = true; idx = s - ord_a; }
+  else if (s < per_xcd + ord_mid) { is_dq = false; idx = s - ord_mid; }
+  else { is_dq = true; idx = s - per_xcd; }
+  const int bid = (idx << 3) | xcd;
+  if (!is_dq) dkv3_body(k, ldk, v, ldv, q, ldq, dout, lddo, stats, dk, lddk, dv, lddv, H, S, S_pad, nblk, B, bid);
+  else dq3_body(q, ldq, dout, lddo, k, ldk, v, ldv, stats, dq, lddq, nullptr, 0, H, S, S_pad, nblk, B, bid);
 }
 #undef B3_KATTR
 
@@ -208,9 +221,37 @@ hipError_t launch_attn_bwd_fused3(const uint16_t* q, int64_t ldq, const uint16_t
   }
   const int hpx = (H + 7) / 8;
   const int nb = (S + 127) / 128;
-  const int n_dkv = 8 * hpx * nb * B;
-  hipLaunchKernelGGL(b3::attn_bwd_fused3_kernel, dim3(2 * n_dkv), dim3(b3::THREADS), lds, stream, q, ldq, k, ldk, v, ldv, dout, lddo, stats, dq, lddq, dk, lddk, dv,
-                     lddv, H, S, S_pad, nb, B, n_dkv);
+  const int per_xcd = hpx * nb * B;                          // work-groups of ONE stream per XCD
+  // order of an XCD's queue: [a dK/dV][mid dQ][per - a dK/dV][per - mid dQ].  The dispatcher hands the next work-group to the first free CU (32 per XCD), so the
+  // finish time of the grid is a list-scheduling makespan: search (a, mid) on a grid of 4 with the streams' cost ratio (dK/dV : dQ = 1.29 at 16 / 8 accumulating
+  // MFMAs per phase); a = mid = 0 is "all dK/dV first".  AFX_ATTN_BWD_ORDER="a,mid" overrides (A/B runs).
+  static int cache_per = -1, cache_a = 0, cache_mid = 0;
+  if (cache_per != per_xcd) {
+    int best_a = 0, best_mid = 0;
+    if (const char* e = getenv("AFX_ATTN_BWD_ORDER")) {
+      if (sscanf(e, "%d,%d", &best_a, &best_mid) != 2) best_a = best_mid = 0;
+      best_a = std::min(std::max(best_a, 0), per_xcd);
+      best_mid = std::min(std::max(best_mid, 0), per_xcd);
+    } else {
+      const double cl = 1.29, cs = 1.0;
+      double best = 1e30;
+      std::vector<double> cu(32);
+      for (int a = 0; a <= per_xcd; a += 4)
+        for (int mid = 0; mid <= per_xcd; mid += 4) {
+          std::fill(cu.begin(), cu.end(), 0.0);
+          for (int i = 0; i < 2 * per_xcd; ++i) {
+            const bool is_dq = (i >= a && i < a + mid) || i >= per_xcd + mid;
+            auto it = std::min_element(cu.begin(), cu.end());
+            *it += is_dq ? cs : cl;
+          }
+          const double m = *std::max_element(cu.begin(), cu.end());
+          if (m < best - 1e-9) { best = m; best_a = a; best_mid = mid; }
+        }
+    }
+    cache_per = per_xcd; cache_a = best_a; cache_mid = best_mid;
+  }
+  hipLaunchKernelGGL(b3::attn_bwd_fused3_kernel, dim3(16 * per_xcd), dim3(b3::THREADS), lds, stream, q, ldq, k, ldk, v, ldv, dout, lddo, stats, dq, lddq, dk, lddk, dv,
+                     lddv, H, S, S_pad, nb, B, per_xcd, cache_a, cache_mid);
   return hipGetLastError();
 }
 
