@@ -27,10 +27,10 @@ for kern, blk in ((0, 0), (0, 1), (1, 0), (1, 1)):
     floor = (1024, 768)[kern]
     for w in range(4):
         t = [buf[((kern * 2 + blk) * 4 + w) * 32 + i] for i in range(32)]
-        cyc, nh = t[24], t[25]
+        cyc, nh, ticks = t[24], t[25], t[26]
         ph = []
         for j in range(7):
             a, b, c, n = t[3 * j], t[3 * j + 1], t[3 * j + 2], t[3 * j + 3]
             ph.append(f'{(b - a) & 0xffffffff:4d}+{(c - b) & 0xffffffff:4d}+{(n - c) & 0xffffffff:4d}')
         print(f'{("dkv3", "dq3")[kern]} block {"0" if blk == 0 else "800"} w{w}: wait/barrier + S/dP half + accumulate half per phase: ' + ' | '.join(ph) +
-              f' || kernel {cyc} cycles / {nh + 2} phases = {cyc / (nh + 2):.0f} per phase (MFMA floor {floor})')
+              f' || kernel {cyc} cycles / {nh + 2} phases = {cyc / (nh + 2):.0f} per phase (MFMA floor {floor}), shader clock {100.0 * cyc / max(ticks, 1):.0f} MHz')
