@@ -1619,8 +1619,8 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   constexpr int TM = 32 * MI, TN = 32 * NJ, KB = 128;          // K-tile: 128 fp8 values = 128 bytes per row
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;
   constexpr int NH = NJ / 2, NM = MI * NH;                     // column tiles / MFMAs per phase
-  constexpr int R0 = NJ, R1 = 2 * MI + NJ;                     // 16-byte fragment reads of phase 0 / phase 1
-  static_assert(NJ % 2 == 0 && 4 * MI * NJ <= 256 && 2 * NJ + R0 <= 2 * NM && MI + R1 <= NM, "v3f8 tile shape");
+  constexpr int R0 = NJ + 2, R1 = 2 * (MI - 1) + NJ;           // 16-byte fragment reads of phase 0 (W_hi + the last A row tile) / phase 1 (A row tiles 0 .. MI - 2, W_lo)
+  static_assert(NJ % 2 == 0 && 4 * MI * NJ <= 256 && NJ + R0 <= NM && MI + R1 <= NM, "v3f8 tile shape");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const smem_w = smem + 2 * A_SLOT;
   const int tid = threadIdx.x;
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   // t+1 is read right behind the last MFMA of tile t that uses row tile i (phase 1 runs row tile by row tile), the last one at the start of the next
   // phase 0 -- 64 + 64 fragment registers instead of 128 + 64 (with two A sets the kernel sat at 250+ of 256 arch VGPRs and hipcc spilled: an LDS
   // address at best, and once an ACCUMULATOR, stored straight behind the inline-asm MFMA that was still writing it).
-  static_assert(MI == 8 && NJ == 8, "the slot tables below are written for the 8 x 8 shape");
+  static_assert((MI == 8 || MI == 7) && NJ == 8, "the slot tables below are written for 8 column tiles and 7 or 8 row tiles");
   i32x8_t af[MI], bl[NH], bh[NH];
   // LDS address of half h of row tile i of a slot = slot + lane part(h) + 2048 i: the swizzle term ((row >> 1) & 7) does not depend on i, so a tile
   // needs FOUR address registers (A / W x two halves: slot + lane part, made opaque per tile) and every read is `base offset:2048 i`.  Left to
@@ -1806,9 +1806,11 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
         V3_FENCE();
         constexpr int kind[32] = {1, 1, 1, 1, 2, 2, 1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 0, 0};   // 1 W_lo, 2 A, 3 DMA
         constexpr int arg[32] = {0, 1, 2, 3, 0, 1, 4, 5, 2, 3, 6, 7, 4, 5, 0, 1, 6, 7, 2, 3, 8, 9, 4, 5, 10, 11, 6, 7, 12, 13, 0, 0};
+        // (MI = 7, the 224x256 shape: the same table cut at 28 MFMAs -- row tiles 0..5 are read where the 8-row table reads them, the seventh DMA piece
+        // sits at m = 26 and the table's eighth is dropped)
         if (kind[m] == 1) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
-        else if (kind[m] == 2) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
-        else if (kind[m] == 3) {
+        else if (kind[m] == 2 && (arg[m] >> 1) < MI - 1) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
+        else if (kind[m] == 3 && arg[m] < MI) {
           if constexpr (more) V3_DMA(asrc_u, aoff[arg[m]], adst + (arg[m] * V3_THREADS + wave * 64) * 16);
         }
         V3_FENCE();
@@ -2147,7 +2149,20 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
     if (mx_any && !(ok && mx_all)) return hipErrorInvalidValue;      // block scales are this kernel's format only (callers ask gemm_fp8_mx_ok() first)
     if ((c8_any || qk_any) && !ok) return hipErrorInvalidValue;     // (the fused q / k epilogue: this kernel only; the engine asks for it with block scales only)
     if (ok && (mx_any || c8_any || qk_any || count_tiles(batch, 256, 256, false) >= min_tiles)) {
-      const int total = count_tiles(batch, 256, 256, true);
+      // 224x256 (round 5): a launch costs ceil(rounds) x tile area and the fp8 kernel had ONE shape -- Qwen-Image's 4096 + 128 rows are 17 + 1
+      // row tiles of 256 (N = 3072: 216 tiles = 0.84 round, N = 12288: 864 = 3.4 -> 4 rounds, N = 9216: 648 = 2.5 -> 3) but 19 + 1 of 224 (240 tiles = 0.94,
+      // 960 = 3.75 -> 4, 720 = 2.8 -> 3 rounds of tiles 7/8 the size); FLUX's joint 4608 rows of the single blocks likewise (out-projection: 252 tiles).
+      // AFX_FP8_TILE=1 / 2 force 256x256 / 224x256 (A/B).  The fused q / k epilogue keeps 256x256 (one head = one wave's 128 columns either way, but its
+      // row-tile loop is written for 8).
+      static int tile_env8 = -1;
+      if (tile_env8 < 0) {
+        const char* e = getenv("AFX_FP8_TILE");
+        tile_env8 = e ? atoi(e) : 0;
+      }
+      const int t8 = count_tiles(batch, 256, 256, false), t7 = count_tiles(batch, 224, 256, false);
+      const int r8 = (t8 + cus - 1) / cus, r7 = (t7 + cus - 1) / cus;
+      bool use7 = !qk_any && (tile_env8 == 2 || (tile_env8 == 0 && (double)r7 * 224 * 1.02 < (double)r8 * 256));
+      const int total = use7 ? count_tiles(batch, 224, 256, true) : count_tiles(batch, 256, 256, true);
       batch.total_tiles = total;
       if (total == 0) return hipSuccess;
       batch.group_m = group_m_env ? group_m_env : GROUP_M;
@@ -2158,9 +2173,23 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
         if (r != hipSuccess) return r;
         r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<8, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(8, 8));
         if (r != hipSuccess) return r;
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<7, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(7, 8));
+        if (r != hipSuccess) return r;
+        r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3f8<7, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(7, 8));
+        if (r != hipSuccess) return r;
         attr = true;
       }
       const bool timed = launch_timer().start != nullptr && launch_timer().stop != nullptr;
+      if (use7) {
+        if (mx_any) {
+          if (timed) hipExtLaunchKernelGGL((gemm_kernel_v3f8<7, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(7, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
+          else hipLaunchKernelGGL((gemm_kernel_v3f8<7, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(7, 8), stream, batch);
+        } else {
+          if (timed) hipExtLaunchKernelGGL((gemm_kernel_v3f8<7, 8, false>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(7, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
+          else hipLaunchKernelGGL((gemm_kernel_v3f8<7, 8, false>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(7, 8), stream, batch);
+        }
+        return hipGetLastError();
+      }
       if (mx_any) {
         if (timed) hipExtLaunchKernelGGL((gemm_kernel_v3f8<8, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, launch_timer().start, launch_timer().stop, 0, batch);
         else hipLaunchKernelGGL((gemm_kernel_v3f8<8, 8, true>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(8, 8), stream, batch);
