@@ -571,8 +571,9 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
   // mx_in: 0 = quantise A here; 1 = A is the wide operand a previous epilogue left in q8 / mxw; 2 = the LayerNorm kernel left it in q8n (+ qs: one scale
   // per row, or + mxn with AFX_FP8_NORM_MX); 3 = the attention kernel left it in q8n / mxn.
   // mx_out: this GEMM's epilogue writes the wide operand.
+  const int split_txt_default = 0;
   auto stream_gemm = [&](const uint16_t* A, int64_t lda, int K, const LinW (&lw)[2], uint16_t* C, int64_t ldc, int Nout, int epi,
-                         int blk, int gate_chunk, const float* qkn = nullptr, int mx_in = 0, bool mx_out = false) -> int {
+                         int blk, int gate_chunk, const float* qkn = nullptr, int mx_in = 0, bool mx_out = false, int kind = 0) -> int {
     GemmBatch gb{};
     if (mx && mx_in == 0) HIP_TRY(launch_quant_rows_mx8(A, lda, ws.q8n, K, ws.mxn, ws.ld_mxn, (int)R, K, st));      // (mx_in 2: the LayerNorm kernel wrote q8n / mxn itself)
     else if (c->fp8 && !mx) HIP_TRY(launch_quant_rows_fp8(A, lda, ws.q8, K, ws.qs, (int)R, K, st));     // per-token scales, all rows at once
@@ -606,6 +607,24 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         }
       }
     gb.sk_slab = ws.sk_slab; gb.sk_flags = ws.sk_flags;
+    // A launch costs ceil(rounds) x tile area: a SHORT text stream (Qwen-Image: 128 rows) costs the grouped launch a whole row of half-empty tiles --
+    // at N = 12288, 4096 + 128 rows are 816 tiles of 256x256 (3.2 -> 4 rounds; the launcher settles for 1024 tiles of 288x192 = 4 rounds) where the image rows
+    // alone are 768 = exactly 3.  split_txt (bit per launch kind: 1 qkv, 2 out, 4 mlp1, 8 mlp2; AFX_SPLIT_TXT overrides): the text problems go out as a launch
+    // of their own (small tiles, two work-groups per CU) behind the image problems'.
+    static int split_env = -2;
+    if (split_env == -2) {
+      const char* e = getenv("AFX_SPLIT_TXT");
+      split_env = e ? atoi(e) : -1;
+    }
+    const int split_mask = split_env >= 0 ? split_env : split_txt_default;
+    if ((split_mask & kind) != 0 && T > 0 && N > 0 && !mx && !c->fp8) {
+      GemmBatch gi{}, gt{};
+      for (int j = 0; j < gb.nprob; ++j) ((j & 1) ? gt : gi).p[((j & 1) ? gt : gi).nprob++] = gb.p[j];
+      gi.sk_slab = gt.sk_slab = ws.sk_slab; gi.sk_flags = gt.sk_flags = ws.sk_flags;
+      { ProfScope ps_(c, st, 0, gemm_flops(gi)); HIP_TRY(launch_gemm(gi, st)); }
+      { ProfScope ps_(c, st, 0, gemm_flops(gt)); HIP_TRY(launch_gemm(gt, st)); }
+      return AFX_OK;
+    }
     { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
     return AFX_OK;
   };
@@ -644,7 +663,7 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
         { ProfScope ps_(c, st, 0, gemm_flops(gb)); HIP_TRY(launch_gemm(gb, st)); }
       }
     } else
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr, norm_fused ? 2 : 0))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.qkv, QKV, 3 * D, (int)(3 * D), EPI_NONE, i, 0, qk_fuse ? qkn : nullptr, norm_fused ? 2 : 0, false, 1))) return rc;
     // k, q: RMSNorm + RoPE in place, v -> V^T: one launch
     if (vt_fuse) {
     } else if (qk_fuse)
@@ -656,10 +675,10 @@ int afx_mmdit_forward_stage(afx_ctx* c, const void* x, const void* ctx_emb, cons
     const AttnMx8 omx_d{ws.q8n, D, ws.mxn, ws.ld_mxn};
     { ProfScope ps_(c, st, 1, 4.0 * B * H * (double)S * S * 128);
       HIP_TRY(launch_attention(QKV + 2 * D, 3 * D, QKV, 3 * D, ws.Vt, QKV + 2 * D, 3 * D, B, H, S, st, nullptr, attn_mx ? &omx_d : nullptr, &o_fused)); }
-    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2, nullptr, o_fused ? 3 : 0))) return rc;
+    if ((rc = stream_gemm(QKV + 2 * D, 3 * D, (int)D, bw.out, ws.X, D, (int)D, EPI_GATE_RES, i, 2, nullptr, o_fused ? 3 : 0, false, 2))) return rc;
     if ((rc = stream_norm(i, 3, 4))) return rc;
-    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0, nullptr, norm_fused ? 2 : 0, mx))) return rc;      // (mx: the hidden leaves as the next GEMM's operand, Hb stays unwritten)
-    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5, nullptr, mx ? 1 : 0))) return rc;
+    if ((rc = stream_gemm(ws.Xn, D, (int)D, bw.mlp1, Hb, 4 * D, (int)(4 * D), EPI_GELU, i, 0, nullptr, norm_fused ? 2 : 0, mx, 4))) return rc;      // (mx: the hidden leaves as the next GEMM's operand, Hb stays unwritten)
+    if ((rc = stream_gemm(Hb, 4 * D, (int)(4 * D), bw.mlp2, ws.X, D, (int)D, EPI_GATE_RES, i, 5, nullptr, mx ? 1 : 0, false, 8))) return rc;
   }
 
   // ---- single-stream blocks on the joint sequence -------------------------------------------------
