@@ -248,8 +248,31 @@ def train_main(args, rank, world, dev, dist):
             'allreduce_bytes_per_step': int(ds.params.numel()) * 4 if world > 1 else 0,
             'max_mem_gb': torch.cuda.max_memory_allocated() / 2 ** 30, 'last_step': info,
         }
+        try:      # the attention backward of ONE (sample, layer) at this workload's sequence length, alone on the chip (the kernel DESIGN 4.3 is about; HIP events, 10 calls)
+            line['attn_backward'] = _attn_backward_probe(dev, T + N_IMG)
+        except Exception as e:              # noqa: BLE001
+            line['attn_backward'] = {'error': f'{type(e).__name__}: {e}'}
         return line
     return None
+
+
+def _attn_backward_probe(dev, S, H=24, calls=10):
+    from arcflow_amd import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    q, k, v, do = (torch.randn(1, S, H, 128, generator=g, device=dev).bfloat16() for _ in range(4))
+    o, lse = ops.attention_fwd_lse(q, k, v)
+    for _ in range(3):
+        ops.attention_bwd(q, k, v, o, do, lse)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(calls):
+        ops.attention_bwd(q, k, v, o, do, lse)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / calls
+    tf = 5 * 2 * H * S * S * 128 / us * 1e-6
+    return {'kernel': 'afx::b3::attn_bwd_fused3_kernel (+ attn_bwd_stats_kernel): generated dK / dV + dQ streams, one launch', 'tokens': S, 'heads': H,
+            'us_per_call': us, 'achieved': tf, 'unit': 'TFLOP/s over the 5 algorithmic matmuls (7 executed)', 'peak': 2500.0, 'frac': tf / 2500.0, 'bound': 'mfma'}
 
 
 def parse_args(argv=None):
@@ -338,7 +361,7 @@ def main(argv=None):
             gc.collect()
             torch.cuda.empty_cache()
             ex = argparse.Namespace(**vars(args))
-            KEYS_T = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline', 'backward_schedule',
+            KEYS_T = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'dtype', 'config', 'roofline', 'attn_backward', 'backward_schedule',
                       'allreduce_exposed_ms_per_step', 'allreduce_bytes_per_step', 'max_mem_gb')
 
             def extra(name, fn):
