@@ -263,6 +263,19 @@ def test_attention_race_probe(ops, S):
     assert _count_nonidentical(lambda: ops.attention(q, k, v), 120, junk) == 0
 
 
+@pytest.mark.parametrize('S', [4608, 4173])
+def test_attention_backward_race_probe(ops, S):
+    """The generated backward streams (afx_attn_bwd3.hip: hand-counted vmcnt / lgkmcnt waits, an 8-slot LDS ring, one barrier per phase, the dK / dV and the dQ
+    work-groups in one grid): 60 calls on fixed inputs with cache-disturbing work in between, dq | dk | dv bit-identical every time -- at S = 4608 and on a ragged
+    S = 4173 (clamped last-tile DMA rows, padded L | -delta side array, the dQ stream's cold key mask)."""
+    g = torch.Generator(device='cuda').manual_seed(1)
+    q, k, v, do = (torch.randn(1, S, 24, 128, generator=g, device='cuda').bfloat16() for _ in range(4))
+    o, lse = ops.attention_fwd_lse(q, k, v)
+    o = o.reshape(1, S, 24, 128)
+    junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    assert _count_nonidentical(lambda: torch.cat([t.reshape(-1) for t in ops.attention_bwd(q, k, v, o, do, lse)]), 60, junk) == 0
+
+
 @pytest.mark.parametrize('M,N,K', [(4608, 3072, 3072), (4608, 9216, 3072), (4608, 3072, 15360), (512, 9216, 3072)])
 def test_gemm_race_probe(ops, M, N, K):
     g = torch.Generator(device='cuda').manual_seed(0)
