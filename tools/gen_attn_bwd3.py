@@ -393,8 +393,11 @@ def phase(lds, J, do_sd=True, do_sm=True, do_dv=True, trace=None):
             out += lds.need(regs)
             out += mfma_variant(text)
         if 'nolds' not in ABL:
-            out += [f() for f in mem[gap]]
-        if gap in dma_gaps and 'nodma' not in ABL:
+            ops_ = [f() for f in mem[gap]]                       # (every read registers with the queue model)
+            if 'halfmem' in ABL:                                 # timing experiment (WRONG results): what a 64-row wave -- every fragment read feeding two MFMAs, half the
+                ops_ = ops_[::2] if len(ops_) > 1 else (ops_ if gap % 2 == 0 else [])      # DMA pieces per MFMA -- would leave of the memory instructions
+            out += ops_
+        if gap in dma_gaps and 'nodma' not in ABL and not ('halfmem' in ABL and dma_gaps[gap] in (1, 3)):
             out.append(dma(dma_gaps[gap], (J + lead()) % NSLOT))
         for op in sm[k:k + VALU_PER_GAP]:
             out += emit_valu(lds, op)
@@ -493,7 +496,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--mode', default='dkv', choices=['dkv', 'dq'])
     ap.add_argument('--out', default='gen', help='directory under arcflow_amd/csrc (afx_attn_bwd3.hip includes B3_GEN/..., default gen)')
-    ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu: timing experiments, WRONG results')
+    ap.add_argument('--ablate', default='', help='comma list of nodma, nolds, novalu, mfma16, halfmem: timing experiments, WRONG results')
     ap.add_argument('--valu-per-gap', type=int, default=3)
     ap.add_argument('--barrier-every', type=int, default=1, choices=[1, 2])
     ap.add_argument('--stat-one-wave', action='store_true')
