@@ -1511,7 +1511,11 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
       if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
       else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
     } else
+#ifdef V3_NO_EPI      // timing bound only (WRONG results: nothing is stored): what hiding the WHOLE epilogue behind matrix work could buy at most (profiles/r05b_gemm_no_epilogue_bound.txt)
+    asm volatile("" ::"v"(frow2), "v"(fq2), "s"(m0e), "s"(n0e));
+#else
     epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
+#endif
 #ifdef AFX_GEMM_TRACE
     AFX_TRC(21)
     tr[23] = (unsigned)__builtin_amdgcn_s_memrealtime();
