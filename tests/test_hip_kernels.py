@@ -287,6 +287,28 @@ def test_gemm_race_probe(ops, M, N, K):
     assert _count_nonidentical(lambda: ops.linear(a, w, b, out=out), 100, junk) == 0
 
 
+@pytest.mark.parametrize('M,N,K,mx', [(4224, 3072, 3072, False), (4608, 9216, 3072, False), (4224, 12288, 3072, True), (4173, 3072, 12288, True)])
+def test_fp8_gemm_race_probe_both_tile_shapes(ops, M, N, K, mx, monkeypatch):
+    """The one-wave-per-SIMD fp8 kernel on its two tile shapes (256x256 and, round 5, 224x256: the launcher picks per launch; these shapes take 224x256): 60 launches
+    on fixed inputs with cache-disturbing work in between, every output bit-identical, and the result within the fp8 tolerance of the fp32 product."""
+    g = torch.Generator(device='cuda').manual_seed(3)
+    a = torch.randn(M, K, generator=g, device='cuda').bfloat16()
+    w = (torch.randn(N, K, generator=g, device='cuda') * 0.02).bfloat16()
+    b = torch.randn(N, generator=g, device='cuda').bfloat16()
+    wq, ws = ops.quant_rows_fp8(w)
+    junk = torch.empty(64 << 20, dtype=torch.float32, device='cuda')
+    if mx:
+        aq, amx = ops.quant_rows_mx8(a)
+        fn = lambda: ops.linear_fp8_mx(aq, amx, wq, ws, b)      # noqa: E731
+    else:
+        aq, asc = ops.quant_rows_fp8(a)
+        fn = lambda: ops.linear_fp8(aq, asc, wq, ws, b)         # noqa: E731
+    assert _count_nonidentical(fn, 60, junk) == 0
+    auto = fn().clone()
+    ref = (a.float() @ w.float().t() + b.float())
+    assert rel_l2(auto.float(), ref) < 6e-2
+
+
 # ------------------------------------------------------------------------------------------ norms / rope / gemv
 @pytest.mark.parametrize('D', [256, 3072, 3584])
 def test_norm_modulate(ops, D):
