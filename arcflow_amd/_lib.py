@@ -26,7 +26,7 @@ EXPORTS = [
     'afx_latent_to_nhwc', 'afx_nhwc_to_image', 'afx_latent_to_nhwc_affine', 'afx_rmsnorm_nhwc',
     'afx_embed_rows_bf16', 'afx_norm_rows_bf16', 'afx_act_mul_bf16', 'afx_rope_half_bf16', 'afx_attention_ext_ws_bytes',
     'afx_attention_ext_bf16', 'afx_linear_bf16_splitk', 'afx_finish_f32_bf16', 'afx_linear_splitk_chunks', 'afx_quant_rows_fp8', 'afx_linear_fp8', 'afx_quant_rows_mx8', 'afx_linear_fp8_mx', 'afx_linear_fp8_to_mx8',
-    'afx_linear_bf16_pre', 'afx_linear_bf16_sk', 'afx_linear_sk_ws_bytes', 'afx_linear_sk_last_split', 'afx_gemm_set_mode', 'afx_attn_set_impl', 'afx_attn_bwd_set_impl', 'afx_mmdit_prepare_steps', 'afx_mmdit_use_prepared_step', 'afx_lora_dropout_bf16', 'afx_mmdit_forward_stage', 'afx_mmdit_import_tokens',
+    'afx_linear_bf16_pre', 'afx_linear_bf16_sk', 'afx_linear_sk_ws_bytes', 'afx_linear_sk_last_split', 'afx_gemm_set_mode', 'afx_gemm_dropres_available', 'afx_attn_set_impl', 'afx_attn_bwd_set_impl', 'afx_mmdit_prepare_steps', 'afx_mmdit_use_prepared_step', 'afx_lora_dropout_bf16', 'afx_mmdit_forward_stage', 'afx_mmdit_import_tokens',
     'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override', 'afx_set_fp8_linear',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
     'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_linear_tn_f32out', 'afx_linear_bf16_dropres', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward', 'afx_normout_backward_split',
@@ -125,6 +125,8 @@ def load() -> C.CDLL:
     lib.afx_mmdit_use_prepared_step.argtypes = [vp, i32]
     lib.afx_gemm_set_mode.argtypes = [i32, i32]
     lib.afx_gemm_set_mode.restype = i32
+    lib.afx_gemm_dropres_available.argtypes = []
+    lib.afx_gemm_dropres_available.restype = i32
     lib.afx_attn_set_impl.argtypes = [i32]
     lib.afx_attn_set_impl.restype = i32
     lib.afx_attn_bwd_set_impl.argtypes = [i32]

@@ -583,47 +583,81 @@ bool build_plan(int B, int H, int S, int ncu, std::vector<a3::Item>& items, int&
   return true;
 }
 
-SplitPlan* plan_for(int B, int H, int S, hipStream_t stream) {
+// One plan per (device, B, H, S, stream), at most PLAN_CACHE_MAX of them (prompt lengths vary batch to batch in training, S = T + N, and every plan
+// owns its partial slots -- up to ~25 MB): the least recently used plan is freed when a new shape arrives (after its stream has drained: a launch of it may still
+// be running).  A new plan is uploaded and cleared on the LAUNCH stream (no device-wide synchronisation); its host table lives as long as the plan, so the
+// asynchronous copy always has its source.  The generation number is advanced under the cache mutex and handed out by value.
+constexpr size_t PLAN_CACHE_MAX = 16;
+struct PlanEntry {
+  SplitPlan pl;
+  std::vector<a3::Item> host_items;
+  char* base = nullptr;
+  uint64_t last_use = 0;
+};
+bool plan_for(int B, int H, int S, hipStream_t stream, SplitPlan& out) {
   static std::mutex mu;
-  static std::map<std::tuple<int, int, int, int, hipStream_t>, SplitPlan> cache;
+  static std::map<std::tuple<int, int, int, int, hipStream_t>, PlanEntry> cache;
+  static uint64_t tick = 0;
   static int enabled = -1;
   std::lock_guard<std::mutex> lock(mu);
   if (enabled < 0) {
     const char* e = getenv("AFX_ATTN_SPLIT");            // 0: the plain grid (A/B runs)
     enabled = (e && e[0] == '0') ? 0 : 1;
   }
-  if (!enabled) return nullptr;
+  if (!enabled) return false;
   // the generation number is a kernel argument: a captured launch would replay a stale one (and nothing may be allocated inside a capture)
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return false;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
   const auto key = std::make_tuple(dev, B, H, S, stream);
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second.split ? &it->second : nullptr;
-  int ncu = 0;
-  if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
-  SplitPlan pl;
-  std::vector<a3::Item> items;
-  if (build_plan(B, H, S, ncu, items, pl.nparts, pl.grid)) {
-    const size_t ib = items.size() * sizeof(a3::Item);
-    const size_t pb = (size_t)pl.nparts * a3::QBLK * 128 * 2, lb = (size_t)pl.nparts * a3::QBLK * 4, fb = (size_t)pl.nparts * 4;
-    char* base = nullptr;
-    const size_t o1 = (ib + 255) / 256 * 256, o2 = o1 + (pb + 255) / 256 * 256, o3 = o2 + (lb + 255) / 256 * 256;
-    if (hipMalloc((void**)&base, o3 + fb) == hipSuccess && hipMemcpy(base, items.data(), ib, hipMemcpyHostToDevice) == hipSuccess &&
-        hipMemset(base + o1, getenv("AFX_ATTN_FILL") ? 0xff : 0, o3 - o1) == hipSuccess && hipMemset(base + o3, 0, fb) == hipSuccess &&
-        hipDeviceSynchronize() == hipSuccess) {
-      pl.items = reinterpret_cast<a3::Item*>(base);
-      pl.po = reinterpret_cast<uint16_t*>(base + o1);
-      pl.plse = reinterpret_cast<float*>(base + o2);
-      pl.pflag = reinterpret_cast<int*>(base + o3);
-      pl.split = true;
-    } else {
-      (void)hipGetLastError();
+  if (it == cache.end()) {
+    if (cache.size() >= PLAN_CACHE_MAX) {
+      auto victim = cache.begin();
+      for (auto j = cache.begin(); j != cache.end(); ++j)
+        if (j->second.last_use < victim->second.last_use) victim = j;
+      if (victim->second.base != nullptr) {
+        int cur = dev;
+        const int vdev = std::get<0>(victim->first);
+        if (vdev != cur) (void)hipSetDevice(vdev);
+        (void)hipStreamSynchronize(std::get<4>(victim->first));      // (a destroyed stream: the error is dropped, hipFree below synchronises by itself)
+        (void)hipFree(victim->second.base);
+        (void)hipGetLastError();
+        if (vdev != cur) (void)hipSetDevice(cur);
+      }
+      cache.erase(victim);
     }
+    int ncu = 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+    PlanEntry& en = cache[key];
+    SplitPlan& pl = en.pl;
+    if (build_plan(B, H, S, ncu, en.host_items, pl.nparts, pl.grid)) {
+      const size_t ib = en.host_items.size() * sizeof(a3::Item);
+      const size_t pb = (size_t)pl.nparts * a3::QBLK * 128 * 2, lb = (size_t)pl.nparts * a3::QBLK * 4, fb = (size_t)pl.nparts * 4;
+      char* base = nullptr;
+      const size_t o1 = (ib + 255) / 256 * 256, o2 = o1 + (pb + 255) / 256 * 256, o3 = o2 + (lb + 255) / 256 * 256;
+      if (hipMalloc((void**)&base, o3 + fb) == hipSuccess && hipMemcpyAsync(base, en.host_items.data(), ib, hipMemcpyHostToDevice, stream) == hipSuccess &&
+          hipMemsetAsync(base + o1, getenv("AFX_ATTN_FILL") ? 0xff : 0, o3 - o1, stream) == hipSuccess && hipMemsetAsync(base + o3, 0, fb, stream) == hipSuccess) {
+        en.base = base;
+        pl.items = reinterpret_cast<a3::Item*>(base);
+        pl.po = reinterpret_cast<uint16_t*>(base + o1);
+        pl.plse = reinterpret_cast<float*>(base + o2);
+        pl.pflag = reinterpret_cast<int*>(base + o3);
+        pl.split = true;
+      } else {
+        (void)hipGetLastError();
+        if (base != nullptr) (void)hipFree(base);
+      }
+    }
+    if (!pl.split) { en.host_items.clear(); en.host_items.shrink_to_fit(); }
+    it = cache.find(key);
   }
-  auto& slot = cache[key] = pl;
-  return slot.split ? &slot : nullptr;
+  it->second.last_use = ++tick;
+  if (!it->second.pl.split) return false;
+  ++it->second.pl.gen;
+  out = it->second.pl;
+  return true;
 }
 }  // namespace
 
@@ -683,13 +717,14 @@ hipError_t launch_attention_v3(const uint16_t* q, int64_t ldq, const uint16_t* k
     const char* e = getenv("AFX_ATTN3_DBG");
     dbg = e ? atoi(e) : 0;
   }
-  SplitPlan* pl = (split && o8 == nullptr && dbg == 0) ? plan_for(B, H, S, stream) : nullptr;      // (the block-scaled fp8 output keeps the plain grid)
+  SplitPlan plan;
+  const SplitPlan* pl = (split && o8 == nullptr && dbg == 0 && plan_for(B, H, S, stream, plan)) ? &plan : nullptr;      // (the block-scaled fp8 output keeps the plain grid)
   const dim3 grid(pl ? pl->grid : 8 * ((H + 7) / 8) * nqb * B);
   const a3::Item* items = pl ? pl->items : nullptr;
   uint16_t* po = pl ? pl->po : nullptr;
   float* plse = pl ? pl->plse : nullptr;
   int* pflag = pl ? pl->pflag : nullptr;
-  const int gen = pl ? ++pl->gen : 0;
+  const int gen = pl ? pl->gen : 0;
   unsigned long long* tl = nullptr;
   if (g_tl_cap > 0 && (int)grid.x <= g_tl_cap) { tl = g_tl; g_tl_grid = (int)grid.x; }
   // AFX_ATTN_HANDOVER: "fence" = plain stores + release fence instead of write-through stores (A/B); "lost" = the long parts never see a partial published and

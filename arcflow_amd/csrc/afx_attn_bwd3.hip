@@ -22,6 +22,10 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include <hip/hip_runtime.h>
@@ -225,30 +229,42 @@ hipError_t launch_attn_bwd_fused3(const uint16_t* q, int64_t ldq, const uint16_t
   // order of an XCD's queue: [a dK/dV][mid dQ][per - a dK/dV][per - mid dQ].  The dispatcher hands the next work-group to the first free CU (32 per XCD), so the
   // finish time of the grid is a list-scheduling makespan: search (a, mid) on a grid of 4 with the streams' cost ratio (dK/dV : dQ = 1.29 at 16 / 8 accumulating
   // MFMAs per phase); a = mid = 0 is "all dK/dV first".  AFX_ATTN_BWD_ORDER="a,mid" overrides (A/B runs).
-  static int cache_per = -1, cache_a = 0, cache_mid = 0;
-  if (cache_per != per_xcd) {
-    int best_a = 0, best_mid = 0;
-    if (const char* e = getenv("AFX_ATTN_BWD_ORDER")) {
-      if (sscanf(e, "%d,%d", &best_a, &best_mid) != 2) best_a = best_mid = 0;
-      best_a = std::min(std::max(best_a, 0), per_xcd);
-      best_mid = std::min(std::max(best_mid, 0), per_xcd);
-    } else {
-      const double cl = 1.29, cs = 1.0;
-      double best = 1e30;
-      std::vector<double> cu(32);
-      for (int a = 0; a <= per_xcd; a += 4)
-        for (int mid = 0; mid <= per_xcd; mid += 4) {
-          std::fill(cu.begin(), cu.end(), 0.0);
-          for (int i = 0; i < 2 * per_xcd; ++i) {
-            const bool is_dq = (i >= a && i < a + mid) || i >= per_xcd + mid;
-            auto it = std::min_element(cu.begin(), cu.end());
-            *it += is_dq ? cs : cl;
+  // Memoised per per_xcd under a mutex (variable prompt lengths alternate shapes; the search is host work inside the launch path); the makespan of
+  // one candidate is a heap walk, O(per_xcd log 32).
+  static std::mutex order_mu;
+  static std::map<int, std::pair<int, int>> order_cache;
+  int cache_a = 0, cache_mid = 0;
+  {
+    std::lock_guard<std::mutex> lock(order_mu);
+    auto hit = order_cache.find(per_xcd);
+    if (hit == order_cache.end()) {
+      int best_a = 0, best_mid = 0;
+      if (const char* e = getenv("AFX_ATTN_BWD_ORDER")) {
+        if (sscanf(e, "%d,%d", &best_a, &best_mid) != 2) best_a = best_mid = 0;
+        best_a = std::min(std::max(best_a, 0), per_xcd);
+        best_mid = std::min(std::max(best_mid, 0), per_xcd);
+      } else {
+        const double cl = 1.29, cs = 1.0;
+        double best = 1e30;
+        std::vector<double> cu(32);
+        for (int a = 0; a <= per_xcd; a += 4)
+          for (int mid = 0; mid <= per_xcd; mid += 4) {
+            std::fill(cu.begin(), cu.end(), 0.0);                     // (all equal: a valid min-heap under std::greater)
+            double m = 0.0;
+            for (int i = 0; i < 2 * per_xcd; ++i) {
+              const bool is_dq = (i >= a && i < a + mid) || i >= per_xcd + mid;
+              std::pop_heap(cu.begin(), cu.end(), std::greater<double>());      // the first free CU
+              cu.back() += is_dq ? cs : cl;
+              m = std::max(m, cu.back());
+              std::push_heap(cu.begin(), cu.end(), std::greater<double>());
+            }
+            if (m < best - 1e-9) { best = m; best_a = a; best_mid = mid; }
           }
-          const double m = *std::max_element(cu.begin(), cu.end());
-          if (m < best - 1e-9) { best = m; best_a = a; best_mid = mid; }
-        }
+      }
+      if (order_cache.size() >= 64) order_cache.clear();
+      hit = order_cache.emplace(per_xcd, std::make_pair(best_a, best_mid)).first;
     }
-    cache_per = per_xcd; cache_a = best_a; cache_mid = best_mid;
+    cache_a = hit->second.first; cache_mid = hit->second.second;
   }
   hipLaunchKernelGGL(b3::attn_bwd_fused3_kernel, dim3(16 * per_xcd), dim3(b3::THREADS), lds, stream, q, ldq, k, ldk, v, ldv, dout, lddo, stats, dq, lddq, dk, lddk, dv,
                      lddv, H, S, S_pad, nb, B, per_xcd, cache_a, cache_mid);

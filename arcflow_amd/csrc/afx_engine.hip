@@ -1048,6 +1048,7 @@ int afx_linear_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
 
 int64_t afx_linear_sk_ws_bytes(void) { return GEMM_SK_FLAG_BYTES + GEMM_SK_SLAB_BYTES; }
 int afx_linear_sk_last_split(void) { return last_sk_cus(); }
+int afx_gemm_dropres_available(void) { return gemm_dropres_available() ? 1 : 0; }
 int afx_gemm_set_mode(int32_t impl, int32_t tile) {
   gemm_set_mode(impl, tile);
   return 0;

@@ -1250,6 +1250,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
 #ifndef V3_EXP
 #define V3_EXP 0
 #endif
+#ifndef V3_EPI_SWAP          // 0: the 4-columns-per-lane epilogue without the permlane exchange (A/B builds; it has no masked residual add: gemm_dropres_available() is false there)
+#define V3_EPI_SWAP 1
+#endif
+#define V3_EPI_SWAP_DEFAULT V3_EPI_SWAP
 AFX_DEV uint64_t v3_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit value, in an SGPR pair
   const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
@@ -1504,9 +1508,6 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     };
     if constexpr (PERSIST == 1) next_tile();
     AFX_TRC(20)
-#ifndef V3_EPI_SWAP
-#define V3_EPI_SWAP 1
-#endif
     if constexpr (CONV) {      // bias (+ residual) + re-zeroing of the border pixels: the output grid is the next layer's padded input
       if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
       else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
@@ -1899,6 +1900,11 @@ bool gemm_qk_fusion_available() {
   const char* k = getenv("AFX_GEMM_SK");
   const char* f = getenv("AFX_QK_FUSE");                // AFX_QK_FUSE=0: keep the separate kv_prep launch (A/B)
   return gemm_mode().impl == 3 && !(k && atoi(k) != 0) && !(f && f[0] == '0');
+}
+bool gemm_dropres_available() {                         // launch_gemm would take a problem with drop_on: the masked residual add exists in the one-wave-per-SIMD
+  if (gemm_mode().impl < 0) (void)gemm_qk_fusion_available();      // kernel's permlane-paired epilogue only (kernel mode 3, no stream-K request)
+  const char* k = getenv("AFX_GEMM_SK");
+  return V3_EPI_SWAP_DEFAULT != 0 && gemm_mode().impl == 3 && !(k && atoi(k) != 0);
 }
 void gemm_set_mode(int impl, int tile) {
   gemm_mode().impl = (impl >= 1 && impl <= 3) ? impl : 3;

@@ -95,6 +95,7 @@ hipError_t launch_gemm_tn_f32(const uint16_t* X, int64_t ldx, const uint16_t* Y,
                               hipStream_t stream);
 bool gemm_conv_stats_available();           // GemmProblem::gn_stats is honoured (kernel mode 3, no forced tile shape)
 bool gemm_qk_fusion_available();            // the launcher would take a problem with qk_D > 0 (kernel mode 3, no stream-K request)
+bool gemm_dropres_available();              // ... a problem with drop_on (the LoRA branch's masked residual add in the epilogue)
 void gemm_set_mode(int impl, int tile);      // kernel / tile-shape override of AFX_GEMM_IMPL / AFX_GEMM_TILE (see launch_gemm)
 constexpr int GN_SLOTS = 64;
 constexpr int64_t GEMM_SK_FLAG_BYTES = 4096;                       // 1024 flag words

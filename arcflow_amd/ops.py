@@ -317,6 +317,12 @@ def linear_dropres(a, w, residual, p: float, seed: int, row0: int = 0, out=None)
     N = w.shape[0]
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    if not lib.afx_gemm_dropres_available():
+        # the masked residual add lives in the one-wave-per-SIMD kernel's epilogue only (set_gemm_mode(1 / 2), AFX_GEMM_IMPL, AFX_GEMM_SK select
+        # other kernels in A/B runs and parity tests): the product to memory, then the mask-and-add pass -- the same bits
+        if out.data_ptr() != residual.data_ptr():
+            out.copy_(residual)
+        return lora_dropout(linear(a, w), p, seed, row0, mode=3, out=out)
     _lib.check(lib.afx_linear_bf16_dropres(_p(a), a.stride(0), _p(w), w.stride(0), _p(out), out.stride(0), M, N, K, _p(residual), residual.stride(0),
                                            float(p), seed & 0xffffffff, row0, _s()))
     return out

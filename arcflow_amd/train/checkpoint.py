@@ -154,6 +154,11 @@ def check_pending_save() -> None:
         raise _pending_error.pop()
 
 
+def pending_save_failed() -> bool:
+    """True when a background save has failed and its error has not been raised yet (tools/train.py shares this flag across ranks before raising)."""
+    return bool(_pending_error)
+
+
 def save_checkpoint_async(distiller, out_dir: str, filename_tmpl: str = 'iter_{}.pth', create_symlink: bool = True, **kw) -> str:
     """``save_checkpoint`` with the file write off the training loop: the state is copied to host memory here (that part synchronises the device:
     ~1 s for the Qwen-Image adapter set), pickling and the ~6 GB write run in a thread.  The file appears under its final name only when complete

@@ -454,11 +454,19 @@ class LoraTrunk:
             self.stash = None
             self._lse.clear()
             free, _ = torch.cuda.mem_get_info(self.dev)
+            room = free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) - (8 << 30)
             need = self.stash_bytes(rows)
-            if need > free + torch.cuda.memory_reserved(self.dev) - torch.cuda.memory_allocated(self.dev) - (8 << 30):
+            if need > room and self.keep_xd:
+                # three levels, the cheapest one that fits: GEMM outputs + dropped adapter inputs > GEMM outputs only (round 4's stash) > recompute
+                import warnings
+                self.keep_xd = False
+                warnings.warn(f'LoraTrunk: {need / 2**30:.0f} GiB of kept forward outputs do not fit ({room / 2**30:.0f} GiB available): keeping the GEMM / '
+                              f'attention outputs only ({self.stash_bytes(rows) / 2**30:.0f} GiB; the adapters\' dropped inputs are recomputed in the backward)')
+                need = self.stash_bytes(rows)
+            if need > room:
                 # not enough HBM for this batch / sequence: the reference's schedule (recompute every block from its checkpoint) still works
                 import warnings
-                warnings.warn(f'LoraTrunk: {need / 2**30:.0f} GiB of kept forward outputs do not fit ({free / 2**30:.0f} GiB free): '
+                warnings.warn(f'LoraTrunk: {need / 2**30:.0f} GiB of kept forward outputs do not fit ({room / 2**30:.0f} GiB available): '
                               f'falling back to recomputing every block in the backward')
                 self.use_stash = False
                 return None

@@ -418,6 +418,10 @@ int afx_linear_sk_last_split(void);
  * 2: 288x192, 3: 320x192, 4: 128x128, 5: 256x224); impl 2 = 8-phase 256x256 kernel for everything; impl 1 = simple reference kernel.  Same meaning as the
  * AFX_GEMM_IMPL / AFX_GEMM_TILE environment variables, which it overrides.  Returns 0. */
 int afx_gemm_set_mode(int32_t impl, int32_t tile);
+/* 1 when afx_linear_bf16_dropres can run under the current kernel choice (its masked residual add lives in the one-wave-per-SIMD kernel's epilogue: kernel
+ * mode 3, no stream-K request), 0 otherwise -- the caller then computes the product with afx_linear_bf16 and masks + adds it with afx_lora_dropout_bf16 mode 3
+ * (arcflow_amd/ops.py linear_dropres does).  Host-side, no GPU needed. */
+int afx_gemm_dropres_available(void);
 /* Kernel choice of every joint attention launch (process-wide; same meaning as AFX_ATTN_IMPL, which it overrides): 0 (default) = the
  * one-wave-per-SIMD kernel (afx_attn3.hip: 64 queries per wave, any S > 64: ragged tails handled) where eligible, else the 4-wave kernel; 1 = 4-wave kernel
  * always; 2 = 8-wave ping-pong kernel (experimental); 3 = the one-wave-per-SIMD kernel on its plain grid (0 cuts the 256-query blocks of an under-filled

@@ -105,6 +105,23 @@ def rand_mixture(gen, b, k, c, h, w, logg_scale=1.0):
     return means, logw, logg
 
 
+G9_STRIDE = 61            # co-prime with 64 channels and 4096 tokens: the sample walks every channel and patch position
+
+
+def golden_full_size_inputs(seed=20260929):
+    """The seeded full-size (4096 tokens, K = 16) mixture + latent of fixture G9, in the token layout the denoiser emits."""
+    gen = torch.Generator().manual_seed(seed)
+    n = 4096
+    m_tok = torch.randn(1, n, 16, 64, generator=gen)
+    lw_tok = torch.log_softmax(torch.randn(1, n, 16, 4, generator=gen) * 2.0, dim=-2)
+    lg_tok = torch.randn(1, n, 15, 4, generator=gen) * 1.2
+    lg_tok[0, :64, 0] = 0.0                  # the clamp / sign branches of phi at full size too
+    lg_tok[0, 64:128, 1] = 1e-5
+    lg_tok[0, 128:192, 2] = -1e-5
+    x_tok = torch.randn(1, n, 64, generator=gen)
+    return dict(means_tok=m_tok, logw_tok=lw_tok, logg_tok=lg_tok, x_tok=x_tok)
+
+
 def main():
     torch.set_num_threads(4)
     ArcFlowPolicy = load_policy()
@@ -199,6 +216,30 @@ def main():
          means_lat=mp['means'], logw_lat=mp['logweights'], logg_lat=mp['loggammas'],
          patchified=pat, unp_means=unp['means'], unp_logw=unp['logweights'], unp_logg=unp['loggammas'],
          x_tok=x_tok, x_end_tok=x_end_tok, hp=np.int64(hh), wp=np.int64(ww))
+
+    # ---------------------------------------------------------------- G9 one FULL-SIZE step (1024^2: latent [1, 16, 128, 128])
+    # Inputs are a seeded CPU draw the test repeats (their fp64 checksums are stored so a changed generator is noticed); of the
+    # 262 144 outputs the fixture keeps a strided sample + fp64 moments, for both steps of the 2-NFE schedule.
+    g9 = golden_full_size_inputs()
+    hh = ww = 64
+    height = width = hh * 16
+    mp = flux['_unpack_mp'](pipe, dict(means=g9['means_tok'].clone(), logweights=g9['logw_tok'].clone(), loggammas=g9['logg_tok'].clone()),
+                            height, width, 16, gm_patch_size=1)
+    x_lat = flux['_unpack_latents'](g9['x_tok'], height, width, 8, target_patch_size=1)
+    assert tuple(x_lat.shape) == (1, 16, 128, 128)
+    out9 = dict(stride=np.int64(G9_STRIDE), **{'in_sum_' + k2: np.float64(v.double().sum().item()) for k2, v in g9.items()})
+    for i, (s_src, t_end) in enumerate([(1.0, 761.9047761), (0.7619047761, 0.0)]):
+        pol = ArcFlowPolicy({k2: v.to(torch.float32) for k2, v in mp.items()}, x_lat, torch.tensor(s_src))
+        x_end = flux['momentum_integration'](pipe, torch.tensor(s_src), x_lat, torch.tensor(s_src), torch.tensor(t_end), pol, eps=1e-4)[0]
+        x_end_tok = flux['_pack_latents'](x_end, 1, 16, 2 * hh, 2 * ww, patch_size=1)
+        flat = x_end_tok.reshape(-1)
+        out9[f'case{i}_sigma_src'] = np.float32(s_src)
+        out9[f'case{i}_t_end'] = np.float32(t_end)
+        out9[f'case{i}_sample'] = flat[::G9_STRIDE].clone()
+        out9[f'case{i}_sum'] = np.float64(flat.double().sum().item())
+        out9[f'case{i}_sumsq'] = np.float64((flat.double() ** 2).sum().item())
+        out9[f'case{i}_absmax'] = np.float32(flat.abs().max().item())
+    save('g9_step_full_size', **out9)
 
     # ---------------------------------------------------------------- training-form pieces
     samp_ns = dict(base_ns)

@@ -52,6 +52,11 @@ def test_argument_validation_no_gpu(lib):
     assert lib.afx_linear_bf16_dropres(None, 64, None, 64, None, 8, 1, 8, 64, None, 8, 0.05, 1, 0, None) == -1
     assert lib.afx_linear_bf16_dropres(C.c_void_p(4096), 64, C.c_void_p(8192), 64, C.c_void_p(16384), 8, 1, 8, 64, C.c_void_p(16384), 8, 1.5, 1, 0, None) == -1   # p >= 1
     assert lib.afx_normout_backward_split(None, 8, None, 8, None, None, 1, 8, None) == -1
+    # round-6: the capability query behind ops.linear_dropres' fallback follows the kernel choice (host-side state only)
+    if os.environ.get('AFX_GEMM_IMPL', '3') == '3' and os.environ.get('AFX_GEMM_SK', '0') == '0':
+        assert lib.afx_gemm_dropres_available() == 1
+        assert lib.afx_gemm_set_mode(2, 0) == 0 and lib.afx_gemm_dropres_available() == 0
+        assert lib.afx_gemm_set_mode(3, 0) == 0 and lib.afx_gemm_dropres_available() == 1
     assert lib.afx_destroy(ctx) == 0
 
 

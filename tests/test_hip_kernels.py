@@ -372,6 +372,15 @@ def test_arcflow_step_golden(ops, golden):
     assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=1e-5)
 
 
+def test_arcflow_step_full_size_golden(ops, golden_full_size_inputs):
+    """One FULL-SIZE step (4096 tokens = latent [1, 16, 128, 128], K = 16, both steps of the 2-NFE schedule) against fixture G9 = the reference's own
+    unpack -> policy -> momentum_integration -> repack on the same seeded draw (arcflux_pipeline.py:482-510; SURVEY 8c "plus one full 128 x 128")."""
+    from test_oracle_golden import _check_g9
+    inp, g = golden_full_size_inputs
+    _check_g9(lambda x, m, lw, lg, s0, s1: ops.arcflow_step(x.to(dev()), m.to(dev()), lw.to(dev()), lg.to(dev()), s0, s0, s1), inp, g,
+              rtol=1e-5, atol=1e-5)
+
+
 def test_arcflow_step_vs_oracle_edge_cases(ops):
     from oracle import arcflow_ref as R
     g = torch.Generator().manual_seed(21)

@@ -348,3 +348,17 @@ def test_linear_dropres_matches_product_then_masked_add(ops, M, N, K, p):
     scale = ref.abs().max().item()
     assert (new.float() - ref).abs().max().item() <= 2 ** -8 * scale           # one bf16 rounding of the sum
     assert (new.float() - ref).abs().max().item() <= (old.float() - ref).abs().max().item() + 1e-6
+    # under a kernel choice without the fused epilogue (A/B runs, parity tests: set_gemm_mode(2) = the 8-phase kernel) the call falls back to product + mask-and-add
+    # instead of failing -- the round-4 formulation's bits exactly
+    from arcflow_amd import _lib
+    try:
+        ops.set_gemm_mode(2)
+        assert _lib.load().afx_gemm_dropres_available() == 0
+        fb = res.clone()
+        ops.linear_dropres(a, w, fb, p, seed, row0, out=fb)
+        old2 = res.clone()
+        ops.lora_dropout(ops.linear(a, w), p, seed, row0, mode=3, out=old2)
+        assert torch.equal(fb, old2)
+    finally:
+        ops.set_gemm_mode(3)
+    assert _lib.load().afx_gemm_dropres_available() == 1

@@ -100,6 +100,29 @@ def test_g5_layouts(golden):
     close(out, g['x_end_tok'])
 
 
+def _check_g9(step, inp, g, rtol, atol):
+    """`step(x_tok, means_tok, logw_tok, logg_tok, sigma_src, sigma_end) -> x_end_tok` against fixture G9 (one FULL-SIZE step of the reference:
+    latent [1, 16, 128, 128], both steps of the 2-NFE schedule): the strided sample element by element, the fp64 moments over all 262 144 outputs."""
+    stride = int(g['stride'])
+    for i in range(2):
+        s_src, s_end = float(g[f'case{i}_sigma_src']), float(np.float32(g[f'case{i}_t_end']) / 1000)
+        out = step(inp['x_tok'], inp['means_tok'], inp['logw_tok'], inp['logg_tok'], s_src, s_end).detach().cpu().reshape(-1)
+        assert out.numel() == 4096 * 64
+        ref = T(g[f'case{i}_sample'])
+        err = (out[::stride].double() - ref.double()).abs().max().item()
+        assert torch.allclose(out[::stride].double(), ref.double(), rtol=rtol, atol=atol), (i, err)
+        n = out.numel()
+        assert abs(out.double().sum().item() - float(g[f'case{i}_sum'])) <= atol * n ** 0.5 * 4, i
+        ssq = float(g[f'case{i}_sumsq'])
+        assert abs((out.double() ** 2).sum().item() - ssq) <= 4 * rtol * ssq + 1e-3, i
+        assert abs(out.abs().max().item() - float(g[f'case{i}_absmax'])) <= 1e-4 * float(g[f'case{i}_absmax']), i
+
+
+def test_g9_step_full_size(golden_full_size_inputs):
+    inp, g = golden_full_size_inputs
+    _check_g9(lambda x, m, lw, lg, s0, s1: R.momentum_step_packed(x, m, lw, lg, s0, s0, s1), inp, g, rtol=2e-6, atol=2e-6)
+
+
 def test_g6_misc(golden):
     g = golden('g6_misc')
     for tag, p in (('01', 0.1), ('97', 0.97)):

@@ -130,6 +130,41 @@ def test_attention_production_shapes(B, S, H):
     assert per_head.max().item() < 1.5e-2, per_head
 
 
+@pytest.mark.parametrize('B,S,H', [(1, 4608, 24), (1, 4224, 24), (1, 4133, 24), (2, 1101, 24)])
+def test_attention_backward_production_shapes(B, S, H):
+    """The generated backward streams (fused 864 + 864 work-group grid, list-scheduled XCD order, head -> XCD map: they only exist at H = 24) against the
+    ANALYTIC fp32 backward of softmax attention evaluated by torch on the device, 4 heads at a time (at these shapes the backward
+    had only been compared with the round-4 kernels).  dV = P^T dO, dP = dO V^T, dS = P (dP - rowsum(dO O)), dQ = dS K / sqrt(d), dK = dS^T Q / sqrt(d) --
+    what SDPA's autograd computes under the reference's attention processor (arcflux.py:181-189).  Per-head bounds: a wrong head -> XCD map or
+    work-group order shows up as ONE bad head, not as a small global error."""
+    from arcflow_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(S + 7)
+    q, k, v, do = (torch.randn(B, S, H, 128, generator=g, device='cuda').bfloat16() for _ in range(4))
+    o, lse = ops.attention_fwd_lse(q, k, v)
+    dq, dk, dv = ops.attention_bwd(q, k, v, o.reshape(B, S, H, 128), do, lse)
+    torch.cuda.synchronize()
+    qf, kf, vf, dof = (t.float().transpose(1, 2) for t in (q, k, v, do))          # [B, H, S, 128]
+    rq, rk, rv = (torch.empty(B, H, S, 128, device='cuda') for _ in range(3))
+    sc = 128 ** -0.5
+    for h0 in range(0, H, 4):
+        hs = slice(h0, h0 + 4)
+        p = torch.softmax(torch.matmul(qf[:, hs], kf[:, hs].transpose(-1, -2)) * sc, dim=-1)
+        of = torch.matmul(p, vf[:, hs])
+        rv[:, hs] = torch.matmul(p.transpose(-1, -2), dof[:, hs])
+        dp = torch.matmul(dof[:, hs], vf[:, hs].transpose(-1, -2))
+        dp.sub_((dof[:, hs] * of).sum(-1, keepdim=True)).mul_(p).mul_(sc)          # dS / sqrt(d), in place (340 MB per buffer at S = 4608)
+        rq[:, hs] = torch.matmul(dp, kf[:, hs])
+        rk[:, hs] = torch.matmul(dp.transpose(-1, -2), qf[:, hs])
+        del p, dp, of
+    for name, got, ref, tol in (('dv', dv, rv, 1.5e-2), ('dq', dq, rq, 2e-2), ('dk', dk, rk, 2e-2)):
+        got = got.float().reshape(B, S, H, 128).transpose(1, 2)
+        assert torch.isfinite(got).all(), name
+        err = ((got - ref).norm() / ref.norm()).item()
+        assert err < tol, (name, err)
+        per_head = (got - ref).norm(dim=(2, 3)) / ref.norm(dim=(2, 3))
+        assert per_head.max().item() < 1.25 * tol, (name, per_head)
+
+
 # ------------------------------------------------------------------------------------------ the whole network
 def _unpack_single(P, i, D, nd):
     """diffusers-keyed fp32 weights of single block i from the packed engine tensors (inverse of weights.pack_flux)."""

@@ -157,7 +157,11 @@ def main():
     while dist_.iteration < total:
         cond = next(loader) if loader is not None else synth
         info = dist_.train_step(cond, B, rng=rng)
-        checkpoint.check_pending_save()        # a background save that failed stops the run now
+        # a background save that failed stops the run now -- on EVERY rank: only the writer's rank sees the error, the others would otherwise walk into the
+        # next gradient all-reduce and sit there until the RCCL timeout.  One scalar MAX-reduce per iteration (an iteration is seconds).
+        if dist_.reducer.all_reduce_max(1.0 if checkpoint.pending_save_failed() else 0.0, dev) > 0:
+            checkpoint.check_pending_save()
+            raise RuntimeError(f'rank {rank}: the checkpoint writer of another rank failed (see its log): stopping')
         if rank == 0:
             now = time.perf_counter()
             print(json.dumps(dict(iter=dist_.iteration, time=round(now - t_last, 3), **{k: (round(v, 6) if isinstance(v, float) else v) for k, v in info.items()})), flush=True)
