@@ -22,7 +22,11 @@ ASM_OWNED = {'afx_attn3.hip': ('attention_v3_kernel', 96), 'afx_attn_bwd3.hip': 
 # kernels whose accumulators are written by inline-asm MFMAs the compiler cannot see into: a register spill there may store an accumulator straight
 # behind the MFMA that is still writing it (happened to gemm_kernel_v3f8 once its epilogue grew) -- they must not use scratch at all
 NO_SCRATCH = {'afx_gemm.hip': ['gemm_kernel_v3f8', 'gemm_kernel_v3ILi8ELi8ELb0ELi0E', 'gemm_kernel_v3ILi8ELi7ELb0ELi0E', 'gemm_kernel_v3ILi7ELi8ELb0ELi0E',
-                               'gemm_kernel_v3ILi9ELi6ELb0ELi0E', 'gemm_kernel_v3ILi4ELi4ELb0ELi0E']}
+                               'gemm_kernel_v3ILi9ELi6ELb0ELi0E', 'gemm_kernel_v3sILi4ELi4ELb0ELi0E']}
+# gemm_kernel_v3 / gemm_kernel_v3s (round 6): the accumulator file is asm-owned (literal register names in every MFMA and every epilogue read, afx_gemm.hip
+# v3_mfma_lit / AccLit) and `amdgpu_num_vgpr` confines hipcc to the arch VGPRs: no compiler-generated instruction may touch an accumulator register
+ACC_OWNED = {'afx_gemm.hip': {'gemm_kernel_v3I': 0, 'gemm_kernel_v3sI': 32}}        # kernel -> first asm-owned accumulator register (hipcc may use the ones below)
+
 
 
 def audit_no_scratch(asm_path: str, kernel_substrs) -> None:
@@ -44,6 +48,42 @@ def audit_no_scratch(asm_path: str, kernel_substrs) -> None:
     missing = [k for k, n in seen.items() if n == 0]
     if missing:       # a listed instantiation that no longer exists (a changed template signature) would silently drop out of the audit
         raise RuntimeError(f'{asm_path}: the scratch audit found no kernel matching {missing}: update NO_SCRATCH in arcflow_amd/build.py')
+
+
+def audit_acc_owned(asm_path: str, kernels) -> None:
+    """Kernels whose accumulator file is asm-owned from register `base` up (kernels: name substring -> base): outside ASMSTART / ASMEND no instruction may name
+    an accumulator register a<n> / a[n:m] with m >= base (hipcc is free to park its own values below base)."""
+    import re
+    reg = re.compile(r'\ba(\d+)\b|\ba\[\d+:(\d+)\]')
+    base = None
+    in_asm = False
+    seen = {k: 0 for k in kernels}
+    bad = []
+    with open(asm_path) as f:
+        for n, line in enumerate(f, 1):
+            t = line.strip()
+            label = t.split(';')[0].strip()
+            if label.endswith(':') and not label.startswith('.L') and label:
+                hits = [k for k in kernels if k in label]
+                base = kernels[hits[0]] if hits else None
+                for k in hits:
+                    seen[k] += 1
+            if base is None or not t:
+                continue
+            if 'ASMSTART' in t:
+                in_asm = True
+            elif 'ASMEND' in t:
+                in_asm = False
+            elif not in_asm and t[0] not in ';.':
+                for m in reg.finditer(t.split(';')[0]):
+                    if int(m.group(1) or m.group(2)) >= base:
+                        bad.append(f'{n}: {t}')
+                        break
+    missing = [k for k, c in seen.items() if c == 0]
+    if missing:
+        raise RuntimeError(f'{asm_path}: the accumulator audit found no kernel matching {missing}: update ACC_OWNED in arcflow_amd/build.py')
+    if bad:
+        raise RuntimeError(f'{asm_path}: compiler-generated code touches the asm-owned accumulator registers ({len(bad)} instructions):\n' + '\n'.join(bad[:20]))
 
 
 def lib_path() -> str:
@@ -139,6 +179,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             audit_asm_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), *ASM_OWNED[src])
         if src in NO_SCRATCH:
             audit_no_scratch(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), NO_SCRATCH[src])
+        if src in ACC_OWNED:
+            audit_acc_owned(os.path.join(objdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ACC_OWNED[src])
     cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out]
     if verbose:
         print('[arcflow_amd.build]', ' '.join(cmd), flush=True)
@@ -168,6 +210,8 @@ def build_variant(name: str, extra_flags, sources) -> str:
                 raise RuntimeError(f'hipcc failed on {src} ({name}):\n{r.stdout}')
             if src in ASM_OWNED:
                 audit_asm_owned(os.path.join(vdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), *ASM_OWNED[src])
+            if src in ACC_OWNED:
+                audit_acc_owned(os.path.join(vdir, src.replace('.hip', '-hip-amdgcn-amd-amdhsa-gfx950.s')), ACC_OWNED[src])
         objs.append(obj)
     out = os.path.join(LIBDIR, f'libarcflow_hip_{name}.so')
     r = subprocess.run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', *objs, '-o', out], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,

@@ -27,6 +27,7 @@
 #include <hip/hip_ext.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "afx_common.h"
 #include "afx_kernels.h"
@@ -162,8 +163,57 @@ AFX_DEV uint32_t drop_mix32(uint32_t h) {          // (= mix32 of afx_train.hip'
   h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
   return h;
 }
-template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false, bool GN = false, bool DROP = false>
-AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+// Compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}) -- the index is a constant expression inside the body
+// (the epilogues name accumulator tiles by it: AccLit below needs the register NUMBER in the instruction text).
+template <class F, int... I>
+AFX_DEV void static_for_(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+AFX_DEV void static_for(F&& f) { static_for_(f, std::make_integer_sequence<int, N>{}); }
+
+// Where a wave's fp32 accumulator tiles live, as the epilogues see them: tile (II, JJ) = 4 floats per lane.
+//   AccArr: a C++ array hipcc allocates (the 8-phase kernel, the fp8 kernel);
+//   AccLit: ASM-OWNED accumulator registers, tile (II, JJ) = a[BASE + 4 (II NJ + JJ) : + 3] by literal name (gemm_kernel_v3, round 6): hipcc does not know these
+//           registers exist, so a read is an `asm volatile` (ordered with the kernel's MFMA statements, which are volatile too) and the MFMA -> read wait
+//           states are the caller's business.
+template <int MI, int NJ>
+struct AccArr {
+  f32x4_t (&a)[MI][NJ];
+  template <int II, int JJ>
+  AFX_DEV void tile(float (&c)[4]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c[e] = a[II][JJ][e];
+  }
+};
+template <int NJ, int BASE = 0>
+struct AccLit {
+  template <int II, int JJ>
+  AFX_DEV void tile(float (&c)[4]) const {
+    constexpr int R = BASE + 4 * (II * NJ + JJ);
+    asm volatile("v_accvgpr_read_b32 %0, a%c4\n\tv_accvgpr_read_b32 %1, a%c5\n\tv_accvgpr_read_b32 %2, a%c6\n\tv_accvgpr_read_b32 %3, a%c7"
+                 : "=v"(c[0]), "=v"(c[1]), "=v"(c[2]), "=v"(c[3])
+                 : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
+  }
+};
+#define AFX_INL __attribute__((always_inline))
+
+// Tail hook (round 6, gemm_kernel_v3's V3_TAIL): the LAST K-tile's MFMAs are issued from inside the epilogue, row tile by row tile -- hk(-1) behind the
+// epilogue's preamble (row tile 0, under the latency of the bias / residual / gate requests), then ONE MFMA of row tile ii + 1 at each of the 4 NS "points" of
+// row tile ii's steps (behind the exchange, behind the bias add, behind the activation, behind the store), so the matrix pipe works under the epilogue's VALU
+// and store issue instead of in front of it.  Point code = ii * (4 NS) + 4 st + q.  hk.all() = every remaining MFMA at once (epilogues without points).
+struct NoHook {
+  template <int CODE>
+  AFX_DEV void at() const {}
+  AFX_DEV void all() const {}
+};
+template <class F>
+struct TailHook {
+  F f;                                             // a generic lambda taking std::integral_constant<int, CODE>
+  template <int CODE>
+  AFX_DEV void at() const { f(std::integral_constant<int, CODE>{}); }
+  AFX_DEV void all() const { f(std::integral_constant<int, -2>{}); }
+};
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8, bool PRE, bool ROWB, bool CONV, bool GN, bool DROP, class HK, class ACC>
+AFX_DEV void epi_store_fast_acc(const GemmProblem& P, const ACC& acc, int row_base, int col_base, int frow, int fq, const HK& hk) {
   constexpr int CW = SWAP ? 8 : 4;             // columns per lane and step
   constexpr int NS = SWAP ? (NJ + 1) / 2 : NJ; // steps per row tile (SWAP with an odd NJ: the last step pairs the lone column tile with
                                                // nothing -- the lanes that would own the missing tile's columns are masked out)
@@ -313,8 +363,9 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         gsq[st][h] = z;
       }
   }
-#pragma unroll
-  for (int ii = 0; ii < MI; ++ii) {
+  hk.template at<-1>();
+  static_for<MI>([&](auto ii_c) AFX_INL {
+    constexpr int ii = decltype(ii_c)::value;
     uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
     bool border = false;
     if constexpr (CONV) {
@@ -355,20 +406,24 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         fetch_gate(b, gi);
       }
     }
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    static_for<NS>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
       float v[CW];
+      float c0[4], c1[4] = {0.f, 0.f, 0.f, 0.f};
+      acc.template tile<ii, SWAP ? 2 * st : st>(c0);
+      if constexpr (SWAP && 2 * st + 1 < NJ) acc.template tile<ii, (2 * st + 1) % NJ>(c1);
       if constexpr (SWAP) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
-          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), 2 * st + 1 < NJ ? __float_as_uint(acc[ii][(2 * st + 1) % NJ][e]) : 0u, false, false);
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
           v[e] = __uint_as_float(sw[0]);
           v[4 + e] = __uint_as_float(sw[1]);
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[ii][st][e];
+        for (int e = 0; e < 4; ++e) v[e] = c0[e];
       }
+      hk.template at<(ii * NS + st) * 4 + 0>();
       if constexpr (FP8) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] *= asc[ii % (PF + 1)] * wsc[st][e];
@@ -382,6 +437,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
           v[e] += __uint_as_float((e & 1) ? (w & 0xffff0000u) : (w << 16));
         }
       }
+      hk.template at<(ii * NS + st) * 4 + 1>();
       if constexpr (EPI == EPI_GELU) {
         if (gcol[st] >= gelu_col0) {
 #pragma unroll
@@ -406,6 +462,7 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
           v[e] = CONV ? rr + v[e] : rr + (has_gate ? gi[st][e] : 1.0f) * v[e];       // no gate: plain residual add
         }
       }
+      hk.template at<(ii * NS + st) * 4 + 2>();
       if constexpr (CONV) {
 #pragma unroll
         for (int e = 0; e < CW; ++e) v[e] = border ? 0.f : v[e];
@@ -426,8 +483,9 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
         const u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         __builtin_amdgcn_raw_buffer_store_b64(o, rc, (int)(roff + coff[st]), 0, 0);
       }
-    }
-  }
+      hk.template at<(ii * NS + st) * 4 + 3>();
+    });
+  });
   if constexpr (GN) {
     if (P.gn_stats != nullptr) {                                  // (uniform)
       static_assert(SWAP && GQ <= 16, "one quantity per lane of a 16-lane row");
@@ -458,11 +516,16 @@ AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int ro
   }
 }
 
+template <int EPI, int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, bool ROWB = false, bool CONV = false, bool GN = false, bool DROP = false, class HK = NoHook>
+AFX_DEV void epi_store_fast(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq, const HK& hk = HK{}) {
+  epi_store_fast_acc<EPI, MI, NJ, SWAP, FP8, PRE, ROWB, CONV, GN, DROP, HK>(P, AccArr<MI, NJ>{acc}, row_base, col_base, frow, fq, hk);
+}
+
 // fp32 output of the weight-gradient products (GemmProblem::out_f32 1: store, 2: C += result; no bias / activation there): 8
 // consecutive columns per lane after the permlane exchange = two 16-byte accesses; rows >= M and masked columns dropped by the
 // bounds check.  The accumulate mode's read of C is requested one row tile ahead.
-template <int MI, int NJ>
-AFX_DEV void epi_store_f32(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+template <int MI, int NJ, class ACC>
+AFX_DEV void epi_store_f32_acc(const GemmProblem& P, const ACC& acc, int row_base, int col_base, int frow, int fq) {
   constexpr int NS = NJ / 2;
   constexpr uint32_t OOB = 0x80000000u;
   const int M = P.M, N = P.N;
@@ -492,16 +555,19 @@ AFX_DEV void epi_store_f32(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
     }
   };
   if (accum) fetch(0);
-#pragma unroll
-  for (int ii = 0; ii < MI; ++ii) {
+  static_for<MI>([&](auto ii_c) AFX_INL {
+    constexpr int ii = decltype(ii_c)::value;
     if (accum && ii + 1 < MI) fetch(ii + 1);
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc4);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    static_for<NS>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
       f32x4_t o0, o1;
+      float c0[4], c1[4];
+      acc.template tile<ii, 2 * st>(c0);
+      acc.template tile<ii, 2 * st + 1>(c1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
         o0[e] = __uint_as_float(sw[0]) + bias[st][e];
         o1[e] = __uint_as_float(sw[1]) + bias[st][4 + e];
       }
@@ -511,8 +577,12 @@ AFX_DEV void epi_store_f32(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o0), rc, (int)(roff + coff[st]), 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, o1), rc, (int)(roff + coff[st]) + 16, 0, 0);
-    }
-  }
+    });
+  });
+}
+template <int MI, int NJ>
+AFX_DEV void epi_store_f32(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+  epi_store_f32_acc<MI, NJ>(P, AccArr<MI, NJ>{acc}, row_base, col_base, frow, fq);
 }
 
 // (uniform) the forward's epilogue modes: bf16 out, no fp8 scales / convolution border / pre-add
@@ -523,8 +593,8 @@ AFX_DEV bool epi_is_fast(const GemmProblem& P) { return P.out_f32 == 0 && P.conv
 // its 32 values + those of the three other fq lanes are the 128 of the RMSNorm (two cross-lane adds); a chunk holds 4 whole
 // rotation pairs.  cos / sin of the NEXT row tile are requested before this one is finished.
 // FP8: the accumulators are first scaled by a_scale[row] * w_scale[col] (the fp8 kernels' products).
-template <int MI, bool FP8 = false>
-AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_base, int col_base, int frow, int fq, const float* wn) {
+template <int MI, bool FP8, class HK, class ACC>
+AFX_DEV void epi_store_qk_acc(const GemmProblem& P, const ACC& acc, int row_base, int col_base, int frow, int fq, const float* wn, const HK& hk) {
   constexpr uint32_t OOB = 0x80000000u;
   const int M = P.M, N = P.N;
   const int rows_ok = min(max(M - row_base, 0), MI * 16);
@@ -570,8 +640,9 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
     }
   };
   fetch(0, cs[0], sn[0]);
-#pragma unroll
-  for (int ii = 0; ii < MI; ++ii) {
+  hk.template at<-1>();
+  static_for<MI>([&](auto ii_c) AFX_INL {
+    constexpr int ii = decltype(ii_c)::value;
     if (ii + 1 < MI) fetch(ii + 1, cs[(ii + 1) & 1], sn[(ii + 1) & 1]);
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * ldc2);
     float v[4][8];
@@ -587,26 +658,31 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
         ws[st][1] = *reinterpret_cast<const f32x4_t*>(wscp + gc + 4);
       }
     }
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    static_for<4>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
+      float c0[4], c1[4];
+      acc.template tile<ii, 2 * st>(c0);
+      acc.template tile<ii, 2 * st + 1>(c1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {     // all 64 lanes take part in the exchange
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
         v[st][e] = __uint_as_float(sw[0]);
         v[st][4 + e] = __uint_as_float(sw[1]);
       }
+      hk.template at<ii * 16 + 2 * st + 0>();             // (tail hook: 16 points per row tile IN PROGRAM ORDER -- the hook issues MFMA p of the next row tile at point p: 8 in the sum-of-squares pass, 8 in the rotation pass)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         if constexpr (FP8) v[st][e] *= asc * ws[st][e >> 2][e & 3];
         v[st][e] += bias[st][e];
         ss += v[st][e] * v[st][e];
       }
-    }
+      hk.template at<ii * 16 + 2 * st + 1>();
+    });
     ss += __shfl_xor(ss, 16, 64);
     ss += __shfl_xor(ss, 32, 64);
     const float rstd = rsqrtf(ss * (1.0f / 128.0f) + 1e-6f);
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    static_for<4>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
       float r[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -616,44 +692,55 @@ AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_b
         r[2 * i] = a * c - b * s_;
         r[2 * i + 1] = a * s_ + b * c;
       }
+      hk.template at<ii * 16 + 8 + 2 * st + 0>();
       __builtin_amdgcn_raw_buffer_store_b128(pack8(r), rc, (int)(roff + coff[st]), 0, 0);
-    }
-  }
+      hk.template at<ii * 16 + 8 + 2 * st + 1>();
+    });
+  });
+}
+template <int MI, bool FP8 = false, class HK = NoHook>
+AFX_DEV void epi_store_qk(const GemmProblem& P, f32x4_t (&acc)[MI][8], int row_base, int col_base, int frow, int fq, const float* wn, const HK& hk = HK{}) {
+  epi_store_qk_acc<MI, FP8, HK>(P, AccArr<MI, 8>{acc}, row_base, col_base, frow, fq, wn, hk);
 }
 
 #ifndef V3_F32_EPI
 #define V3_F32_EPI 1
 #endif
-template <int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false>
-AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+template <int MI, int NJ, bool SWAP, bool FP8, bool PRE, class HK, class ACC>
+AFX_DEV void epi_store_fast_any_acc(const GemmProblem& P, const ACC& acc, int row_base, int col_base, int frow, int fq, const HK& hk) {
   if constexpr (NJ == 8 && SWAP && !PRE) {
     if (P.qk_D > 0) {                                            // (uniform) which 128-column head of k | v | q (| mlp) is this wave's?
       const int region = col_base / P.qk_D;
-      if (region == 0) { epi_store_qk<MI, FP8>(P, acc, row_base, col_base, frow, fq, P.qk_wk); return; }
-      if (region == 2) { epi_store_qk<MI, FP8>(P, acc, row_base, col_base, frow, fq, P.qk_wq); return; }
+      if (region == 0) { epi_store_qk_acc<MI, FP8, HK>(P, acc, row_base, col_base, frow, fq, P.qk_wk, hk); return; }
+      if (region == 2) { epi_store_qk_acc<MI, FP8, HK>(P, acc, row_base, col_base, frow, fq, P.qk_wq, hk); return; }
     }
   }
   if constexpr (SWAP && !FP8 && !PRE && V3_F32_EPI && !(MI == 8 && NJ == 4) && NJ % 2 == 0) {      // (8 x 4 is the 8-phase kernel's patch: it keeps its own)
-    if (P.out_f32 == 1 || P.out_f32 == 2) { epi_store_f32<MI, NJ>(P, acc, row_base, col_base, frow, fq); return; }
+    if (P.out_f32 == 1 || P.out_f32 == 2) { hk.all(); epi_store_f32_acc<MI, NJ>(P, acc, row_base, col_base, frow, fq); return; }
   }
   if (P.epi == EPI_GATE_RES) {
     if constexpr (SWAP && !FP8 && !PRE) {
-      if (P.drop_on) { epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, false, false, false, false, false, true>(P, acc, row_base, col_base, frow, fq); return; }
+      if (P.drop_on) { epi_store_fast_acc<EPI_GATE_RES, MI, NJ, SWAP, false, false, false, false, false, true, HK>(P, acc, row_base, col_base, frow, fq, hk); return; }
     }
-    epi_store_fast<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+    epi_store_fast_acc<EPI_GATE_RES, MI, NJ, SWAP, FP8, PRE, false, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
   } else if (P.epi == EPI_GELU) {
     // The per-lane test `column >= gelu_col0` made every one of the 32 steps its own basic block behind an exec-mask branch (a lone wave pays ~30 cycles of
     // refetch per taken branch, and no step overlaps the next one's exchange / loads): 14.6 k cycles per 256 x 256 tile against 10.2 k without GELU.  A wave's
     // columns are (in every launch of the forward) all activated or none: decide once, wave-uniformly, and run straight-line code.
 #ifndef AFX_GELU_PER_LANE         // (-DAFX_GELU_PER_LANE: the per-lane test everywhere, for A/B builds)
-    if (col_base >= P.gelu_col0) epi_store_fast<EPI_GELU_ALL, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
-    else if (col_base + 16 * NJ <= P.gelu_col0) epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+    if (col_base >= P.gelu_col0) epi_store_fast_acc<EPI_GELU_ALL, MI, NJ, SWAP, FP8, PRE, false, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
+    else if (col_base + 16 * NJ <= P.gelu_col0) epi_store_fast_acc<EPI_NONE, MI, NJ, SWAP, FP8, PRE, false, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
     else
 #endif
-    epi_store_fast<EPI_GELU, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+    epi_store_fast_acc<EPI_GELU, MI, NJ, SWAP, FP8, PRE, false, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
   }
-  else if (SWAP && !FP8 && !PRE && !(MI == 8 && NJ == 4) && P.bias_rows) epi_store_fast<EPI_NONE, MI, NJ, SWAP, false, false, true>(P, acc, row_base, col_base, frow, fq);
-  else epi_store_fast<EPI_NONE, MI, NJ, SWAP, FP8, PRE>(P, acc, row_base, col_base, frow, fq);
+  else if (SWAP && !FP8 && !PRE && !(MI == 8 && NJ == 4) && P.bias_rows) epi_store_fast_acc<EPI_NONE, MI, NJ, SWAP, false, false, true, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
+  else epi_store_fast_acc<EPI_NONE, MI, NJ, SWAP, FP8, PRE, false, false, false, false, HK>(P, acc, row_base, col_base, frow, fq, hk);
+}
+
+template <int MI, int NJ, bool SWAP, bool FP8 = false, bool PRE = false, class HK = NoHook>
+AFX_DEV void epi_store_fast_any(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq, const HK& hk = HK{}) {
+  epi_store_fast_any_acc<MI, NJ, SWAP, FP8, PRE, HK>(P, AccArr<MI, NJ>{acc}, row_base, col_base, frow, fq, hk);
 }
 
 template <bool FP8K = false>
@@ -1250,6 +1337,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
 #ifndef V3_EXP
 #define V3_EXP 0
 #endif
+#ifndef V3_TAIL              // 0: the last K-tile in front of the epilogue (round 5's schedule; A/B builds)
+#define V3_TAIL 1
+#endif
 #ifndef V3_EPI_SWAP          // 0: the 4-columns-per-lane epilogue without the permlane exchange (A/B builds; it has no masked residual add: gemm_dropres_available() is false there)
 #define V3_EPI_SWAP 1
 #endif
@@ -1259,6 +1349,36 @@ AFX_DEV uint64_t v3_uniform_u64(uint64_t v) {      // a wave-uniform 64-bit valu
   const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
+// ASM-OWNED accumulators (round 6): gemm_kernel_v3's 4 MI NJ fp32 accumulators per lane are a[0 : 4 MI NJ) BY LITERAL NAME -- tile (i, j) = a[4 (i NJ + j) : + 3] --
+// in every MFMA and every epilogue read (AccLit), and `amdgpu_num_vgpr` confines hipcc's own allocation to the arch VGPRs: hipcc does not know the accumulator
+// file is in use.  (With "+a" operands hipcc owned the placement: fine for ONE MFMA chain in front of the epilogue, but once the last K-tile's MFMAs were issued
+// from inside the epilogue branches -- V3_TAIL -- it moved tiles between registers around every MFMA, parked them in arch VGPRs and spilled accumulators, also in
+// the main loop.  Physical-register constraints "+{a[n:m]}" made it spill the tiles it could no longer move.)  What hipcc no longer does for us: the MFMA ->
+// accumulator-read wait states (explicit s_nop / program order below) and "parking" arch VGPRs in retired accumulator rows during the epilogue.
+// Which registers hipcc may still take: the arch VGPRs up to `amdgpu_num_vgpr`, and -- it allocates values that only move (copies, loads, stores) to either
+// file -- the accumulator registers from a0 up, as many as the launch bounds leave beside its arch VGPRs.  The big tiles (one work-group per CU) leave it no
+// reason to (arcflow_amd/build.py audits every build: no compiler-generated instruction may name an accumulator register at or above the kernel's BASE); the
+// 128 x 128 tile (two work-groups per CU: 256 registers per lane) gives it v[0:159] + a[0:31] and keeps its 64 accumulators at a[32:95].
+template <int TILE, int BASE>
+AFX_DEV void v3_mfma_lit(const bf16x8_t& a_, const bf16x8_t& b_) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"n"(BASE + 4 * TILE), "n"(BASE + 4 * TILE + 3), "v"(a_), "v"(b_));
+}
+template <int NACC, int BASE>
+AFX_DEV void v3_acc_zero() {      // + the clobber that makes the kernel descriptor allocate the accumulator file (hipcc counts only what it knows of)
+  static_assert((BASE == 0 && (NACC == 256 || NACC == 240 || NACC == 224 || NACC == 216 || NACC == 128)) || (BASE == 32 && NACC == 64), "add the clobber of this accumulator range");
+  if constexpr (NACC == 256) asm volatile("" ::: "a255");
+  else if constexpr (NACC == 240) asm volatile("" ::: "a239");
+  else if constexpr (NACC == 224) asm volatile("" ::: "a223");
+  else if constexpr (NACC == 216) asm volatile("" ::: "a215");
+  else if constexpr (NACC == 128) asm volatile("" ::: "a127");
+  else asm volatile("" ::: "a95");
+  static_for<NACC / 8>([&](auto c) AFX_INL {
+    constexpr int R = BASE + 8 * decltype(c)::value;
+    asm volatile("v_accvgpr_write_b32 a%c0, 0\n\tv_accvgpr_write_b32 a%c1, 0\n\tv_accvgpr_write_b32 a%c2, 0\n\tv_accvgpr_write_b32 a%c3, 0\n\t"
+                 "v_accvgpr_write_b32 a%c4, 0\n\tv_accvgpr_write_b32 a%c5, 0\n\tv_accvgpr_write_b32 a%c6, 0\n\tv_accvgpr_write_b32 a%c7, 0"
+                 ::"n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3), "n"(R + 4), "n"(R + 5), "n"(R + 6), "n"(R + 7));
+  });
+}
 constexpr int V3_THREADS = 256;
 constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (32 * NJ) * 128; }
 
@@ -1266,13 +1386,19 @@ constexpr int v3_lds_bytes(int MI, int NJ) { return 2 * (32 * MI) * 128 + 3 * (3
 // the CU count, a multiple of 8: the walk stays on the work-group's XCD chunk) and issues the NEXT tile's first four DMA batches
 // (A(0) W(0) W(1) A(1)) between its last K-tile and its epilogue, so their latency -- and the launch of a fresh work-group -- hide
 // behind the epilogue's stores.  VMEM operations retire in order: the epilogue's own residual loads then queue behind those batches.
-template <int MI, int NJ, bool CONV = false, int PERSIST = 0>      // PERSIST 1: next tile's DMA in front of the epilogue, 2: behind it; 3: no walk, ONE copy of the K-tile body (see the loop)
-__global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_kernel_v3(const GemmBatch batch) {
+template <int MI, int NJ, bool CONV, int PERSIST>      // PERSIST 1: next tile's DMA in front of the epilogue, 2: behind it; 3: no walk, ONE copy of the K-tile body (see the loop)
+AFX_DEV void gemm_v3_body(const GemmBatch& batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ;
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;          // bytes: rows of 64 bf16, chunk-swizzled like every tile here
   constexpr int NM = MI * NJ;                                  // MFMAs per k-half
   constexpr int W_SP = (NM / 2) / NJ, A_SP = (NM / 2) / MI;    // MFMAs between two DMA issues in the second half of a phase
   static_assert(4 * MI * NJ <= 256 && 2 * (MI + NJ) <= NM && W_SP >= 2 && A_SP >= 2, "v3 tile shape");
+  // TAIL (round 6): the last K-tile is not multiplied in front of the epilogue but FROM INSIDE it, row tile by row tile -- row tile 0 behind the
+  // epilogue's preamble, then one MFMA of row tile i + 1 at each of the 4 NS points of row tile i's steps (TailHook above) -- so 2 MI NJ - 2 NJ of the tile's last
+  // 2 MI NJ MFMAs run under the epilogue's VALU / store issue instead of in front of it.  Everything the last tile needs has landed at the mid-tile barrier of
+  // tile nk - 2 (or at the very first barrier for nk = 1), so the tail has no barrier and no wait of its own; accumulation order per accumulator is unchanged
+  // (k-half 0, then k-half 1 of the last tile): the results are bit-identical to the plain schedule (-DV3_TAIL=0).
+  constexpr bool TAIL = V3_TAIL != 0 && !CONV && PERSIST == 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const smem_w = smem + 2 * A_SLOT;
   const int tid = threadIdx.x;
@@ -1367,7 +1493,8 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + woff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
   };
 
-  f32x4_t acc[MI][NJ];
+  constexpr int ABASE = 4 * MI * NJ <= 64 ? 32 : 0;      // first accumulator register (v3_mfma_lit above)
+  const AccLit<NJ, ABASE> acc{};            // the accumulators: a[ABASE : ABASE + 4 MI NJ), asm-owned
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
 
@@ -1380,10 +1507,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
   // prologue: A(0) W(0) | W(1) A(1) stay in flight
   stage_a(0); stage_w(0); stage_w(1); stage_a(1);
   for (;;) {        // one pass per tile (PERSIST: the walk; otherwise left by the break behind the epilogue)
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  v3_acc_zero<4 * MI * NJ, ABASE>();
   // (PERSIST, second tile on: in-order retirement -- at most MI + NJ operations outstanding means the four batches issued in front of
   // the previous epilogue have landed, whatever that epilogue issued behind them)
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
@@ -1394,11 +1518,10 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #pragma unroll
   for (int i = 0; i < MI; ++i) a0[i] = lds_frag(smem, arow + i * 16, fq);
 
-  // The MFMAs are inline asm with the accumulator pinned to the accumulator file ("+a"): left to itself hipcc keeps part of the
-  // accumulators in arch VGPRs and shuttles them through v_accvgpr moves around every MFMA (452 moves per 128 MFMAs).  An asm
-  // statement with a "memory" clobber is also the ordering tool: the fragment reads and DMA issues written between two MFMAs
-  // stay there, which is the interleave sched_group_barrier would give for builtin MFMAs.
-#define V3_ONE(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+  // The MFMAs are inline asm on asm-owned accumulator registers (v3_mfma_lit above; left to itself hipcc keeps part of the accumulators in arch
+  // VGPRs and shuttles them through v_accvgpr moves around every MFMA: 452 moves per 128 MFMAs).  An asm statement with a "memory" clobber is also
+  // the ordering tool: the fragment reads and DMA issues written between two MFMAs stay there, which is the interleave sched_group_barrier would
+  // give for builtin MFMAs.  The m loops are compile-time loops (static_for): the tile index is part of the instruction text.
 #define V3_FENCE() asm volatile("" ::: "memory")
   // LDS-DMA in the SGPR-base + 32-bit-lane-offset form (hipcc widens the builtin's address to a 64-bit VGPR pair with a
   // v_lshl_add_u64 in front of every issue); M0 = LDS byte address of the wave's 1 KiB destination
@@ -1408,7 +1531,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
                : "memory", "m0")   /* M0 is compiler-reserved (the clobber entry draws a warning and is otherwise recorded as an   \
                                      implicit def): the prologue's builtin LDS-DMAs must never see a stale M0 */
   // MFMA m of a k-half: A row tile m / NJ, W column tile m % NJ (operands swapped: the accumulator holds C^T, see epi_store_fast)
-#define V3_MFMA_AT(m, AF, BF) V3_ONE(acc[(m) / NJ][(m) % NJ], BF[(m) % NJ], AF[(m) / NJ])
+#define V3_MFMA_AT(m, AF, BF) v3_mfma_lit<(m), ABASE>(BF[(m) % NJ], AF[(m) / NJ])          // (tile index of (row tile m / NJ, column tile m % NJ) = m)
 
   AFX_TRC(18)
   // Two copies of the K-tile body: tiles whose successor t+2 exists issue its DMA, the last two tiles issue nothing -- as a
@@ -1421,7 +1544,7 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
 #pragma unroll
   for (int part = 0; part < (PERSIST == 3 ? 1 : 2); ++part) {
   const bool more = part == 0;                 // a constant once the two parts are unrolled
-  const int t_end = (more && PERSIST != 3) ? nk - 2 : nk;
+  const int t_end = (more && PERSIST != 3) ? nk - 2 : (TAIL ? nk - 1 : nk);      // TAIL: the last K-tile's MFMAs are issued from inside the epilogue (below)
 #pragma unroll 1
   for (; t < t_end; ++t) {
     const char* sa = smem + (t & 1) * A_SLOT;
@@ -1431,8 +1554,8 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     {
       const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(PERSIST == 3 ? min(t + 2, nk - 1) : t + 2) * (BK * 2)));
       char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {          // one memory instruction at most between two MFMAs (12 free issue cycles)
+      static_for<NM>([&](auto m_c) AFX_INL {          // one memory instruction at most between two MFMAs (12 free issue cycles)
+        constexpr int m = decltype(m_c)::value;
         V3_MFMA_AT(m, a0, b0);
         V3_FENCE();
         if ((m & 1) && (m >> 1) < MI + NJ) {
@@ -1443,10 +1566,13 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
         }
         if (m >= NM / 2 && (m - NM / 2) % W_SP == 1 && (m - NM / 2) / W_SP < NJ && V3_EXP != 1) {
           const int q = (m - NM / 2) / W_SP;
-          if (more) V3_DMA(wsrc_u, woff[q], wdst + (q * V3_THREADS + wave * 64) * 16);
+          const uint64_t src_ = wsrc_u;             // (locals: operands of an asm statement inside a generic lambda do not capture by themselves)
+          const uint32_t off_ = woff[q];
+          char* const dst_ = wdst + (q * V3_THREADS + wave * 64) * 16;
+          if (more) V3_DMA(src_, off_, dst_);
         }
         V3_FENCE();
-      }
+      });
     }
     // ---- mid-tile: every LDS read of tile t is done; W(t+1), A(t+1) have landed (W(t+2), just issued, may still fly)
     AFX_TR(1)
@@ -1461,29 +1587,33 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
       char* adst = smem + (t & 1) * A_SLOT;
       const char* na = smem + ((t + 1) & 1) * A_SLOT;
       const char* nw = smem_w + ((t + 1) % 3) * W_SLOT;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
+      static_for<NM>([&](auto m_c) AFX_INL {
+        constexpr int m = decltype(m_c)::value;
         V3_MFMA_AT(m, a1, b1);
         V3_FENCE();
         if ((m & 1) && (m >> 1) < MI + NJ) {
           const int r = m >> 1;               // (past the last tile: re-reads a landed slot, unused)
           if (V3_EXP == 2) {
+          } else if (TAIL && !more) {          // (the tail reads the last tile's fragments itself, a few MFMAs ahead of their use: nothing of them is live across the epilogue's preamble)
           } else if (r < NJ) b0[r] = lds_frag(nw, brow + r * 16, fq);
           else a0[r - NJ] = lds_frag(na, arow + (r - NJ) * 16, fq);
         }
         if (m >= NM / 2 && (m - NM / 2) % A_SP == 1 && (m - NM / 2) / A_SP < MI && V3_EXP != 1) {
           const int q = (m - NM / 2) / A_SP;
-          if (more) V3_DMA(asrc_u, aoff[q], adst + (q * V3_THREADS + wave * 64) * 16);
+          const uint64_t src_ = asrc_u;
+          const uint32_t off_ = aoff[q];
+          char* const dst_ = adst + (q * V3_THREADS + wave * 64) * 16;
+          if (more) V3_DMA(src_, off_, dst_);
         }
         V3_FENCE();
-      }
+      });
     }
     AFX_TR(4)
   }
   }
   AFX_TRC(19)
   // MFMA -> accumulator-read wait states hipcc cannot see inside the asm (nothing is in flight any more: the last two tiles issue no DMA)
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
+  if constexpr (!TAIL) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
   {   // lane constants of the epilogue from an OPAQUE copy of threadIdx: otherwise they are hoisted above the main loop (all 512
       // registers are spoken for there) and the accumulators get shuffled through v_accvgpr moves to make room
     int tid2 = threadIdx.x;
@@ -1509,13 +1639,74 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     if constexpr (PERSIST == 1) next_tile();
     AFX_TRC(20)
     if constexpr (CONV) {      // bias (+ residual) + re-zeroing of the border pixels: the output grid is the next layer's padded input
-      if (P.epi == EPI_GATE_RES) epi_store_fast<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
-      else epi_store_fast<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4)>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
+      if (P.epi == EPI_GATE_RES) epi_store_fast_acc<EPI_GATE_RES, MI, NJ, true, false, false, false, true, (NJ <= 4), false, NoHook>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2, NoHook{});
+      else epi_store_fast_acc<EPI_NONE, MI, NJ, true, false, false, false, true, (NJ <= 4), false, NoHook>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2, NoHook{});
     } else
 #ifdef V3_NO_EPI      // timing bound only (WRONG results: nothing is stored): what hiding the WHOLE epilogue behind matrix work could buy at most (profiles/r05b_gemm_no_epilogue_bound.txt)
     asm volatile("" ::"v"(frow2), "v"(fq2), "s"(m0e), "s"(n0e));
 #else
-    epi_store_fast_any<MI, NJ, V3_EPI_SWAP != 0>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2);
+    if constexpr (TAIL) {
+      // tile nk - 1: its k-half-0 fragments are in a0 / b0 (read during k-half 1 of tile nk - 2, or in front of the loop for nk = 1); the k-half-1
+      // fragments are read here -- W's behind the first NJ MFMAs of row tile 0, row tile i + 1's A fragment behind MFMA NJ of row tile i (one LDS
+      // read at most behind an MFMA, as in the loop)
+      const char* const sa_l = smem + ((nk - 1) & 1) * A_SLOT;
+      const char* const sw_l = smem_w + ((nk - 1) % 3) * W_SLOT;
+      constexpr int PER_ROW = 2 * NJ;                                  // MFMAs per row tile: k-half 0 then k-half 1, column tiles in order
+      constexpr int PTS = 4 * (V3_EPI_SWAP != 0 ? (NJ + 1) / 2 : NJ);  // hook points per row tile (>= PER_ROW)
+      static_assert(PTS >= PER_ROW, "one MFMA per hook point");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (nothing in flight for nk >= 2; nk = 1: the prologue's clamped re-fetches must not outlive the work-group's LDS)
+      // Register budget: the epilogues' own state (bias, RMSNorm weights, cos / sin, residual and gate words: up to ~160 VGPRs) sits beside ALL 256 accumulators
+      // until row tiles retire, so the tail holds no fragment array: W fragments stream through a ring of RING registers (read RING MFMAs ahead of their use --
+      // every row tile re-reads its 2 NJ W fragments: 2 NJ + 2 LDS reads per row tile against 2 NJ MFMAs), A fragments one row tile ahead.
+      const int arow2 = wr2 * (16 * MI) + frow2, brow2 = wc2 * (16 * NJ) + frow2;      // (from the opaque thread id: nothing of the tail's addressing may be live across the main loop -- it has no register to spare)
+      constexpr int RING = 4;
+      bf16x8_t tb[RING], ta0[MI], ta1[MI];
+      auto b_of = [&](int g) {                                         // W fragment of tail MFMA g = row * PER_ROW + m
+        const int m = g % PER_ROW;
+        return lds_frag(sw_l, brow2 + (m % NJ) * 16, (m < NJ ? 0 : 4) + fq2);
+      };
+      auto prime = [&]() {                                             // (inside the chosen epilogue, behind its preamble: nothing of the ring is live across the mode dispatch)
+#pragma unroll
+        for (int g = 0; g < RING; ++g) tb[g] = b_of(g);
+        ta0[0] = lds_frag(sa_l, arow2, fq2);
+        ta1[0] = lds_frag(sa_l, arow2, 4 + fq2);
+      };
+      auto tail_mfma = [&](auto row_c, auto m_c) AFX_INL {
+        constexpr int row = decltype(row_c)::value, m = decltype(m_c)::value, g = row * PER_ROW + m;
+        if constexpr (m < NJ) v3_mfma_lit<row * NJ + m % NJ, ABASE>(tb[g % RING], ta0[row]);
+        else v3_mfma_lit<row * NJ + m % NJ, ABASE>(tb[g % RING], ta1[row]);
+        V3_FENCE();
+        if constexpr (g + RING < MI * PER_ROW) tb[g % RING] = b_of(g + RING);
+        if constexpr (m == NJ - 2 && row + 1 < MI) ta0[row + 1] = lds_frag(sa_l, arow2 + (row + 1) * 16, fq2);
+        if constexpr (m == NJ + 2 && row + 1 < MI) ta1[row + 1] = lds_frag(sa_l, arow2 + (row + 1) * 16, 4 + fq2);
+        V3_FENCE();
+      };
+      // MFMA -> accumulator-read wait states (hipcc cannot see the dependency): a step's reads of row tile ii's tiles (2 st, 2 st + 1) come >= 6 MFMAs behind the
+      // MFMA that finished them (k-half 1 of column tile j is MFMA NJ + j of the row tile, issued at point NJ + j of row tile ii - 1; the reads of step st sit behind
+      // point 4 (NS - 1) + 3 of that row tile and in front of point 4 st of this one) -- each independent MFMA holds the issue port >= 4 cycles, so >= 24 cycles
+      // against the 18 the 8-pass MFMA needs; the un-hooked path and the last points of a row tile carry explicit s_nops.
+      auto hook = [&](auto code_c) AFX_INL {
+        constexpr int code = decltype(code_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (code == -1) {                                    // row tile 0, behind the epilogue's preamble
+          prime();
+          static_for<PER_ROW>([&](auto m_c) AFX_INL { tail_mfma(std::integral_constant<int, 0>{}, m_c); });
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");           // (row tile 0's last MFMAs -> its first step's reads)
+        } else if constexpr (code == -2) {                             // everything (an epilogue without hook points), then the MFMA -> accumulator-read wait states
+          prime();
+          static_for<MI>([&](auto r_c) AFX_INL { static_for<PER_ROW>([&](auto m_c) AFX_INL { tail_mfma(r_c, m_c); }); });
+          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        } else {
+          constexpr int row = code / PTS + 1, m = code % PTS;
+          if constexpr (row < MI && m < PER_ROW) tail_mfma(std::integral_constant<int, row>{}, std::integral_constant<int, m>{});
+          if constexpr (row < MI && m == PTS - 1) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // (the row tile's last MFMAs -> the next step's reads: see above)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const TailHook<decltype(hook)> hk{hook};
+      epi_store_fast_any_acc<MI, NJ, V3_EPI_SWAP != 0, false, false, TailHook<decltype(hook)>>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2, hk);
+    } else
+    epi_store_fast_any_acc<MI, NJ, V3_EPI_SWAP != 0, false, false, NoHook>(P, acc, m0e + wr2 * (16 * MI), n0e + wc2 * (16 * NJ), frow2, fq2, NoHook{});
 #endif
 #ifdef AFX_GEMM_TRACE
     AFX_TRC(21)
@@ -1528,6 +1719,18 @@ __global__ __launch_bounds__(V3_THREADS, (4 * MI * NJ <= 64 ? 2 : 1)) void gemm_
     if (!has_next) break;
   }
   }
+}
+// `amdgpu_num_vgpr` takes a literal: one kernel per register budget.  gemm_kernel_v3: one work-group per CU, hipcc in v[0:255], up to 256 accumulators;
+// gemm_kernel_v3s: the 128 x 128 tile, TWO work-groups per CU (256 registers per lane: hipcc's v[0:159] + a[0:31], 64 accumulators a[32:95]).
+template <int MI, int NJ, bool CONV = false, int PERSIST = 0>
+__global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))) void gemm_kernel_v3(const GemmBatch batch) {
+  static_assert(4 * MI * NJ > 64, "the small tile runs as gemm_kernel_v3s");
+  gemm_v3_body<MI, NJ, CONV, PERSIST>(batch);
+}
+template <int MI, int NJ, bool CONV = false, int PERSIST = 0>
+__global__ __launch_bounds__(V3_THREADS, 2) __attribute__((amdgpu_num_vgpr(160))) void gemm_kernel_v3s(const GemmBatch batch) {
+  static_assert(4 * MI * NJ <= 64, "two work-groups per CU: 64 accumulators at most");
+  gemm_v3_body<MI, NJ, CONV, PERSIST>(batch);
 }
 
 // fp8 GEMM -> block-scaled fp8 output (GemmProblem::c8): a wave's 128 columns are ONE block of the next GEMM's A operand.  Per row tile: the
@@ -1880,6 +2083,11 @@ LaunchTimer& launch_timer() {
   return t;
 }
 
+#ifdef V3_KERNELS_ONLY      // experiment builds (register-allocation turnarounds in seconds, never the product): `-DV3_KERNELS_ONLY="8,8,false,0"` compiles ONE instance of
+template __global__ void gemm_kernel_v3<V3_KERNELS_ONLY>(const GemmBatch);      // gemm_kernel_v3 and none of the launchers
+template __global__ void gemm_kernel_v3s<4, 4, false, 0>(const GemmBatch);
+}  // namespace afx
+#else
 // ---- tile shape / kernel choice -------------------------------------------------------------------------------------------
 struct GemmMode { int impl = -1, tile = 0; };
 bool gemm_qk_fusion_available();
@@ -1940,17 +2148,18 @@ static int count_tiles(GemmBatch& batch, int tm, int tn, bool fill) {
 template <int MI, int NJ, bool CONV = false, int PERSIST = 0>
 static hipError_t launch_v3_impl(GemmBatch& batch, int total, hipStream_t stream) {
   static bool attr = false;
+  void (*kern)(const GemmBatch);
+  if constexpr (4 * MI * NJ <= 64) kern = gemm_kernel_v3s<MI, NJ, CONV, PERSIST>;
+  else kern = gemm_kernel_v3<MI, NJ, CONV, PERSIST>;
   if (!attr) {
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel_v3<MI, NJ, CONV, PERSIST>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       v3_lds_bytes(MI, NJ));
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, v3_lds_bytes(MI, NJ));
     if (r != hipSuccess) return r;
     attr = true;
   }
   if (launch_timer().start != nullptr && launch_timer().stop != nullptr)
-    hipExtLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV, PERSIST>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start,
-                          launch_timer().stop, 0, batch);
+    hipExtLaunchKernelGGL(kern, dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, launch_timer().start, launch_timer().stop, 0, batch);
   else
-    hipLaunchKernelGGL((gemm_kernel_v3<MI, NJ, CONV, PERSIST>), dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
+    hipLaunchKernelGGL(kern, dim3(total), dim3(V3_THREADS), v3_lds_bytes(MI, NJ), stream, batch);
   return hipGetLastError();
 }
 
@@ -1976,13 +2185,9 @@ static hipError_t launch_v3(GemmBatch& batch, int total, hipStream_t stream) {
   if constexpr (!CONV) {
     if (gemm_persist() == 1 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 1>(batch, slots, stream);
     if (gemm_persist() == 2 && total > slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
-  } else {
-    // the VAE's convolutions: thousands of tiles with 18-72 K-tiles each (K = taps x channel chunks): the per-tile prologue is a large share of a tile, which
-    // is the case the persistent walk was built for (AFX_CONV_PERSIST=1|2: next tile's first DMA batches in front of / behind the epilogue; round 5 A/B)
-    static const int cp = [] { const char* e = getenv("AFX_CONV_PERSIST"); return e ? atoi(e) : 0; }();
-    if (cp == 1 && total > 2 * slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 1>(batch, slots, stream);
-    if (cp == 2 && total > 2 * slots && slots % 8 == 0) return launch_v3_impl<MI, NJ, CONV, 2>(batch, slots, stream);
   }
+  // (The VAE's convolutions ran the persistent walk as an A/B in round 5 -- AFX_CONV_PERSIST, measured level, profiles/r05*: with the accumulator file asm-owned
+  // (round 6) those instances no longer fit hipcc's arch VGPRs and it parked values in accumulator registers: dropped rather than shipped unsafe.)
   return launch_v3_impl<MI, NJ, CONV, 0>(batch, total, stream);
 }
 
@@ -2274,3 +2479,4 @@ hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream) {
 }
 
 }  // namespace afx
+#endif      // V3_KERNELS_ONLY

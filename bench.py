@@ -287,7 +287,7 @@ def parse_args(argv=None):
     ap.add_argument('--student-fp8', action='store_true', help='--train: the student forward / recompute linears on the fp8 MFMA, gradients bf16 (configs[4]); says so in dtype')
     ap.add_argument('--teacher-fp8', action='store_true', help='--train: frozen teacher forwards on the fp8 MFMA (configs[4]); the line says so in dtype')
     ap.add_argument('--streams', type=int, default=1, help='images in flight per GPU (one HIP stream + engine context each, shared weights); '
-                                                           '1 = the canonical line, 2 fills the under-filled last rounds: +3.8 % (r02)')
+                                                           '1 = the canonical line, 2 fills the under-filled last rounds: +3.8 %% (r02)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='N = 1 FLUX run: skip the extra objects (Qwen inference, the two distillation iterations, prompt -> image)')
     ap.add_argument('--e2e', action='store_true', help='only the prompt -> image object of --model (encoders + 2 NFE + VAE)')
