@@ -29,7 +29,7 @@ EXPORTS = [
     'afx_linear_bf16_pre', 'afx_linear_bf16_sk', 'afx_linear_sk_ws_bytes', 'afx_linear_sk_last_split', 'afx_gemm_set_mode', 'afx_gemm_dropres_available', 'afx_attn_set_impl', 'afx_attn_bwd_set_impl', 'afx_mmdit_prepare_steps', 'afx_mmdit_use_prepared_step', 'afx_lora_dropout_bf16', 'afx_mmdit_forward_stage', 'afx_mmdit_import_tokens',
     'afx_coldot_bf16', 'afx_gate_residual_bf16', 'afx_gemv_t_bf16', 'afx_set_temb_override', 'afx_set_fp8_linear',
     'afx_arcflow_step_dropout', 'afx_arcflow_backward', 'afx_mse_loss', 'afx_euler_roll', 'afx_axpby_rows', 'afx_cfg_combine',
-    'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_linear_tn_f32out', 'afx_linear_bf16_dropres', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward', 'afx_normout_backward_split',
+    'afx_head_grad', 'afx_linear_bf16_f32out', 'afx_linear_tn_f32out', 'afx_linear_tn_f32out_ws', 'afx_linear_tn_ws_bytes', 'afx_linear_bf16_dropres', 'afx_transpose_bf16', 'afx_colsum_bf16', 'afx_normout_backward', 'afx_normout_backward_split',
     'afx_outer_accum', 'afx_mmdit_export', 'afx_sumsq', 'afx_adamw_step', 'afx_adamw8bit_step', 'afx_ema_lerp', 'afx_cast_f32_bf16',
 ]
 
@@ -153,6 +153,9 @@ def load() -> C.CDLL:
     lib.afx_head_grad.argtypes = [vp, vp, vp, vp, vp, i64, i64, i32, i32, i32, vp]
     lib.afx_linear_bf16_f32out.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
     lib.afx_linear_tn_f32out.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp]
+    lib.afx_linear_tn_f32out_ws.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, vp, vp]
+    lib.afx_linear_tn_ws_bytes.argtypes = [i32, i32, i32]
+    lib.afx_linear_tn_ws_bytes.restype = i64
     lib.afx_linear_bf16_dropres.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, f32, C.c_uint32, i64, vp]
     lib.afx_transpose_bf16.argtypes = [vp, i64, vp, i64, i32, i32, vp]
     lib.afx_colsum_bf16.argtypes = [vp, i64, vp, i32, i32, vp]

@@ -938,6 +938,22 @@ int afx_linear_tn_f32out(const void* X, int64_t ldx, const void* Y, int64_t ldy,
   return AFX_OK;
 }
 
+int64_t afx_linear_tn_ws_bytes(int32_t M, int32_t N1, int32_t N2) {
+  if (M < 0 || N1 < 0 || N2 < 0) return fail(AFX_E_INVALID, "bad shape to afx_linear_tn_ws_bytes");
+  return gemm_tn_ws_bytes(M, N1, N2);
+}
+
+int afx_linear_tn_f32out_ws(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
+                            int32_t accumulate, void* ws, void* stream) {
+  if (!X || !Y || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_tn_f32out_ws");
+  if (M < 0 || N1 < 0 || N2 < 0 || N1 % 8 || N2 % 8 || ldx % 8 || ldy % 8 || ldc % 4 || ldx < N1 || ldy < N2 || ldc < N2)
+    return fail(AFX_E_INVALID, "afx_linear_tn_f32out_ws: need N1%%8==0, N2%%8==0, ldx/ldy%%8==0, ldc%%4==0, leading dimensions >= the widths");
+  if (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)C | (uintptr_t)ws) & 15) return fail(AFX_E_INVALID, "afx_linear_tn_f32out_ws: operands must be 16-byte aligned");
+  if (!ws && gemm_tn_ws_bytes(M, N1, N2) > 0) return fail(AFX_E_INVALID, "afx_linear_tn_f32out_ws: this shape needs afx_linear_tn_ws_bytes() of workspace");
+  HIP_TRY(launch_gemm_tn_f32((const uint16_t*)X, ldx, (const uint16_t*)Y, ldy, C, ldc, M, N1, N2, accumulate, (hipStream_t)stream, (float*)ws));
+  return AFX_OK;
+}
+
 int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ldw, float* C, int64_t ldc, int32_t M,
                            int32_t N, int32_t K, int32_t accumulate, void* stream) {
   if (!A || !W || !C) return fail(AFX_E_INVALID, "null argument to afx_linear_bf16_f32out");

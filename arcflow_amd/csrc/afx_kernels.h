@@ -92,7 +92,9 @@ struct GemmBatch {
 hipError_t launch_gemm(GemmBatch& batch, hipStream_t stream);
 // C (fp32) [N1, N2] (+)= X^T Y with X [M, N1], Y [M, N2] token-major bf16 (afx_tn.hip: LDS transpose reads; the LoRA weight gradients without transposed copies)
 hipError_t launch_gemm_tn_f32(const uint16_t* X, int64_t ldx, const uint16_t* Y, int64_t ldy, float* C, int64_t ldc, int M, int N1, int N2, int accumulate,
-                              hipStream_t stream);
+                              hipStream_t stream, float* ws = nullptr);      // ws: gemm_tn_ws_bytes() bytes (token split, round 6) or nullptr (one work-group per tile)
+int gemm_tn_ksplit(int M, int N1, int N2);
+int64_t gemm_tn_ws_bytes(int M, int N1, int N2);
 bool gemm_conv_stats_available();           // GemmProblem::gn_stats is honoured (kernel mode 3, no forced tile shape)
 bool gemm_qk_fusion_available();            // the launcher would take a problem with qk_D > 0 (kernel mode 3, no stream-K request)
 bool gemm_dropres_available();              // ... a problem with drop_on (the LoRA branch's masked residual add in the epilogue)

@@ -11,6 +11,9 @@
 // Tile 128 (n1) x 128 (n2) x 64 tokens, 4 waves (2 x 2) of 64 x 64, two LDS stages of 16 KB X + 16 KB Y (64 KB: two work-groups per CU).  16-byte chunk c of
 // token row r sits at physical chunk c ^ f(r), f(r) = 2 (r % 4) + 8 ((r / 8) % 2): the 8 rows x 2 chunks a half-wave's transpose read touches are 16 distinct
 // chunks = all 64 banks once.  Deterministic: a tile is owned by one work-group, the token loop runs in order (no split over tokens, no atomics).
+#include <algorithm>
+#include <cstdlib>
+
 #include <hip/hip_runtime.h>
 
 #include "afx_common.h"
@@ -25,14 +28,22 @@ constexpr int LDS_BYTES = 4 * TILE_BYTES;             // (X, Y) x 2 stages
 
 AFX_DEV int swz(int row) { return 2 * (row & 3) + 8 * ((row >> 3) & 1); }
 
+// Token split (round 6): a [3072, 256] gradient is 48 tiles for 256 CUs x 2 resident work-groups, and the launch takes as long as ONE work-group's walk over
+// all 4608 tokens.  With ksplit > 1 the grid is tiles x ksplit: work-group (tile, s) contracts K-steps [s per, (s + 1) per) and stores its fp32 partial tile
+// into slab s of a workspace ([ksplit][N1][N2], no accumulate); tn_reduce_kernel then adds the slabs IN ORDER s = 0, 1, ... into C (deterministic: the
+// summation tree is fixed by the shape, no atomics).
 __global__ __launch_bounds__(THREADS, 2) void gemm_tn_f32_kernel(const bf16_t* __restrict__ X, int64_t ldx, const bf16_t* __restrict__ Y, int64_t ldy,
-                                                                 float* __restrict__ C, int64_t ldc, int M, int N1, int N2, int tiles2, int accumulate) {
+                                                                 float* __restrict__ C, int64_t ldc, int M, int N1, int N2, int tiles2, int accumulate,
+                                                                 int ksplit, int per, int64_t slab_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 1, wc = wave & 1;             // this wave's 64 n1 columns (wr) x 64 n2 columns (wc)
-  const int n1_0 = (blockIdx.x / tiles2) * BM, n2_0 = (blockIdx.x % tiles2) * BN;
-  const int nk = (M + BK - 1) / BK;
+  const int tile = blockIdx.x / ksplit, split = blockIdx.x - tile * ksplit;
+  const int n1_0 = (tile / tiles2) * BM, n2_0 = (tile % tiles2) * BN;
+  const int nk_all = (M + BK - 1) / BK;
+  const int t_lo = split * per, nk = min(nk_all, t_lo + per);      // this work-group's K-steps [t_lo, nk)
+  C += (int64_t)split * slab_stride;                                // (slab_stride = 0 without a split)
 
   // ---- LDS-DMA sources: instruction j of a wave moves rows 16 wave + 4 j .. + 3 (1 KB); lane l -> row + l / 16, physical chunk l % 16 = logical chunk (l % 16) ^ f(row)
   uint32_t xoff[4], yoff[4];        // byte offsets of this lane's 16 bytes relative to token row k0 (rows clamped per K-step through the base pointer: see stage())
@@ -77,9 +88,9 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_f32_kernel(const bf16_t* _
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[p][q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-  stage(0);
+  stage(t_lo);
 #pragma unroll 1
-  for (int t = 0; t < nk; ++t) {
+  for (int t = t_lo; t < nk; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // tile t has landed (this wave's pieces; the barrier makes it everybody's)
     __syncthreads();                                       // ... and every wave is done reading the other stage
     if (t + 1 < nk) stage(t + 1);
@@ -135,10 +146,41 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_tn_f32_kernel(const bf16_t* _
   }
 }
 
+// C[n1][n2] (+)= slab[0][n1][n2] + slab[1][n1][n2] + ... in this order; 4 floats per thread
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ slabs, int64_t slab_stride, int ksplit, float* __restrict__ C, int64_t ldc, int N1,
+                                                        int N2, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int q = N2 >> 2;
+  if (idx >= (int64_t)N1 * q) return;
+  const int n1 = (int)(idx / q), n2 = (int)(idx - (int64_t)n1 * q) * 4;
+  const float* src = slabs + (int64_t)n1 * N2 + n2;
+  f32x4_t v = *reinterpret_cast<const f32x4_t*>(src);
+  for (int s_ = 1; s_ < ksplit; ++s_) v += *reinterpret_cast<const f32x4_t*>(src + (int64_t)s_ * slab_stride);
+  float* dst = C + (int64_t)n1 * ldc + n2;
+  if (accumulate) v += *reinterpret_cast<const f32x4_t*>(dst);
+  *reinterpret_cast<f32x4_t*>(dst) = v;
+}
+
 }  // namespace tn
 
+// How many ways the token loop of a [N1, N2] product over M tokens is cut (1: no split, no workspace): fill the 2 x CUs work-group slots, at least 4 K-steps each.
+int gemm_tn_ksplit(int M, int N1, int N2) {
+  static const int forced = [] { const char* e = getenv("AFX_TN_SPLIT"); return e ? atoi(e) : -1; }();      // 0 / 1: never split (A/B), n: force n ways
+  const int tiles = ((N1 + tn::BM - 1) / tn::BM) * ((N2 + tn::BN - 1) / tn::BN), nk = (M + tn::BK - 1) / tn::BK;
+  if (forced == 0 || forced == 1 || N2 % 4 || tiles <= 0 || nk < 8) return 1;
+  int want = forced > 1 ? forced : 512 / tiles;
+  want = std::min(want, nk / 4);
+  if (want < 2) return 1;
+  const int per = (nk + want - 1) / want;
+  return (nk + per - 1) / per;
+}
+int64_t gemm_tn_ws_bytes(int M, int N1, int N2) {
+  const int ks = gemm_tn_ksplit(M, N1, N2);
+  return ks > 1 ? (int64_t)ks * N1 * N2 * 4 : 0;
+}
+
 hipError_t launch_gemm_tn_f32(const uint16_t* X, int64_t ldx, const uint16_t* Y, int64_t ldy, float* C, int64_t ldc, int M, int N1, int N2, int accumulate,
-                              hipStream_t stream) {
+                              hipStream_t stream, float* ws) {
   if (M <= 0 || N1 <= 0 || N2 <= 0) return hipSuccess;
   if (N1 % 8 || N2 % 8 || ldx % 8 || ldy % 8 || ldc % 4 || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(Y) & 15) ||
       (reinterpret_cast<uintptr_t>(C) & 15))
@@ -149,8 +191,19 @@ hipError_t launch_gemm_tn_f32(const uint16_t* X, int64_t ldx, const uint16_t* Y,
     if (r != hipSuccess) return r;
     attr = true;
   }
-  const int tiles1 = (N1 + tn::BM - 1) / tn::BM, tiles2 = (N2 + tn::BN - 1) / tn::BN;
-  hipLaunchKernelGGL(tn::gemm_tn_f32_kernel, dim3(tiles1 * tiles2), dim3(tn::THREADS), tn::LDS_BYTES, stream, X, ldx, Y, ldy, C, ldc, M, N1, N2, tiles2, accumulate);
+  const int tiles1 = (N1 + tn::BM - 1) / tn::BM, tiles2 = (N2 + tn::BN - 1) / tn::BN, nk = (M + tn::BK - 1) / tn::BK;
+  const int ks = ws != nullptr ? gemm_tn_ksplit(M, N1, N2) : 1;
+  if (ks <= 1) {
+    hipLaunchKernelGGL(tn::gemm_tn_f32_kernel, dim3(tiles1 * tiles2), dim3(tn::THREADS), tn::LDS_BYTES, stream, X, ldx, Y, ldy, C, ldc, M, N1, N2, tiles2, accumulate, 1,
+                       nk, (int64_t)0);
+    return hipGetLastError();
+  }
+  if (reinterpret_cast<uintptr_t>(ws) & 15) return hipErrorInvalidValue;
+  const int per = (nk + ks - 1) / ks;
+  const int64_t slab = (int64_t)N1 * N2;
+  hipLaunchKernelGGL(tn::gemm_tn_f32_kernel, dim3(tiles1 * tiles2 * ks), dim3(tn::THREADS), tn::LDS_BYTES, stream, X, ldx, Y, ldy, ws, (int64_t)N2, M, N1, N2, tiles2, 0, ks,
+                     per, slab);
+  hipLaunchKernelGGL(tn::tn_reduce_kernel, dim3((unsigned)((slab / 4 + 255) / 256)), dim3(256), 0, stream, ws, slab, ks, C, ldc, N1, N2, accumulate);
   return hipGetLastError();
 }
 

@@ -337,7 +337,9 @@ def linear_tn_f32out(x, y, out=None, accumulate: bool = False):
     assert y.shape[0] == M and x.stride(1) == 1 and y.stride(1) == 1
     if out is None:
         out = torch.zeros(N1, N2, dtype=torch.float32, device=x.device)
-    _lib.check(lib.afx_linear_tn_f32out(_p(x), x.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), M, N1, N2, int(accumulate), _s()))
+    nws = lib.afx_linear_tn_ws_bytes(M, N1, N2)       # > 0: the token loop is cut into runs (fp32 partial tiles in ws, added in a fixed order: deterministic)
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device) if nws > 0 else None      # (from the current stream's pool: private until the launches have run)
+    _lib.check(lib.afx_linear_tn_f32out_ws(_p(x), x.stride(0), _p(y), y.stride(0), _p(out), out.stride(0), M, N1, N2, int(accumulate), _p(ws), _s()))
     return out
 
 

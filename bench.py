@@ -113,11 +113,11 @@ def cpu_baseline(budget_s: float = 12.0):
 
 # the bf16 block GEMMs of the forward: two instantiations of one kernel template -- 256x224 tiles for the N = 3072 / 12288 launches (96 per
 # forward), 256x256 for the k|q|v^T and the single blocks' fused launches (57); the events cover every launch (AFX_GEMM_IMPL=2: gemm_kernel_v2<false>)
-GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 7, false> + afx::gemm_kernel_v3<8, 8, false>'
+GEMM_KERNEL_NAME = 'afx::gemm_kernel_v3<8, 7, false, 0> + afx::gemm_kernel_v3<8, 8, false, 0>'      # (as rocprofv3 prints them: MI, NJ, CONV, PERSIST)
 if os.environ.get('AFX_GEMM_IMPL', '3')[:1] == '2':
     GEMM_KERNEL_NAME = 'afx::gemm_kernel_v2<false>'
 # --fp8: the one-wave-per-SIMD fp8 kernel, plain (row-scaled operands out of LayerNorm) and block-scaled (v_mfma_scale) instances; AFX_FP8_V3=0: the 8-phase kernel
-FP8_KERNEL_NAME = 'afx::gemm_kernel_v2<true>' if os.environ.get('AFX_FP8_V3', '1')[:1] == '0' else 'afx::gemm_kernel_v3f8<8, 8, false> + afx::gemm_kernel_v3f8<8, 8, true>'
+FP8_KERNEL_NAME = 'afx::gemm_kernel_v2<true>' if os.environ.get('AFX_FP8_V3', '1')[:1] == '0' else 'afx::gemm_kernel_v3f8<8, 8, false> + afx::gemm_kernel_v3f8<8, 8, true> + afx::gemm_kernel_v3f8<7, 8, false> + afx::gemm_kernel_v3f8<7, 8, true>'
 POWER_CAPPED_MFMA_TF = 1950.0
 
 

@@ -206,6 +206,13 @@ int afx_linear_bf16_f32out(const void* A, int64_t lda, const void* W, int64_t ld
  * no transposed copies (ds_read_b64_tr_b16 gathers the MFMA fragments out of LDS).  N1, N2 multiples of 8; deterministic (no atomics). */
 int afx_linear_tn_f32out(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
                          int32_t accumulate, void* stream);
+/* The same product with the TOKEN loop split over work-groups (round 6): a [3072, 256] gradient is 48 tiles for 512 work-group slots, so each tile's 4608
+ * tokens are cut into afx_linear_tn_ws_bytes() / (4 N1 N2) runs whose fp32 partial tiles go to `ws` and are then added IN ORDER into C by a second launch --
+ * deterministic (the summation tree depends on the shape only), no atomics.  ws: afx_linear_tn_ws_bytes(M, N1, N2) bytes, 16-byte aligned, private to the
+ * call until it has run (0 bytes = this shape runs unsplit; ws may then be NULL).  Same reference as above (peft lora_A / lora_B gradients, arcflux.py:294-302). */
+int64_t afx_linear_tn_ws_bytes(int32_t M, int32_t N1, int32_t N2);
+int afx_linear_tn_f32out_ws(const void* X, int64_t ldx, const void* Y, int64_t ldy, float* C, int64_t ldc, int32_t M, int32_t N1, int32_t N2,
+                            int32_t accumulate, void* ws, void* stream);
 /* C = res + (A . W^T) . keep / (1 - p): the input gradient of peft's LoRA branch with lora_dropout, dx = dx0 + ((dy B) A) . mask, in ONE launch -- the mask
  * (the counter hash of afx_lora_dropout_bf16: seed, row0 + row, column) is applied to the fp32 product in the GEMM's epilogue; res may alias C.  bf16. */
 int afx_linear_bf16_dropres(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int32_t M, int32_t N, int32_t K,

@@ -322,8 +322,14 @@ def test_linear_tn_f32out_matches_transposed_products(ops, M, N1, N2):
     if True:                                                                   # the round-4 formulation: same products, fp32 accumulation in another order
         old = ops.linear_f32out(ops.transpose(x.contiguous(), 64), ops.transpose(y.contiguous(), 64))
         assert (out - old).abs().max().item() <= 2e-5 * scale * (M / 64) ** 0.5
-    # deterministic: a second launch is bit-identical
+    # deterministic: a second launch is bit-identical (also with the token loop split over work-groups: partial tiles added in a fixed order)
     assert torch.equal(out, ops.linear_tn_f32out(x, y))
+    from arcflow_amd import _lib
+    nws = _lib.load().afx_linear_tn_ws_bytes(M, N1, N2)
+    if (M, N1, N2) in ((4608, 3072, 256), (4096, 256, 3072), (4608, 256, 15360)):
+        assert nws > 0 and nws % (4 * N1 * N2) == 0 and nws // (4 * N1 * N2) >= 2         # the LoRA gradient shapes take the split
+    if M <= 130:
+        assert nws == 0                                                                    # too few K-steps to cut
 
 
 @pytest.mark.parametrize('M,N,K,p', [(4608, 3072, 256, 0.05), (512, 12288, 256, 0.05), (130, 192, 64, 0.3), (4096, 15360, 256, 0.0)])

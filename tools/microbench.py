@@ -42,6 +42,28 @@ def gemm():
               f'   (torch/hipBLASLt {2*M*N*K/ref/1e12:7.1f} TF)')
 
 
+def tn():
+    print('--- TN product (LoRA weight gradients): C[N1,N2] += X[M,N1]^T Y[M,N2], fp32 out')
+    import os
+    for M, N1, N2 in [(4608, 3072, 256), (4608, 256, 3072), (4608, 12288, 256), (4608, 256, 12288), (4608, 256, 15360), (512, 3072, 256), (4096, 12288, 256),
+                      (18432, 3072, 256), (18432, 256, 3072), (18432, 12288, 256)]:
+        x = torch.randn(M, N1, device='cuda').bfloat16()
+        y = torch.randn(M, N2, device='cuda').bfloat16()
+        out = torch.zeros(N1, N2, device='cuda')
+        dt = timeit(lambda: ops.linear_tn_f32out(x, y, out=out, accumulate=True))
+        lib = __import__('arcflow_amd')._lib.load()
+        ks = lib.afx_linear_tn_ws_bytes(M, N1, N2) // (4 * N1 * N2)
+        print(f'M={M:5d} N1={N1:5d} N2={N2:5d}  {dt*1e6:8.1f} us {2*M*N1*N2/dt/1e12:7.1f} TF   token split {ks}')
+    print('--- rank-256 forward products (128x128 tiles / split-K): t = x A^T')
+    for M, K in [(4608, 3072), (4608, 12288), (4608, 15360), (4096, 3072), (512, 3072), (18432, 3072), (18432, 12288)]:
+        x = torch.randn(M, K, device='cuda').bfloat16()
+        w = (torch.randn(256, K, device='cuda') * 0.02).bfloat16()
+        out = torch.empty(M, 256, device='cuda', dtype=torch.bfloat16)
+        dt = timeit(lambda: ops.linear(x, w, out=out))
+        dk = timeit(lambda: ops.linear_splitk(x, w, out=out, split_k=8))
+        print(f'M={M:5d} N=  256 K={K:5d}  plain {dt*1e6:8.1f} us {2*M*256*K/dt/1e12:7.1f} TF | split-K 8 {dk*1e6:8.1f} us {2*M*256*K/dk/1e12:7.1f} TF')
+
+
 def gemm8():
     print('--- fp8 (e4m3, row-wise scales) linear vs the bf16 kernel')
     for M, N, K in [(4608, 9216, 3072), (4608, 21504, 3072), (4608, 3072, 15360), (4608, 12288, 3072), (4608, 3072, 3072), (4608, 3072, 12288),
