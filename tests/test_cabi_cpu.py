@@ -52,6 +52,16 @@ def test_argument_validation_no_gpu(lib):
     assert lib.afx_linear_bf16_dropres(None, 64, None, 64, None, 8, 1, 8, 64, None, 8, 0.05, 1, 0, None) == -1
     assert lib.afx_linear_bf16_dropres(C.c_void_p(4096), 64, C.c_void_p(8192), 64, C.c_void_p(16384), 8, 1, 8, 64, C.c_void_p(16384), 8, 1.5, 1, 0, None) == -1   # p >= 1
     assert lib.afx_normout_backward_split(None, 8, None, 8, None, None, 1, 8, None) == -1
+    # round-6: the token-split TN product: workspace sizes are a host-side function of the shape; the _ws entry refuses a missing / misaligned workspace before any launch
+    if os.environ.get('AFX_TN_SPLIT') is None:
+        assert lib.afx_linear_tn_ws_bytes(4608, 3072, 256) == 9 * 3072 * 256 * 4          # 48 tiles -> 9 runs of 8 K-steps
+        assert lib.afx_linear_tn_ws_bytes(4608, 12288, 256) == 2 * 12288 * 256 * 4
+        assert lib.afx_linear_tn_ws_bytes(130, 64, 192) == 0 and lib.afx_linear_tn_ws_bytes(1, 8, 8) == 0
+        assert lib.afx_linear_tn_f32out_ws(C.c_void_p(4096), 3072, C.c_void_p(8192), 256, C.c_void_p(16384), 256, 4608, 3072, 256, 0, None, None) == -1     # needs a workspace
+        assert b'workspace' in lib.afx_last_error()
+    assert lib.afx_linear_tn_ws_bytes(-1, 8, 8) == -1
+    assert lib.afx_linear_tn_f32out_ws(None, 8, None, 8, None, 8, 64, 8, 8, 0, None, None) == -1
+    assert lib.afx_linear_tn_f32out_ws(C.c_void_p(4096), 8, C.c_void_p(8192), 8, C.c_void_p(16384), 8, 64, 8, 8, 0, C.c_void_p(4096 + 4), None) == -1   # misaligned workspace
     # round-6: the capability query behind ops.linear_dropres' fallback follows the kernel choice (host-side state only)
     if os.environ.get('AFX_GEMM_IMPL', '3') == '3' and os.environ.get('AFX_GEMM_SK', '0') == '0':
         assert lib.afx_gemm_dropres_available() == 1

@@ -221,6 +221,30 @@ def test_attention_kv_split_of_the_last_round(ops, B, S, H):
     assert (outs[0][1] - outs[3][1]).abs().max().item() < 2e-3
 
 
+def test_attention_plan_cache_is_bounded_and_plans_survive_eviction(ops):
+    """Prompt lengths vary batch to batch in training (S = T + N): the per-(B, H, S, stream) work tables of the balanced grid live in a cache of at most 16 plans,
+    the least recently used one is freed when a new shape arrives, a new plan is uploaded on the launch stream.  20 distinct lengths, then the first one again (its plan was
+    evicted and is rebuilt): every result equals the plain grid's up to the double rounding of merged rows, and device memory does not grow with the number of shapes."""
+    H = 24
+    g = torch.Generator(device='cuda').manual_seed(5)
+    lengths = [4608 - 64 * i for i in range(20)] + [4608, 4544]
+    qkv = {S: tuple(torch.randn(1, S, H, 128, generator=g, device='cuda').bfloat16() for _ in range(3)) for S in set(lengths)}
+    ops.set_attn_impl(3)
+    ref = {S: ops.attention(*qkv[S]).float() for S in set(lengths)}
+    ops.set_attn_impl(0)
+    torch.cuda.synchronize()
+    free0 = None
+    for n, S in enumerate(lengths):
+        out = ops.attention(*qkv[S]).float()
+        assert torch.isfinite(out).all()
+        assert rel_l2(out, ref[S]) < 4e-3, S
+        if n == 17:                                   # the cache is full (16 plans): from here on every new shape must free an old plan
+            torch.cuda.synchronize()
+            free0 = torch.cuda.mem_get_info()[0]
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20)        # a plan is <= ~26 MB; an unbounded cache would have grown by four more
+
+
 def test_attention_hand_over_fallback_when_partials_never_arrive(ops, monkeypatch):
     """HIP promises no dispatch order: a long part that does not see its block's partials published must still produce the right rows.  With
     AFX_ATTN_HANDOVER=lost the long parts act as if no flag were ever raised and compute their whole key range from zero (the short ends' work is
