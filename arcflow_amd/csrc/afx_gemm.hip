@@ -1333,7 +1333,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
 // tools/gemm_trace.hip: 2664 -> 2376 cycles per K-tile from the interleave alone; the 8-phase kernel: 2440).
 //   * LDS = A x 2 slots + W x 3 slots: W(t+2) goes to the slot W(t-1) left at mid-tile t-1 (1.5 tiles ahead of its first read),
 //     A(t+2) to the slot A(t) leaves at mid-tile t (one tile ahead).
-//   * epilogue: the bf16 modes of epi_store_fast only -- the launcher keeps every other mode on the 8-phase kernel.
+//   * epilogue: epi_store_fast_any_acc on the asm-owned accumulator file (AccLit); round 6: the last K-tile's MFMAs are issued from inside it (TAIL, below).
 #ifndef V3_EXP
 #define V3_EXP 0
 #endif
@@ -1646,9 +1646,8 @@ AFX_DEV void gemm_v3_body(const GemmBatch& batch) {
     asm volatile("" ::"v"(frow2), "v"(fq2), "s"(m0e), "s"(n0e));
 #else
     if constexpr (TAIL) {
-      // tile nk - 1: its k-half-0 fragments are in a0 / b0 (read during k-half 1 of tile nk - 2, or in front of the loop for nk = 1); the k-half-1
-      // fragments are read here -- W's behind the first NJ MFMAs of row tile 0, row tile i + 1's A fragment behind MFMA NJ of row tile i (one LDS
-      // read at most behind an MFMA, as in the loop)
+      // tile nk - 1 is multiplied from here on: ALL of its fragments are read by the tail itself (the loop's second copy no longer pre-reads them), a few MFMAs
+      // ahead of their use, out of the slots tile nk - 1 landed in
       const char* const sa_l = smem + ((nk - 1) & 1) * A_SLOT;
       const char* const sw_l = smem_w + ((nk - 1) % 3) * W_SLOT;
       constexpr int PER_ROW = 2 * NJ;                                  // MFMAs per row tile: k-half 0 then k-half 1, column tiles in order
