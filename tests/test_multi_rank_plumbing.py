@@ -82,3 +82,19 @@ def test_train_cli_launcher_pytorch_two_ranks(tmp_path):
     logs = _json_lines(r.stdout)
     assert [l['iter'] for l in logs] == [1, 2] and all(l['loss'] == l['loss'] for l in logs)
     assert (tmp_path / 'w' / 'checkpoints' / 'iter_2.pth').exists()
+
+
+def test_background_checkpoint_failure_stops_both_ranks(tmp_path):
+    """A background save that fails on the writer's rank (here: its temporary file's name is taken by a directory) must stop EVERY rank at the next
+    iteration: the failure flag is MAX-reduced each iteration, so rank 1 raises too instead of waiting in the next gradient all-reduce
+    for the collective's timeout."""
+    cfgp = tmp_path / 'tiny.py'
+    cfgp.write_text(_TINY_CFG.replace('interval=2', 'interval=1').replace('total_iters = 2', 'total_iters = 6'))
+    ck = tmp_path / 'w' / 'checkpoints'
+    (ck / 'iter_1.pth.tmp').mkdir(parents=True)
+    r = _torchrun([os.path.join(ROOT, 'tools', 'train.py'), str(cfgp), '--launcher', 'pytorch', '--diff_seed', '--synthetic', '--work-dir',
+                   str(tmp_path / 'w'), '--latent-tokens', '8', '8', '--iters', '6'], timeout=600)
+    assert r.returncode != 0
+    assert 'checkpoint writer of another rank failed' in r.stderr or 'IsADirectoryError' in r.stderr, r.stderr[-3000:]
+    assert 'checkpoint writer of another rank failed' in r.stderr, r.stderr[-3000:]       # the rank that does not own the writer stopped by itself
+    assert not (ck / 'iter_6.pth').exists()
