@@ -25,7 +25,7 @@ NO_SCRATCH = {'afx_gemm.hip': ['gemm_kernel_v3f8', 'gemm_kernel_v3ILi8ELi8ELb0EL
                                'gemm_kernel_v3ILi9ELi6ELb0ELi0E', 'gemm_kernel_v3sILi4ELi4ELb0ELi0E']}
 # gemm_kernel_v3 / gemm_kernel_v3s (round 6): the accumulator file is asm-owned (literal register names in every MFMA and every epilogue read, afx_gemm.hip
 # v3_mfma_lit / AccLit) and `amdgpu_num_vgpr` confines hipcc to the arch VGPRs: no compiler-generated instruction may touch an accumulator register
-ACC_OWNED = {'afx_gemm.hip': {'gemm_kernel_v3I': 0, 'gemm_kernel_v3sI': 32}}        # kernel -> first asm-owned accumulator register (hipcc may use the ones below)
+ACC_OWNED = {'afx_gemm.hip': {'gemm_kernel_v3I': 0, 'gemm_kernel_v3sI': 32, 'gemm_kernel_v3f8I': 0}}        # kernel -> first asm-owned accumulator register (hipcc may use the ones below)
 
 
 

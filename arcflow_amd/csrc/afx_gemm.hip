@@ -1736,13 +1736,13 @@ __global__ __launch_bounds__(V3_THREADS, 2) __attribute__((amdgpu_num_vgpr(160))
 // 32 values a lane owns (4 steps x 8 columns after the permlane exchange) are finished in fp32 (scales, bias, GELU), their absolute maximum
 // is combined over the 4 lanes of the row (two cross-lane exchanges), and the row's 128 values leave as e4m3 bytes (8 per lane and step)
 // with one E8M0 byte.  Half the store traffic of the bf16 epilogue and no quantisation pass behind it.
-template <bool GELU, int MI, int NJ>
-AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row_base, int col_base, int frow, int fq) {
+template <bool GELU, int MI, int NJ, class HK, class ACC>
+AFX_DEV void epi_store_mx8(const GemmProblem& P, const ACC& acc, int row_base, int col_base, int frow, int fq, const HK& hk) {
   static_assert(NJ == 8, "one wave = 128 columns = one scale block");
   constexpr int NS = NJ / 2;
   constexpr uint32_t OOB = 0x80000000u;
   const int M = P.M, N = P.N;
-  if (col_base >= N) return;                         // (uniform) a wave past the last column owns no block: its scale byte would land in the next row
+  if (col_base >= N) { hk.all(); return; }           // (uniform) a wave past the last column owns no block: its scale byte would land in the next row (the tail's MFMAs still run: uniform control flow for the hook's LDS reads)
   const int rows_ok = min(max(M - row_base, 0), MI * 16);
   const int64_t ldc8 = P.ldc8;
   __amdgpu_buffer_rsrc_t rc = uniform_rsrc(P.c8 + (int64_t)row_base * ldc8, (int)(rows_ok * ldc8));
@@ -1761,20 +1761,25 @@ AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
     if (P.bias != nullptr && col_ok) unpack8(*reinterpret_cast<const u32x4_t*>(P.bias + gcol), bias[st]);
   }
   float asc_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, frow * 4, 0, 0));
-#pragma unroll
-  for (int ii = 0; ii < MI; ++ii) {
+  hk.template at<-1>();
+  static_for<MI>([&](auto ii_c) AFX_INL {
+    constexpr int ii = decltype(ii_c)::value;
     const float asc = asc_n;
     if (ii + 1 < MI) asc_n = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, ((ii + 1) * 16 + frow) * 4, 0, 0));
     float v[NS][8];
     float amax = 0.f;
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    static_for<NS>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
+      float c0[4], c1[4];
+      acc.template tile<ii, 2 * st>(c0);
+      acc.template tile<ii, 2 * st + 1>(c1);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[ii][2 * st][e]), __float_as_uint(acc[ii][2 * st + 1][e]), false, false);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(c0[e]), __float_as_uint(c1[e]), false, false);
         v[st][e] = __uint_as_float(sw[0]);
         v[st][4 + e] = __uint_as_float(sw[1]);
       }
+      hk.template at<ii * 16 + 2 * st + 0>();          // (tail hook: 16 points per row tile in program order, 8 in this pass, 8 in the packing pass)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float x = v[st][e] * (asc * wsc[st][e]) + bias[st][e];
@@ -1783,20 +1788,23 @@ AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
         v[st][e] = x;
         amax = fmaxf(amax, fabsf(x));
       }
-    }
+      hk.template at<ii * 16 + 2 * st + 1>();
+    });
     amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
     amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
     const int eb = mx_exp(amax);
     const float inv = mx_inv(eb);
     const uint32_t roff = (uint32_t)((ii * 16 + frow) * (int)ldc8);
-#pragma unroll
-    for (int st = 0; st < NS; ++st) {
+    static_for<NS>([&](auto st_c) AFX_INL {
+      constexpr int st = decltype(st_c)::value;
       uint32_t w0, w1;
       mx_pack8(v[st], inv, w0, w1);
+      hk.template at<ii * 16 + 8 + 2 * st + 0>();
       __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){w0, w1}, rc, (int)(roff + coff[st]), 0, 0);
-    }
+      hk.template at<ii * 16 + 8 + 2 * st + 1>();
+    });
     if (fq == 0) __builtin_amdgcn_raw_buffer_store_b8((uint8_t)eb, rm, (ii * 16 + frow) * (int)P.ld_cmx + blk, 0, 0);
-  }
+  });
 }
 
 // =================================================================================================
@@ -1822,7 +1830,7 @@ AFX_DEV void epi_store_mx8(const GemmProblem& P, f32x4_t (&acc)[MI][NJ], int row
 // the group's second tile: in-order retirement makes the next mid-tile wait cover them); the byte is picked by op_sel, so the loop is
 // unrolled over the 4 tiles of a group.  K % 512 == 0.
 template <int MI, int NJ, bool MX = false>
-__global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatch batch) {
+__global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))) void gemm_kernel_v3f8(const GemmBatch batch) {
   constexpr int TM = 32 * MI, TN = 32 * NJ, KB = 128;          // K-tile: 128 fp8 values = 128 bytes per row
   constexpr int A_SLOT = TM * 128, W_SLOT = TN * 128;
   constexpr int NH = NJ / 2, NM = MI * NH;                     // column tiles / MFMAs per phase
@@ -1885,7 +1893,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(src + woff[i]), (lds_void_t*)(dst + (i * V3_THREADS + wave * 64) * 16), 16, 0, 0);
   };
 
-  f32x4_t acc[MI][NJ];
+  const AccLit<NJ, 0> acc{};              // the accumulators: a[0 : 4 MI NJ), asm-owned as in gemm_kernel_v3 (round 6): tile (i, j) = a[4 (i NJ + j) : + 3]
   const int frow = lane & 15, fq = lane >> 4;
   const int arow = wr * (16 * MI) + frow, brow = wc * (16 * NJ) + frow;
   // ---- MX: scale bytes of this lane's MI row tiles, 4 K-tiles per dword --------------------------------------------------------
@@ -1916,10 +1924,7 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   };
   if constexpr (MX) mx_fetch(sc_nxt, 0);          // in front of the prologue's DMA: the wait for A(0) / W(0) below covers them
   stage_a(0); stage_w(0); stage_w(1); stage_a(1);
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  v3_acc_zero<4 * MI * NJ, 0>();
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MI + NJ) : "memory");        // A(0), W(0)
   __builtin_amdgcn_s_barrier();
   // 32-byte operands: words 0..3 = chunk fq, words 4..7 = chunk 4 + fq of the lane's row.  ONE register set for A: row tile i's fragment of tile
@@ -1956,20 +1961,22 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
   // (the host pass parses this body too, and x86's "v" constraint does not take a 256-bit operand without AVX: the function would be dropped
   // from the host object -- silently, as a deferred diagnostic -- and its launch stub with it)
 #if defined(__HIP_DEVICE_COMPILE__)
-#define V3F8_ONE(ACC, A_, B_) asm volatile("v_mfma_f32_16x16x128_f8f6f4 %0, %1, %2, %0" : "+a"(ACC) : "v"(A_), "v"(B_))
+#define V3F8_ONE(TILE, A_, B_) \
+  asm volatile("v_mfma_f32_16x16x128_f8f6f4 a[%c0:%c1], %2, %3, a[%c0:%c1]" ::"n"(4 * (TILE)), "n"(4 * (TILE) + 3), "v"(A_), "v"(B_))
   // scaled form: src A = the weight fragment (scale 2^0: byte 0 of `one`), src B = the activation fragment, its scale = byte BT of SC
-#define V3F8_SC(ACC, A_, B_, SC, OPS) \
-  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " OPS : "+a"(ACC) : "v"(A_), "v"(B_), "v"(mx_one), "v"(SC))
+#define V3F8_SC(TILE, A_, B_, SC, OPS)                                                                                                                   \
+  asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 a[%c0:%c1], %2, %3, a[%c0:%c1], %4, %5 " OPS ::"n"(4 * (TILE)), "n"(4 * (TILE) + 3), "v"(A_), "v"(B_), \
+               "v"(mx_one), "v"(SC))
 #else
-#define V3F8_ONE(ACC, A_, B_) (void)(ACC)
-#define V3F8_SC(ACC, A_, B_, SC, OPS) (void)(ACC)
+#define V3F8_ONE(TILE, A_, B_) (void)(A_)
+#define V3F8_SC(TILE, A_, B_, SC, OPS) (void)(A_)
 #endif
-#define V3F8_MFMA(BT, ACC, A_, B_, SC)                                                        \
-  if constexpr (!MX) V3F8_ONE(ACC, A_, B_);                                                   \
-  else if constexpr ((BT) == 0) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,0,0]"); \
-  else if constexpr ((BT) == 1) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,0,0]"); \
-  else if constexpr ((BT) == 2) V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,1,0]"); \
-  else V3F8_SC(ACC, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,1,0]")
+#define V3F8_MFMA(BT, TILE, A_, B_, SC)                                                        \
+  if constexpr (!MX) V3F8_ONE(TILE, A_, B_);                                                   \
+  else if constexpr ((BT) == 0) V3F8_SC(TILE, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,0,0]"); \
+  else if constexpr ((BT) == 1) V3F8_SC(TILE, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,0,0]"); \
+  else if constexpr ((BT) == 2) V3F8_SC(TILE, A_, B_, SC, "op_sel:[0,0,0] op_sel_hi:[0,1,0]"); \
+  else V3F8_SC(TILE, A_, B_, SC, "op_sel:[0,1,0] op_sel_hi:[0,1,0]")
   // One K-tile.  MORE: tile t+2 exists -> issue its DMA (compile-time: a scalar branch around each DMA issue costs the lone wave ~30 cycles of
   // instruction refetch).  Memory instruction behind MFMA m (at most one per gap):
   //   phase 0   even m < 16: W(t+2) piece m / 2 | odd m < 16: W_hi(t) half (m - 1) / 2 | m = 16, 17: A(t) row tile 7 (first used by MFMA 28)
@@ -1985,18 +1992,27 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
     {
       const uint64_t wsrc_u = v3_uniform_u64((uintptr_t)(wbase + (int64_t)(t + 2) * KB));
       char* wdst = smem_w + ((t + 2) % 3) * W_SLOT;
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        V3F8_MFMA(bt, acc[m / NH][m % NH], bl[m % NH], af[m / NH], sc_cur[MX ? m / NH : 0]);
-        V3_FENCE();
-        if (m < 16 && (m & 1)) { const int r = m >> 1; ld_at(bh[r >> 1], r & 1, pw[r & 1], NH + (r >> 1)); }
-        if (m < 16 && !(m & 1) && more) {
-          const int q = m >> 1;
-          V3_DMA(wsrc_u, woff[q], wdst + (q * V3_THREADS + wave * 64) * 16);
+      static_for<NM>([&](auto m_c) AFX_INL {
+        constexpr int m = decltype(m_c)::value;
+        {
+          const i32x8_t& wa_ = bl[m % NH];              // (locals: operands of an asm statement inside a generic lambda do not capture by themselves)
+          const i32x8_t& xa_ = af[m / NH];
+          const uint32_t sc_ = sc_cur[MX ? m / NH : 0];
+          (void)sc_;
+          V3F8_MFMA(bt, (m / NH) * NJ + m % NH, wa_, xa_, sc_);
         }
-        if (m == 16 || m == 17) ld_at(af[MI - 1], m - 16, pa[m - 16], MI - 1);
         V3_FENCE();
-      }
+        if constexpr (m < 16 && (m & 1)) { constexpr int r = m >> 1; ld_at(bh[r >> 1], r & 1, pw[r & 1], NH + (r >> 1)); }
+        if constexpr (m < 16 && !(m & 1) && more) {
+          constexpr int q = m >> 1;
+          const uint64_t src_ = wsrc_u;
+          const uint32_t off_ = woff[q];
+          char* const dst_ = wdst + (q * V3_THREADS + wave * 64) * 16;
+          V3_DMA(src_, off_, dst_);
+        }
+        if constexpr (m == 16 || m == 17) ld_at(af[MI - 1], m - 16, pa[m - 16], MI - 1);
+        V3_FENCE();
+      });
     }
     if constexpr (more) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NJ) : "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -2007,21 +2023,30 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
       uint32_t na[2], nw[2];
       slot_bases(smem + ((t + 1) & 1) * A_SLOT, la0, la1, na);
       slot_bases(smem_w + ((t + 1) % 3) * W_SLOT, lb0, lb1, nw);
-#pragma unroll
-      for (int m = 0; m < NM; ++m) {
-        V3F8_MFMA(bt, acc[m / NH][NH + m % NH], bh[m % NH], af[m / NH], sc_cur[MX ? m / NH : 0]);
+      static_for<NM>([&](auto m_c) AFX_INL {
+        constexpr int m = decltype(m_c)::value;
+        {
+          const i32x8_t& wa_ = bh[m % NH];
+          const i32x8_t& xa_ = af[m / NH];
+          const uint32_t sc_ = sc_cur[MX ? m / NH : 0];
+          (void)sc_;
+          V3F8_MFMA(bt, (m / NH) * NJ + NH + m % NH, wa_, xa_, sc_);
+        }
         V3_FENCE();
         constexpr int kind[32] = {1, 1, 1, 1, 2, 2, 1, 1, 2, 2, 1, 1, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 3, 3, 2, 2, 0, 0};   // 1 W_lo, 2 A, 3 DMA
         constexpr int arg[32] = {0, 1, 2, 3, 0, 1, 4, 5, 2, 3, 6, 7, 4, 5, 0, 1, 6, 7, 2, 3, 8, 9, 4, 5, 10, 11, 6, 7, 12, 13, 0, 0};
         // (MI = 7, the 224x256 shape: the same table cut at 28 MFMAs -- row tiles 0..5 are read where the 8-row table reads them, the seventh DMA piece
         // sits at m = 26 and the table's eighth is dropped)
-        if (kind[m] == 1) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
-        else if (kind[m] == 2 && (arg[m] >> 1) < MI - 1) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
-        else if (kind[m] == 3 && arg[m] < MI) {
-          if constexpr (more) V3_DMA(asrc_u, aoff[arg[m]], adst + (arg[m] * V3_THREADS + wave * 64) * 16);
+        if constexpr (kind[m] == 1) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
+        else if constexpr (kind[m] == 2 && (arg[m] >> 1) < MI - 1) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
+        else if constexpr (kind[m] == 3 && arg[m] < MI && more) {
+          const uint64_t src_ = asrc_u;
+          const uint32_t off_ = aoff[arg[m]];
+          char* const dst_ = adst + (arg[m] * V3_THREADS + wave * 64) * 16;
+          V3_DMA(src_, off_, dst_);
         }
         V3_FENCE();
-      }
+      });
       if constexpr (fetch) mx_fetch(sc_nxt, (t >> 2) + 1);
     }
   };
@@ -2059,17 +2084,17 @@ __global__ __launch_bounds__(V3_THREADS, 1) void gemm_kernel_v3f8(const GemmBatc
     tile(F_{}, t, I0{}, F_{});
     tile(F_{}, t + 1, I0{}, F_{});
   }
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" : "+a"(acc[MI - 1][NJ - 4]), "+a"(acc[MI - 1][NJ - 3]), "+a"(acc[MI - 1][NJ - 2]), "+a"(acc[MI - 1][NJ - 1])::"memory");
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");       // MFMA -> accumulator-read wait states (hipcc does not know the dependency)
   {
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
     if (Q.c8 != nullptr && n0 + wc2 * (16 * NJ) >= Q.c8_col0) {       // (uniform) this wave's 128 columns go out as the next GEMM's block-scaled operand
-      if (Q.epi == EPI_GELU) epi_store_mx8<true, MI, NJ>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
-      else epi_store_mx8<false, MI, NJ>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+      if (Q.epi == EPI_GELU) epi_store_mx8<true, MI, NJ, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
+      else epi_store_mx8<false, MI, NJ, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
     } else
-    epi_store_fast_any<MI, NJ, true, true, false>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2);
+    epi_store_fast_any_acc<MI, NJ, true, true, false, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
   }
 }
 
@@ -2085,6 +2110,9 @@ LaunchTimer& launch_timer() {
 #ifdef V3_KERNELS_ONLY      // experiment builds (register-allocation turnarounds in seconds, never the product): `-DV3_KERNELS_ONLY="8,8,false,0"` compiles ONE instance of
 template __global__ void gemm_kernel_v3<V3_KERNELS_ONLY>(const GemmBatch);      // gemm_kernel_v3 and none of the launchers
 template __global__ void gemm_kernel_v3s<4, 4, false, 0>(const GemmBatch);
+#ifdef V3F8_ONLY
+template __global__ void gemm_kernel_v3f8<V3F8_ONLY>(const GemmBatch);
+#endif
 }  // namespace afx
 #else
 // ---- tile shape / kernel choice -------------------------------------------------------------------------------------------
