@@ -711,6 +711,11 @@ AFX_DEV void epi_store_fast_any_acc(const GemmProblem& P, const ACC& acc, int ro
   if constexpr (NJ == 8 && SWAP && !PRE) {
     if (P.qk_D > 0) {                                            // (uniform) which 128-column head of k | v | q (| mlp) is this wave's?
       const int region = col_base / P.qk_D;
+      if constexpr (FP8) {        // (the fp8 form holds weight scales + cos / sin beside bias and RMSNorm weights: with the tail's fragment ring it needs > 256 arch VGPRs -- hipcc then
+                                  // parks values in accumulator registers, which the build's audit refuses: it runs the tail's MFMAs up front)
+        if (region == 0) { hk.all(); epi_store_qk_acc<MI, FP8, NoHook>(P, acc, row_base, col_base, frow, fq, P.qk_wk, NoHook{}); return; }
+        if (region == 2) { hk.all(); epi_store_qk_acc<MI, FP8, NoHook>(P, acc, row_base, col_base, frow, fq, P.qk_wq, NoHook{}); return; }
+      }
       if (region == 0) { epi_store_qk_acc<MI, FP8, HK>(P, acc, row_base, col_base, frow, fq, P.qk_wk, hk); return; }
       if (region == 2) { epi_store_qk_acc<MI, FP8, HK>(P, acc, row_base, col_base, frow, fq, P.qk_wq, hk); return; }
     }
@@ -1336,6 +1341,9 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel_v2(const GemmBatc
 //   * epilogue: epi_store_fast_any_acc on the asm-owned accumulator file (AccLit); round 6: the last K-tile's MFMAs are issued from inside it (TAIL, below).
 #ifndef V3_EXP
 #define V3_EXP 0
+#endif
+#ifndef V3F8_TAIL            // the same for the fp8 kernel (gemm_kernel_v3f8)
+#define V3F8_TAIL 1
 #endif
 #ifndef V3_TAIL              // 0: the last K-tile in front of the epilogue (round 5's schedule; A/B builds)
 #define V3_TAIL 1
@@ -1982,8 +1990,9 @@ __global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))
   //   phase 0   even m < 16: W(t+2) piece m / 2 | odd m < 16: W_hi(t) half (m - 1) / 2 | m = 16, 17: A(t) row tile 7 (first used by MFMA 28)
   //   phase 1   m = 0..3, 6, 7, 10, 11: W_lo(t+1) halves | m = 4 i + 4, 4 i + 5 (i < 7): A(t+1) row tile i (free since MFMA 4 i + 3)
   //             m = 14, 15, 18, 19, 22, 23, 26, 27: A(t+2) pieces 0..7
-  auto tile = [&](auto MORE_, int t, auto BT_, auto FETCH_) {
+  auto tile = [&](auto MORE_, int t, auto BT_, auto FETCH_, auto NOREAD_) {
     constexpr bool more = decltype(MORE_)::value;
+    constexpr bool noread = decltype(NOREAD_)::value;     // the next tile is the TAIL (below): it reads its fragments itself -- no pre-reads of tile t + 1 here
     constexpr int bt = decltype(BT_)::value;            // MX: byte of the scale dwords = tile index inside its group of 4
     constexpr bool fetch = decltype(FETCH_)::value;     // MX: request the next group's scale dwords behind this tile's A DMA
     uint32_t pa[2], pw[2];
@@ -2037,8 +2046,8 @@ __global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))
         constexpr int arg[32] = {0, 1, 2, 3, 0, 1, 4, 5, 2, 3, 6, 7, 4, 5, 0, 1, 6, 7, 2, 3, 8, 9, 4, 5, 10, 11, 6, 7, 12, 13, 0, 0};
         // (MI = 7, the 224x256 shape: the same table cut at 28 MFMAs -- row tiles 0..5 are read where the 8-row table reads them, the seventh DMA piece
         // sits at m = 26 and the table's eighth is dropped)
-        if constexpr (kind[m] == 1) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
-        else if constexpr (kind[m] == 2 && (arg[m] >> 1) < MI - 1) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
+        if constexpr (kind[m] == 1 && !noread) ld_at(bl[arg[m] >> 1], arg[m] & 1, nw[arg[m] & 1], arg[m] >> 1);
+        else if constexpr (kind[m] == 2 && (arg[m] >> 1) < MI - 1 && !noread) ld_at(af[arg[m] >> 1], arg[m] & 1, na[arg[m] & 1], arg[m] >> 1);
         else if constexpr (kind[m] == 3 && arg[m] < MI && more) {
           const uint64_t src_ = asrc_u;
           const uint32_t off_ = aoff[arg[m]];
@@ -2056,6 +2065,11 @@ __global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))
   using I3 = std::integral_constant<int, 3>;
   using T_ = std::true_type;
   using F_ = std::false_type;
+  // TAIL (round 6, as gemm_kernel_v3's): the LAST K-tile is not multiplied in front of the epilogue but from inside it, row tile by row tile (NJ MFMAs of 32
+  // cycles each per row tile, one at every second hook point of the previous row tile's steps).  Everything tile nk - 1 needs has landed at the mid-tile
+  // barrier of tile nk - 2 (its wait is vmcnt(0)); per accumulator the order of the K-tiles is unchanged: bit-identical results (-DV3F8_TAIL=0).
+  constexpr bool TAIL = V3F8_TAIL != 0;
+  using TL = std::integral_constant<bool, TAIL>;
   int t = 0;
   if constexpr (MX) {
     // nk = 4 G tiles; the first group's scales were requested in front of the prologue's DMA
@@ -2068,33 +2082,95 @@ __global__ __launch_bounds__(V3_THREADS, 1) __attribute__((amdgpu_num_vgpr(256))
     take();
 #pragma unroll 1
     for (; t < nk - 4; t += 4) {
-      tile(T_{}, t, I0{}, F_{});
-      tile(T_{}, t + 1, I1{}, T_{});
-      tile(T_{}, t + 2, I2{}, F_{});            // its mid-tile wait leaves only W(t+4) in flight: the scale dwords have landed
-      tile(T_{}, t + 3, I3{}, F_{});
+      tile(T_{}, t, I0{}, F_{}, F_{});
+      tile(T_{}, t + 1, I1{}, T_{}, F_{});
+      tile(T_{}, t + 2, I2{}, F_{}, F_{});            // its mid-tile wait leaves only W(t+4) in flight: the scale dwords have landed
+      tile(T_{}, t + 3, I3{}, F_{}, F_{});
       take();
     }
-    tile(T_{}, t, I0{}, F_{});
-    tile(T_{}, t + 1, I1{}, F_{});
-    tile(F_{}, t + 2, I2{}, F_{});
-    tile(F_{}, t + 3, I3{}, F_{});
+    tile(T_{}, t, I0{}, F_{}, F_{});
+    tile(T_{}, t + 1, I1{}, F_{}, F_{});
+    tile(F_{}, t + 2, I2{}, F_{}, TL{});
+    if constexpr (!TAIL) tile(F_{}, t + 3, I3{}, F_{}, F_{});
   } else {
 #pragma unroll 1
-    for (; t < nk - 2; ++t) tile(T_{}, t, I0{}, F_{});
-    tile(F_{}, t, I0{}, F_{});
-    tile(F_{}, t + 1, I0{}, F_{});
+    for (; t < nk - 2; ++t) tile(T_{}, t, I0{}, F_{}, F_{});
+    tile(F_{}, t, I0{}, F_{}, TL{});                  // (nk >= 2: the launcher sends K >= 256 here)
+    if constexpr (!TAIL) tile(F_{}, t + 1, I0{}, F_{}, F_{});
   }
-  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");       // MFMA -> accumulator-read wait states (hipcc does not know the dependency)
+  if constexpr (!TAIL) asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");       // MFMA -> accumulator-read wait states (hipcc does not know the dependency)
   {
     int tid2 = threadIdx.x;
     asm volatile("" : "+v"(tid2));
     const int lane2 = tid2 & 63, wave2 = __builtin_amdgcn_readfirstlane(tid2 >> 6);
     const int wr2 = wave2 >> 1, wc2 = wave2 & 1, frow2 = lane2 & 15, fq2 = lane2 >> 4;
-    if (Q.c8 != nullptr && n0 + wc2 * (16 * NJ) >= Q.c8_col0) {       // (uniform) this wave's 128 columns go out as the next GEMM's block-scaled operand
-      if (Q.epi == EPI_GELU) epi_store_mx8<true, MI, NJ, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
-      else epi_store_mx8<false, MI, NJ, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
-    } else
-    epi_store_fast_any_acc<MI, NJ, true, true, false, NoHook>(Q, acc, m0 + wr2 * (16 * MI), n0 + wc2 * (16 * NJ), frow2, fq2, NoHook{});
+    const int rb = m0 + wr2 * (16 * MI), cb = n0 + wc2 * (16 * NJ);
+    auto epilogue = [&](const auto& hk) AFX_INL {
+      using HK = std::decay_t<decltype(hk)>;
+      if (Q.c8 != nullptr && cb >= Q.c8_col0) {       // (uniform) this wave's 128 columns go out as the next GEMM's block-scaled operand
+        if (Q.epi == EPI_GELU) epi_store_mx8<true, MI, NJ, HK>(Q, acc, rb, cb, frow2, fq2, hk);
+        else epi_store_mx8<false, MI, NJ, HK>(Q, acc, rb, cb, frow2, fq2, hk);
+      } else
+        epi_store_fast_any_acc<MI, NJ, true, true, false, HK>(Q, acc, rb, cb, frow2, fq2, hk);
+    };
+    if constexpr (TAIL) {
+      // tile nk - 1: every fragment is read here, out of the slots it landed in, a few MFMAs ahead of its use: W fragments (32 bytes per lane = two reads) through
+      // a ring of RING register sets -- every row tile re-reads its NJ W fragments: the epilogues' own state sits beside all accumulators --, A one row tile ahead
+      const int tl = nk - 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int arow2 = wr2 * (16 * MI) + frow2, brow2 = wc2 * (16 * NJ) + frow2;      // (from the opaque thread id: nothing of the tail's addressing is live across the main loop)
+      const uint32_t ta0_ = (uint32_t)(arow2 * 128 + (((0 + fq2) ^ ((arow2 >> 1) & 7)) << 4)), ta1_ = (uint32_t)(arow2 * 128 + (((4 + fq2) ^ ((arow2 >> 1) & 7)) << 4));
+      const uint32_t tb0_ = (uint32_t)(brow2 * 128 + (((0 + fq2) ^ ((brow2 >> 1) & 7)) << 4)), tb1_ = (uint32_t)(brow2 * 128 + (((4 + fq2) ^ ((brow2 >> 1) & 7)) << 4));
+      uint32_t pa[2], pw[2];
+      slot_bases(smem + (tl & 1) * A_SLOT, ta0_, ta1_, pa);
+      slot_bases(smem_w + (tl % 3) * W_SLOT, tb0_, tb1_, pw);
+      constexpr int RING = 2, PTS = 16, NA = 2;
+      constexpr int BT_LAST = 3;                           // MX: nk is a multiple of 4, the last tile is byte 3 of its scale dwords
+      i32x8_t tw[RING], ta[NA];
+      auto w_of = [&](i32x8_t& f, int g) { ld_at(f, 0, pw[0], g % NJ); ld_at(f, 1, pw[1], g % NJ); };      // W fragment of tail MFMA g = row * NJ + j
+      auto a_of = [&](i32x8_t& f, int row) { ld_at(f, 0, pa[0], row); ld_at(f, 1, pa[1], row); };
+      auto prime = [&]() {
+#pragma unroll
+        for (int g = 0; g < RING; ++g) w_of(tw[g], g);
+        a_of(ta[0], 0);
+      };
+      auto tail_mfma = [&](auto row_c, auto j_c) AFX_INL {
+        constexpr int row = decltype(row_c)::value, j = decltype(j_c)::value, g = row * NJ + j;
+        {
+          const i32x8_t& wa_ = tw[g % RING];
+          const i32x8_t& xa_ = ta[row % NA];
+          const uint32_t sc_ = sc_cur[MX ? row : 0];
+          (void)sc_;
+          V3F8_MFMA(BT_LAST, row * NJ + j, wa_, xa_, sc_);
+        }
+        V3_FENCE();
+        if constexpr (g + RING < MI * NJ) w_of(tw[g % RING], g + RING);
+        if constexpr (j == (NA == 2 ? 2 : NJ - 1) && row + 1 < MI) a_of(ta[(row + 1) % NA], row + 1);
+        V3_FENCE();
+      };
+      auto hook = [&](auto code_c) AFX_INL {
+        constexpr int code = decltype(code_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (code == -1) {                                    // row tile 0, behind the epilogue's preamble
+          prime();
+          static_for<NJ>([&](auto j_c) AFX_INL { tail_mfma(std::integral_constant<int, 0>{}, j_c); });
+          asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        } else if constexpr (code == -2) {                             // everything at once (an epilogue without hook points)
+          prime();
+          static_for<MI>([&](auto r_c) AFX_INL { static_for<NJ>([&](auto j_c) AFX_INL { tail_mfma(r_c, j_c); }); });
+          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+        } else {
+          constexpr int row = code / PTS + 1, pt = code % PTS;         // one MFMA at every second point (NJ MFMAs, 16 points per row tile)
+          if constexpr (row < MI && pt % 2 == 0 && pt / 2 < NJ) tail_mfma(std::integral_constant<int, row>{}, std::integral_constant<int, pt / 2>{});
+          if constexpr (row < MI && pt == PTS - 1) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      const TailHook<decltype(hook)> hk{hook};
+      epilogue(hk);
+    } else {
+      epilogue(NoHook{});
+    }
   }
 }
 
